@@ -1,0 +1,62 @@
+/*
+ * glrt_host.h -- C ABI of libglrt_host.so: host-side (CPU) helpers that sit
+ * next to the device path: BVH construction into the reference's flat
+ * 'u_bvhBuffer' format and the camera matrices the reference computes with GLM.
+ * No GPU, no HIP; loadable on any box.
+ *
+ * Reference interfaces replaced:
+ *   glrt_bvh_build_sah      BVH::construct / constructRec   src/core/bvh.cpp:59-160
+ *   glrt_bvh_build_chain    (no counterpart: expresses BASELINE config "brute force, no BVH"
+ *                            in the same node format)
+ *   glrt_look_at            glm::lookAt                     src/core/scene.cpp:93
+ *   glrt_perspective        glm::perspective(radians(fov))  src/core/scene.cpp:113
+ *   glrt_mat4_inverse/_mul  glm::inverse, operator*         src/core/window.cpp:230-233
+ *   glrt_frame_seed         per-frame u_seed draw           src/core/window.cpp:226-238
+ *                            (the reference draws from mt19937(random_device); this is the
+ *                             deterministic sequence SURVEY.md section 8(d) fixes)
+ * All matrices are column-major float[16] exactly as uploaded by
+ * glUniformMatrix4fv(..., GL_FALSE, ...) (shader_program.cpp:151-156).
+ */
+#ifndef GLRT_HOST_H
+#define GLRT_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLRT_HOST_OK 0
+#define GLRT_HOST_EINVAL (-1) /* null pointer / empty input */
+#define GLRT_HOST_EINDEX (-2) /* triangle references a vertex out of range */
+#define GLRT_HOST_EDEPTH (-3) /* tree deeper than the 64-entry traversal stack allows */
+
+/* floats per Vertex record in u_vertBuffer: pos, normal, uv, tangent, binormal (trimesh.h:15-25) */
+#define GLRT_VERTEX_FLOATS 15
+/* floats per Material record in u_matBuffer: 6 x vec3 (scene.h:28-35) */
+#define GLRT_MATERIAL_FLOATS 18
+/* floats per BVH node in u_bvhBuffer: 3 x vec3 (bvh.h:84-100) */
+#define GLRT_BVHNODE_FLOATS 9
+
+/* 2*n_tri-1 (one triangle per leaf), 0 for an empty scene. */
+size_t glrt_bvh_node_count(size_t n_tri);
+
+/* vert: n_vert * GLRT_VERTEX_FLOATS, tri: n_tri * 4 (i, j, k, material) as floats.
+ * nodes_out: glrt_bvh_node_count(n_tri) * 9 floats.  max_depth_out may be NULL. */
+int glrt_bvh_build_sah(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
+                       int *max_depth_out);
+int glrt_bvh_build_chain(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out);
+
+void glrt_look_at(const float eye[3], const float center[3], const float up[3], float out[16]);
+void glrt_perspective(float fovy_deg, float aspect, float z_near, float z_far, float out[16]);
+void glrt_mat4_mul(const float a[16], const float b[16], float out[16]);
+/* returns 0, or GLRT_HOST_EINVAL for a singular matrix */
+int glrt_mat4_inverse(const float m[16], float out[16]);
+/* frame f -> (fract(0.137 + 0.6180340 f), fract(0.731 + 0.3819660 f)) */
+void glrt_frame_seed(uint32_t frame, float out[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

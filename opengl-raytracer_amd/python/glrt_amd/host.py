@@ -1,0 +1,96 @@
+"""ctypes binding of libglrt_host.so (include/glrt_host.h): BVH builders and camera matrices.
+
+CPU-only; loadable without a GPU.  Raises if the library has not been built
+(`make -C opengl-raytracer_amd host` or `__graft_entry__.build()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+
+import numpy as np
+
+PKG_ROOT = pathlib.Path(__file__).resolve().parents[2]
+LIB_DIR = PKG_ROOT / "lib"
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = LIB_DIR / "libglrt_host.so"
+        if not path.exists():
+            raise RuntimeError(f"{path} is missing: run `make -C {PKG_ROOT}` (or __graft_entry__.build())")
+        L = C.CDLL(str(path))
+        fp = C.POINTER(C.c_float)
+        L.glrt_bvh_node_count.restype = C.c_size_t
+        L.glrt_bvh_node_count.argtypes = [C.c_size_t]
+        L.glrt_bvh_build_sah.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
+        L.glrt_bvh_build_chain.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp]
+        L.glrt_look_at.argtypes = [fp, fp, fp, fp]
+        L.glrt_perspective.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, fp]
+        L.glrt_mat4_mul.argtypes = [fp, fp, fp]
+        L.glrt_mat4_inverse.argtypes = [fp, fp]
+        L.glrt_frame_seed.argtypes = [C.c_uint32, fp]
+        _lib = L
+    return _lib
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def build_bvh(vert: np.ndarray, tri: np.ndarray, kind: str = "sah"):
+    """vert: (nV*5, 3) float32 texels, tri: (nT, 4).  Returns (nodes (nN*3, 3) float32, max_depth)."""
+    L = lib()
+    vert = _f32(vert).reshape(-1, 15)
+    tri = _f32(tri).reshape(-1, 4)
+    n = int(L.glrt_bvh_node_count(tri.shape[0]))
+    nodes = np.zeros((n * 3, 3), np.float32)
+    depth = C.c_int(0)
+    if kind == "sah":
+        rc = L.glrt_bvh_build_sah(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
+    elif kind == "chain":
+        rc = L.glrt_bvh_build_chain(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes))
+        depth.value = 2
+    else:
+        raise ValueError(kind)
+    if rc != 0:
+        raise RuntimeError(f"glrt_bvh_build_{kind} failed: {rc}")
+    return nodes, depth.value
+
+
+def look_at(eye, center, up) -> np.ndarray:
+    out = np.zeros(16, np.float32)
+    lib().glrt_look_at(_fp(_f32(eye)), _fp(_f32(center)), _fp(_f32(up)), _fp(out))
+    return out
+
+
+def perspective(fovy_deg, aspect, z_near, z_far) -> np.ndarray:
+    out = np.zeros(16, np.float32)
+    lib().glrt_perspective(fovy_deg, aspect, z_near, z_far, _fp(out))
+    return out
+
+
+def mat4_inverse(m) -> np.ndarray:
+    out = np.zeros(16, np.float32)
+    if lib().glrt_mat4_inverse(_fp(_f32(m)), _fp(out)) != 0:
+        raise RuntimeError("singular matrix")
+    return out
+
+
+def mat4_mul(a, b) -> np.ndarray:
+    out = np.zeros(16, np.float32)
+    lib().glrt_mat4_mul(_fp(_f32(a)), _fp(_f32(b)), _fp(out))
+    return out
+
+
+def frame_seed(frame: int):
+    out = np.zeros(2, np.float32)
+    lib().glrt_frame_seed(frame, _fp(out))
+    return float(out[0]), float(out[1])
