@@ -1,0 +1,148 @@
+/*
+ * glrtx.h -- C ABI of libglrtx.so, the MI355X (gfx950) device layer that replaces the
+ * GL side of tatsy/opengl-raytracer's per-pixel path-tracing pass.
+ *
+ * Drop-in boundary.  What each entry point replaces in the reference:
+ *
+ *   glrtx_create / glrtx_destroy     GL context + program setup: Window::Window, Window::initialize
+ *                                    src/core/window.cpp:30-81, :185-211
+ *   glrtx_upload_scene               the five TextureBuffer(size, fmt, usage) + setData(ptr) uploads
+ *                                    src/core/scene.cpp:254-269, src/core/texture_buffer.h:8-12
+ *                                    (byte layouts unchanged: scene.h:16-35, trimesh.h:15-25, bvh.h:84-100)
+ *   glrtx_resize                     Window::resize -> resetBuffer (accumulators re-created, cleared)
+ *                                    src/core/window.cpp:324-335, :366-381
+ *   glrtx_clear                      glClear of the accumulation targets on reset (same lines)
+ *   glrtx_render                     first half of Window::render(): uniform upload + the single
+ *                                    glDrawArrays(GL_TRIANGLES, 0, 6) that runs raytrace.frag on every pixel
+ *                                    src/core/window.cpp:213-295; shader src/shaders/raytrace.frag:565-614
+ *   glrtx_params                     the uniforms set per frame, window.cpp:230-243, plus u_maxDepth which
+ *                                    the reference leaves at its shader default 16 (raytrace.frag:47)
+ *   glrtx_read_accum                 reading fbo[select] colour attachments 0/1 (RGB32F + R32F)
+ *                                    src/core/window.cpp:366-381; fused here into float4(L.rgb, count)
+ *   glrtx_resolve_rgba8              second half of Window::render() (screen.frag: rgb/count, clamp, gamma)
+ *                                    + saveCurrentFrame's read-back and vertical flip
+ *                                    src/shaders/screen.frag:15-25, src/core/window.cpp:297-317, :383-414
+ *   glrtx_set_partition / glrtx_bind_accum / glrtx_set_stream
+ *                                    no counterpart (reference is single-GPU): row-stripe sharding across
+ *                                    one-process-per-GPU ranks, SURVEY.md section 8(e)
+ *   glrtx_stats / glrtx_timer_*      replaces the whole-frame Timer, src/core/timer.h:7-36, window.cpp:119-168
+ *   glrtx_last_error                 replaces FatalError's stderr + abort(), src/core/common.h:88-94
+ *
+ * Conventions: plain C, no torch / HIP types in signatures.  Host pointers are borrowed for the
+ * duration of a call and copied; the ctx owns all device memory it allocates; the caller owns
+ * output buffers.  Return value 0 = ok, negative = GLRTX_E*; the message is available from
+ * glrtx_last_error(ctx) (ctx may be NULL for create-time failures).  One host thread drives a ctx.
+ * Image rows use GL orientation: row 0 is gl_FragCoord.y = 0.5 (bottom), like the reference's FBOs.
+ */
+#ifndef GLRTX_H
+#define GLRTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLRTX_OK 0
+#define GLRTX_EINVAL (-1)   /* bad argument / call order */
+#define GLRTX_EDEVICE (-2)  /* HIP runtime error or no usable gfx950 device */
+#define GLRTX_ESCENE (-3)   /* scene buffers inconsistent (index out of range, BVH not a tree) */
+#define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
+#define GLRTX_ENOMEM (-5)
+
+#define GLRTX_ABI_VERSION 1
+
+typedef struct glrtx_ctx glrtx_ctx;
+
+/* Per-frame uniforms (window.cpp:230-243).  Matrices are column-major, untransposed, exactly the
+ * 16 floats glUniformMatrix4fv(..., GL_FALSE, ...) receives (shader_program.cpp:151-156). */
+typedef struct glrtx_params {
+    float c2w[16];   /* u_c2wMat = inverse(viewM * modelM) */
+    float s2c[16];   /* u_s2cMat = inverse(projM) */
+    float aperture;  /* u_apertureRadius */
+    float focal;     /* u_focalLength */
+    float seed[2];   /* u_seed */
+    int32_t n_samples; /* u_nSamples (reference host sends 1, window.cpp:239) */
+    int32_t max_depth; /* u_maxDepth ("k bounces" := k) */
+} glrtx_params;
+
+typedef struct glrtx_stats {
+    uint64_t rays;          /* executions of intersect(Ray, out Intersection) since last clear/reset_stats;
+                               only counted by launches made while ray counting is enabled */
+    uint64_t paths;         /* pixel samples traced (owned pixels * n_samples per launch) */
+    uint64_t launches;      /* glrtx_render calls */
+    double kernel_ms_total; /* sum of per-launch device time (HIP events on the ctx stream) */
+    float kernel_ms_last;
+    int32_t width, height;  /* full image */
+    int32_t owned_rows;     /* rows of this ctx's partition */
+    int32_t stack_entries;  /* traversal stack entries the uploaded BVH needs */
+    int32_t lds_bytes;      /* dynamic LDS per workgroup of the render kernel */
+    int32_t n_tri, n_fork, n_mat, n_light;
+} glrtx_stats;
+
+int glrtx_abi_version(void);
+
+/* device_id: HIP ordinal, or -1 for the current device. */
+int glrtx_create(glrtx_ctx **out, int device_id);
+void glrtx_destroy(glrtx_ctx *ctx);
+const char *glrtx_last_error(const glrtx_ctx *ctx);
+
+/* Buffers in the reference wire format; counts are in records (vertices, triangles, materials,
+ * light triangles, BVH nodes).  n_light may be 0.  The scene is validated and repacked for the
+ * device; it replaces any previous scene. */
+int glrtx_upload_scene(glrtx_ctx *ctx, const float *vert, size_t n_vert, const float *tri, size_t n_tri,
+                       const float *mat, size_t n_mat, const float *light, size_t n_light, const float *bvh,
+                       size_t n_nodes);
+
+/* Host-only (no device, no ctx): run the validation and repacking glrtx_upload_scene performs and
+ * report the interior-node count and the traversal stack entries the BVH needs.  On failure the
+ * message is available from glrtx_last_error(NULL). */
+int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat, size_t n_mat,
+                      const float *light, size_t n_light, const float *bvh, size_t n_nodes, int *n_fork_out,
+                      int *stack_entries_out);
+
+/* Full image size; (re)allocates and clears this ctx's accumulator rows. */
+int glrtx_resize(glrtx_ctx *ctx, int width, int height);
+int glrtx_clear(glrtx_ctx *ctx);
+
+/* Row-stripe partition for multi-GPU: this ctx owns stripes s (of stripe_rows rows) with
+ * s % world == rank; its accumulator holds only those rows, in increasing y, pixel coordinates
+ * stay global.  Default (rank 0, world 1) owns everything.  Must precede glrtx_resize. */
+int glrtx_set_partition(glrtx_ctx *ctx, int rank, int world, int stripe_rows);
+/* Global y of local accumulator row r (r in [0, owned_rows)), or -1. */
+int glrtx_local_row_to_y(const glrtx_ctx *ctx, int local_row);
+
+/* Optional: render into caller-owned device memory (e.g. a torch tensor that RCCL gathers)
+ * instead of the ctx's own buffer: owned_rows rows of pitch_bytes, width float4 each.  NULL unbinds. */
+int glrtx_bind_accum(glrtx_ctx *ctx, void *device_ptr, size_t pitch_bytes);
+/* Optional: launch on a caller-owned hipStream_t (passed as void*); NULL restores the ctx stream. */
+int glrtx_set_stream(glrtx_ctx *ctx, void *hip_stream);
+
+/* Enable/disable per-launch ray counting (one atomic per wavefront); default off. */
+int glrtx_count_rays(glrtx_ctx *ctx, int enable);
+
+/* Asynchronous: accumulates n_samples new samples per owned pixel (read-modify-write). */
+int glrtx_render(glrtx_ctx *ctx, const glrtx_params *params);
+int glrtx_sync(glrtx_ctx *ctx);
+
+/* Copy the owned rows (owned_rows x width float4) to host memory; implies a sync. */
+int glrtx_read_accum(glrtx_ctx *ctx, float *dst_rgba, size_t dst_pitch_bytes);
+/* Device address / pitch of the accumulator currently rendered into. */
+int glrtx_accum_device_ptr(const glrtx_ctx *ctx, void **ptr_out, size_t *pitch_bytes_out);
+
+/* Tonemap the owned rows to RGBA8: clamp(rgb/count, 0, 1)^(1/gamma), alpha 255.  If flip_y, row 0 of
+ * dst is the top image row (as written by the reference's saveCurrentFrame).  Implies a sync. */
+int glrtx_resolve_rgba8(glrtx_ctx *ctx, uint8_t *dst, size_t dst_pitch_bytes, float gamma, int flip_y);
+
+int glrtx_get_stats(const glrtx_ctx *ctx, glrtx_stats *out);
+int glrtx_reset_stats(glrtx_ctx *ctx);
+
+/* HIP-event stopwatch on the stream launches go to: begin, N x render, end -> elapsed device ms. */
+int glrtx_timer_begin(glrtx_ctx *ctx);
+int glrtx_timer_end(glrtx_ctx *ctx, float *elapsed_ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

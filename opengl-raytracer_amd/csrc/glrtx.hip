@@ -1,0 +1,581 @@
+// glrtx.hip -- C-ABI host layer of libglrtx.so (include/glrtx.h): context, scene validation and
+// repacking, accumulator management, kernel launch, timing.  This is the "thin C-ABI HIP host
+// layer" that stands where GLFW/GL stood in the reference (src/core/window.cpp,
+// src/core/texture_buffer.cpp, src/core/framebuffer_object.cpp).  gfx950 only.
+#include "glrtx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pt_kernel.hip.h"
+
+using namespace glrtx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct glrtx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;      // per-launch
+    hipEvent_t tm0 = nullptr, tm1 = nullptr;      // glrtx_timer_*
+    std::string err;
+
+    DevBuf forks, tris, nrms, mats, lights, accum_own, counter, rgba8;
+    DevScene sc{};
+    bool have_scene = false;
+    int n_tri = 0, n_fork = 0, n_mat = 0, n_light = 0;
+
+    int width = 0, height = 0;
+    int rank = 0, world = 1, stripe = 16;
+    int owned_rows = 0;
+    float4 *accum = nullptr;  // own or bound
+    size_t pitch_bytes = 0;
+    bool bound = false;
+
+    bool count_rays = false;
+    bool launch_pending = false;  // ev1 recorded, kernel time not yet folded into stats
+    glrtx_stats st{};
+};
+
+namespace {
+
+int fail(glrtx_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(c, GLRTX_EDEVICE, "%s failed: %s", #call, hipGetErrorString(e_));     \
+    } while (0)
+
+int dev_upload(glrtx_ctx *c, DevBuf &b, const void *src, size_t bytes) {
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    const size_t alloc = std::max<size_t>(bytes, 64);
+    HIP_TRY(c, hipMalloc(&b.p, alloc));
+    b.bytes = alloc;
+    if (bytes) HIP_TRY(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return GLRTX_OK;
+}
+
+void dev_free(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+}
+
+int owned_rows_of(int height, int rank, int world, int stripe) {
+    int rows = 0;
+    const int n_stripes = (height + stripe - 1) / stripe;
+    for (int s = rank; s < n_stripes; s += world) rows += std::min(stripe, height - s * stripe);
+    return rows;
+}
+
+inline float as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
+
+// Fold the last launch's event pair into the stats (needs the stream to have passed ev1).
+int fold_launch_time(glrtx_ctx *c) {
+    if (!c->launch_pending) return GLRTX_OK;
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->st.kernel_ms_last = ms;
+    c->st.kernel_ms_total += ms;
+    c->launch_pending = false;
+    return GLRTX_OK;
+}
+
+int lds_bytes_for(const DevScene &sc) {
+    return (sc.mats_in_lds ? 3 * sc.n_mat * (int)sizeof(float4) : 0) + sc.stack_entries * kBlockThreads * (int)sizeof(int);
+}
+
+int pfail(glrtx_ctx *c, std::string *err_out, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (err_out) *err_out = buf;
+    else if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+// Validation + repacking of the wire-format scene; pure host code (no HIP calls), so it can be
+// exercised without a GPU through glrtx_check_scene.
+struct Packed {
+    std::vector<float4> forks, tris, nrms, mats, lights;
+    int root_ref = REF_ABSENT;
+    int stack_need = 0;
+};
+
+int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert, size_t n_vert, const float *tri, size_t n_tri,
+               const float *mat, size_t n_mat, const float *light, size_t n_light, const float *bvh, size_t n_nodes) {
+    if ((n_vert && !vert) || (n_tri && !tri) || (n_mat && !mat) || (n_light && !light) || (n_nodes && !bvh))
+        return pfail(c, err_out, GLRTX_EINVAL, "glrtx_upload_scene: NULL buffer with non-zero count");
+    if (n_tri > (size_t)INT32_MAX / 4 || n_nodes > (size_t)INT32_MAX / 4 || n_vert > (size_t)INT32_MAX / 16)
+        return pfail(c, err_out, GLRTX_EINVAL, "glrtx_upload_scene: scene too large for 32-bit indices");
+
+    auto vidx = [&](float f, int &out) {
+        if (!(f >= 0.0f) || (size_t)f >= n_vert) return false;
+        out = (int)f;
+        return true;
+    };
+
+    // ---- triangles: {v0, material} {v1-v0} {v2-v0}; normals {n0} {n1} {n2}
+    std::vector<float4> &tris = P.tris, &nrms = P.nrms;
+    tris.assign(3 * n_tri, make_float4(0.f, 0.f, 0.f, 0.f));
+    nrms.assign(3 * n_tri, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t t = 0; t < n_tri; t++) {
+        int i[3];
+        for (int k = 0; k < 3; k++)
+            if (!vidx(tri[4 * t + k], i[k])) return pfail(c, err_out, GLRTX_ESCENE, "triangle %zu: vertex index %g out of range", t, tri[4 * t + k]);
+        const float mf = tri[4 * t + 3];
+        if (!(mf >= 0.0f) || (size_t)mf >= n_mat) return pfail(c, err_out, GLRTX_ESCENE, "triangle %zu: material %g out of range", t, mf);
+        const float *p0 = vert + 15 * (size_t)i[0], *p1 = vert + 15 * (size_t)i[1], *p2 = vert + 15 * (size_t)i[2];
+        tris[3 * t + 0] = make_float4(p0[0], p0[1], p0[2], as_float((int)mf));
+        tris[3 * t + 1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.f);
+        tris[3 * t + 2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.f);
+        nrms[3 * t + 0] = make_float4(p0[3], p0[4], p0[5], 0.f);
+        nrms[3 * t + 1] = make_float4(p1[3], p1[4], p1[5], 0.f);
+        nrms[3 * t + 2] = make_float4(p2[3], p2[4], p2[5], 0.f);
+    }
+
+    // ---- materials: {emission, type} {param0, alpha.x} {param1, alpha.y}
+    std::vector<float4> &mats = P.mats;
+    mats.assign(3 * n_mat, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t m = 0; m < n_mat; m++) {
+        const float *r = mat + 18 * m;
+        mats[3 * m + 0] = make_float4(r[3], r[4], r[5], as_float((int)r[0]));
+        mats[3 * m + 1] = make_float4(r[6], r[7], r[8], r[12]);
+        mats[3 * m + 2] = make_float4(r[9], r[10], r[11], r[13]);
+    }
+
+    // ---- lights: {v0, material} {v1} {v2} {n0} {n1} {n2}
+    std::vector<float4> &lights = P.lights;
+    lights.assign(6 * n_light, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t l = 0; l < n_light; l++) {
+        int i[3];
+        for (int k = 0; k < 3; k++)
+            if (!vidx(light[4 * l + k], i[k])) return pfail(c, err_out, GLRTX_ESCENE, "light %zu: vertex index out of range", l);
+        const float mf = light[4 * l + 3];
+        if (!(mf >= 0.0f) || (size_t)mf >= n_mat) return pfail(c, err_out, GLRTX_ESCENE, "light %zu: material out of range", l);
+        for (int k = 0; k < 3; k++) {
+            const float *p = vert + 15 * (size_t)i[k];
+            lights[6 * l + k] = make_float4(p[0], p[1], p[2], k == 0 ? as_float((int)mf) : 0.f);
+            lights[6 * l + 3 + k] = make_float4(p[3], p[4], p[5], 0.f);
+        }
+    }
+
+    // ---- BVH: walk the wire-format tree from node 0, fold leaves into refs, renumber forks in DFS order
+    std::vector<float4> &forks = P.forks;
+    forks.clear();
+    int root_ref = REF_ABSENT;
+    int stack_need = 0;
+    if (n_nodes > 0 && n_tri > 0) {
+        std::vector<int> ref_of(n_nodes, 0);          // ref assigned to each wire node
+        std::vector<unsigned char> seen(n_nodes, 0);
+        struct Frame { int node; int stage; };
+        std::vector<Frame> st;
+        std::vector<int> need(n_nodes, 0);
+        auto is_fork = [&](int n) { return bvh[9 * (size_t)n + 8] < 0.0f; };
+        auto child = [&](int n, int k, int &out) {  // k = 0 left (children.x), 1 right (children.y)
+            const float f = bvh[9 * (size_t)n + 6 + k];
+            if (!(f >= 0.0f)) { out = -1; return true; }
+            if ((size_t)f >= n_nodes) return false;
+            out = (int)f;
+            return true;
+        };
+        st.push_back({0, 0});
+        while (!st.empty()) {
+            Frame &f = st.back();
+            const int n = f.node;
+            if (f.stage == 0) {
+                if (seen[n]) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d is referenced more than once (not a tree)", n);
+                seen[n] = 1;
+                if (!is_fork(n)) {
+                    const float tf = bvh[9 * (size_t)n + 8];
+                    if ((size_t)tf >= n_tri) return pfail(c, err_out, GLRTX_ESCENE, "BVH leaf %d: triangle %g out of range", n, tf);
+                    ref_of[n] = ~(int)tf;
+                    need[n] = 0;
+                    st.pop_back();
+                    continue;
+                }
+                ref_of[n] = (int)(forks.size() / 2);
+                forks.push_back(make_float4(bvh[9 * (size_t)n + 0], bvh[9 * (size_t)n + 1], bvh[9 * (size_t)n + 2], as_float(REF_ABSENT)));
+                forks.push_back(make_float4(bvh[9 * (size_t)n + 3], bvh[9 * (size_t)n + 4], bvh[9 * (size_t)n + 5], as_float(REF_ABSENT)));
+                f.stage = 1;
+                int l;
+                if (!child(n, 0, l)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
+                if (l >= 0) { st.push_back({l, 0}); }
+                continue;
+            }
+            if (f.stage == 1) {
+                f.stage = 2;
+                int r;
+                if (!child(n, 1, r)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
+                if (r >= 0) { st.push_back({r, 0}); }
+                continue;
+            }
+            int l, r;
+            child(n, 0, l);
+            child(n, 1, r);
+            const int fi = ref_of[n];
+            if (l >= 0) forks[2 * fi].w = as_float(ref_of[l]);
+            if (r >= 0) forks[2 * fi + 1].w = as_float(ref_of[r]);
+            // traversal continues with the right child while the left one waits on the stack
+            if (l >= 0 && r >= 0) need[n] = std::max(1 + need[r], need[l]);
+            else if (r >= 0) need[n] = need[r];
+            else if (l >= 0) need[n] = need[l];
+            else need[n] = 0;
+            st.pop_back();
+        }
+        root_ref = ref_of[0];
+        stack_need = need[0];
+    }
+    if (root_ref == REF_ABSENT) {  // empty scene: one childless fork, every ray misses
+        forks.assign(2, make_float4(0.f, 0.f, 0.f, as_float(REF_ABSENT)));
+        root_ref = 0;
+    }
+    if (stack_need > 63)
+        return pfail(c, err_out, GLRTX_EDEPTH, "BVH needs %d traversal stack entries; the reference shader's stack holds 64", stack_need + 1);
+
+    P.root_ref = root_ref;
+    P.stack_need = stack_need;
+    return GLRTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int glrtx_abi_version(void) { return GLRTX_ABI_VERSION; }
+
+const char *glrtx_last_error(const glrtx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int glrtx_create(glrtx_ctx **out, int device_id) {
+    if (!out) return fail(nullptr, GLRTX_EINVAL, "glrtx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, GLRTX_EDEVICE, "no HIP device available (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device_id < 0) {
+        if (hipGetDevice(&device_id) != hipSuccess) device_id = 0;
+    }
+    if (device_id >= n) return fail(nullptr, GLRTX_EINVAL, "device %d out of range (%d devices)", device_id, n);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
+        return fail(nullptr, GLRTX_EDEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, GLRTX_EDEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    glrtx_ctx *c = new (std::nothrow) glrtx_ctx;
+    if (!c) return fail(nullptr, GLRTX_ENOMEM, "out of host memory");
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipEventCreate(&c->tm0)) != hipSuccess || (e = hipEventCreate(&c->tm1)) != hipSuccess ||
+        (e = hipMalloc(&c->counter.p, sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(c->counter.p, 0, sizeof(unsigned long long))) != hipSuccess) {
+        fail(nullptr, GLRTX_EDEVICE, "context setup failed: %s", hipGetErrorString(e));
+        glrtx_destroy(c);
+        return GLRTX_EDEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return GLRTX_OK;
+}
+
+void glrtx_destroy(glrtx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    dev_free(c->forks); dev_free(c->tris); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights);
+    dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->tm0) (void)hipEventDestroy(c->tm0);
+    if (c->tm1) (void)hipEventDestroy(c->tm1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat,
+                       size_t n_mat, const float *light, size_t n_light, const float *bvh, size_t n_nodes) {
+    if (!c) return GLRTX_EINVAL;
+    Packed P;
+    if (int prc = pack_scene(c, nullptr, P, vert, n_vert, tri, n_tri, mat, n_mat, light, n_light, bvh, n_nodes)) return prc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<float4> &forks = P.forks, &tris = P.tris, &nrms = P.nrms, &mats = P.mats, &lights = P.lights;
+    const int root_ref = P.root_ref, stack_need = P.stack_need;
+
+    int rc;
+    if ((rc = dev_upload(c, c->forks, forks.data(), forks.size() * sizeof(float4)))) return rc;
+    if ((rc = dev_upload(c, c->tris, tris.data(), tris.size() * sizeof(float4)))) return rc;
+    if ((rc = dev_upload(c, c->nrms, nrms.data(), nrms.size() * sizeof(float4)))) return rc;
+    if ((rc = dev_upload(c, c->mats, mats.data(), mats.size() * sizeof(float4)))) return rc;
+    if ((rc = dev_upload(c, c->lights, lights.data(), lights.size() * sizeof(float4)))) return rc;
+
+    DevScene &sc = c->sc;
+    sc.forks = (const float4 *)c->forks.p;
+    sc.tris = (const float4 *)c->tris.p;
+    sc.nrms = (const float4 *)c->nrms.p;
+    sc.mats = (const float4 *)c->mats.p;
+    sc.lights = (const float4 *)c->lights.p;
+    sc.root_ref = root_ref;
+    sc.n_light = (int)n_light;
+    sc.n_mat = (int)n_mat;
+    sc.stack_entries = stack_need;
+    sc.mats_in_lds = (n_mat > 0 && n_mat <= (size_t)kMaxLdsMaterials) ? 1 : 0;
+    c->n_tri = (int)n_tri; c->n_fork = (int)(forks.size() / 2); c->n_mat = (int)n_mat; c->n_light = (int)n_light;
+    c->have_scene = true;
+    c->st.stack_entries = stack_need;
+    c->st.lds_bytes = lds_bytes_for(sc);
+    c->st.n_tri = c->n_tri; c->st.n_fork = c->n_fork; c->st.n_mat = c->n_mat; c->st.n_light = c->n_light;
+    return GLRTX_OK;
+}
+
+// Host-only validation of a wire-format scene (no device needed): the same checks and repacking
+// glrtx_upload_scene performs.  Outputs may be NULL.
+int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat, size_t n_mat,
+                      const float *light, size_t n_light, const float *bvh, size_t n_nodes, int *n_fork_out,
+                      int *stack_entries_out) {
+    Packed P;
+    if (int rc = pack_scene(nullptr, &g_create_error, P, vert, n_vert, tri, n_tri, mat, n_mat, light, n_light, bvh, n_nodes)) return rc;
+    if (n_fork_out) *n_fork_out = (int)(P.forks.size() / 2);
+    if (stack_entries_out) *stack_entries_out = P.stack_need;
+    return GLRTX_OK;
+}
+
+int glrtx_set_partition(glrtx_ctx *c, int rank, int world, int stripe_rows) {
+    if (!c) return GLRTX_EINVAL;
+    if (world < 1 || rank < 0 || rank >= world || stripe_rows < 1)
+        return fail(c, GLRTX_EINVAL, "glrtx_set_partition: bad rank/world/stripe %d/%d/%d", rank, world, stripe_rows);
+    if (stripe_rows % kTile != 0)
+        return fail(c, GLRTX_EINVAL, "glrtx_set_partition: stripe_rows must be a multiple of %d", kTile);
+    c->rank = rank; c->world = world; c->stripe = stripe_rows;
+    if (c->width > 0) return glrtx_resize(c, c->width, c->height);
+    return GLRTX_OK;
+}
+
+int glrtx_local_row_to_y(const glrtx_ctx *c, int r) {
+    if (!c || r < 0 || r >= c->owned_rows) return -1;
+    return ((r / c->stripe) * c->world + c->rank) * c->stripe + r % c->stripe;
+}
+
+int glrtx_resize(glrtx_ctx *c, int width, int height) {
+    if (!c) return GLRTX_EINVAL;
+    if (width < 1 || height < 1 || width > 65536 || height > 65536) return fail(c, GLRTX_EINVAL, "glrtx_resize: bad size %dx%d", width, height);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->width = width; c->height = height;
+    c->owned_rows = owned_rows_of(height, c->rank, c->world, c->stripe);
+    c->st.width = width; c->st.height = height; c->st.owned_rows = c->owned_rows;
+    if (!c->bound) {
+        // pitch: rows padded to 256 B so every 8-pixel tile row is one aligned 128 B segment
+        const size_t pitch = ((size_t)width * sizeof(float4) + 255) / 256 * 256;
+        const size_t bytes = pitch * (size_t)std::max(c->owned_rows, 1);
+        if (c->accum_own.bytes < bytes) {
+            dev_free(c->accum_own);
+            HIP_TRY(c, hipMalloc(&c->accum_own.p, bytes));
+            c->accum_own.bytes = bytes;
+        }
+        c->accum = (float4 *)c->accum_own.p;
+        c->pitch_bytes = pitch;
+    }
+    return glrtx_clear(c);
+}
+
+int glrtx_clear(glrtx_ctx *c) {
+    if (!c) return GLRTX_EINVAL;
+    if (!c->accum) return fail(c, GLRTX_EINVAL, "glrtx_clear: no accumulator (call glrtx_resize first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->accum, 0, c->pitch_bytes * (size_t)c->owned_rows, c->stream));
+    return GLRTX_OK;
+}
+
+int glrtx_bind_accum(glrtx_ctx *c, void *device_ptr, size_t pitch_bytes) {
+    if (!c) return GLRTX_EINVAL;
+    if (c->width < 1) return fail(c, GLRTX_EINVAL, "glrtx_bind_accum: call glrtx_resize first");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!device_ptr) {
+        c->bound = false;
+        return glrtx_resize(c, c->width, c->height);
+    }
+    if (pitch_bytes < (size_t)c->width * sizeof(float4) || pitch_bytes % sizeof(float4) != 0 || ((uintptr_t)device_ptr & 15) != 0)
+        return fail(c, GLRTX_EINVAL, "glrtx_bind_accum: pitch/alignment invalid");
+    c->bound = true;
+    c->accum = (float4 *)device_ptr;
+    c->pitch_bytes = pitch_bytes;
+    return GLRTX_OK;
+}
+
+int glrtx_set_stream(glrtx_ctx *c, void *hip_stream) {
+    if (!c) return GLRTX_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = fold_launch_time(c)) return rc;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return GLRTX_OK;
+}
+
+int glrtx_count_rays(glrtx_ctx *c, int enable) {
+    if (!c) return GLRTX_EINVAL;
+    c->count_rays = enable != 0;
+    return GLRTX_OK;
+}
+
+int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
+    if (!c || !p) return GLRTX_EINVAL;
+    if (!c->have_scene) return fail(c, GLRTX_EINVAL, "glrtx_render: no scene uploaded");
+    if (!c->accum || c->width < 1) return fail(c, GLRTX_EINVAL, "glrtx_render: no accumulator (call glrtx_resize)");
+    if (p->n_samples < 0 || p->max_depth < 0) return fail(c, GLRTX_EINVAL, "glrtx_render: negative n_samples/max_depth");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = fold_launch_time(c)) return rc;
+    c->st.launches++;
+    if (c->owned_rows == 0) return GLRTX_OK;
+
+    KernelArgs a;
+    a.sc = c->sc;
+    std::memcpy(a.c2w, p->c2w, sizeof a.c2w);
+    std::memcpy(a.s2c, p->s2c, sizeof a.s2c);
+    a.aperture = p->aperture; a.focal = p->focal;
+    a.seed_x = p->seed[0]; a.seed_y = p->seed[1];
+    a.n_samples = p->n_samples; a.max_depth = p->max_depth;
+    a.width = c->width; a.height = c->height;
+    a.owned_rows = c->owned_rows;
+    a.rank = c->rank; a.world = c->world; a.stripe = c->stripe;
+    a.accum = c->accum;
+    a.pitch_f4 = (int)(c->pitch_bytes / sizeof(float4));
+    a.ray_counter = (unsigned long long *)c->counter.p;
+    a.tiles_x = (c->width + kTile - 1) / kTile;
+    const int tiles_y = (c->owned_rows + kTile - 1) / kTile;
+    a.n_tiles = a.tiles_x * tiles_y;
+
+    // Host-side shape checks before launching a hand-written kernel.
+    const int lds = lds_bytes_for(c->sc);
+    if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "render kernel needs %d B of LDS (> 160 KiB)", lds);
+    if (a.pitch_f4 < c->width) return fail(c, GLRTX_EINVAL, "accumulator pitch smaller than a row");
+
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (c->count_rays) {
+        if (lds > 64 * 1024)
+            HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(pt_render_kernel<true>, dim3(a.n_tiles), dim3(kBlockThreads), lds, c->stream, a);
+    } else {
+        if (lds > 64 * 1024)
+            HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(pt_render_kernel<false>, dim3(a.n_tiles), dim3(kBlockThreads), lds, c->stream, a);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->launch_pending = true;
+    c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples;
+    return GLRTX_OK;
+}
+
+int glrtx_sync(glrtx_ctx *c) {
+    if (!c) return GLRTX_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return fold_launch_time(c);
+}
+
+int glrtx_read_accum(glrtx_ctx *c, float *dst, size_t dst_pitch_bytes) {
+    if (!c || !dst) return GLRTX_EINVAL;
+    if (!c->accum) return fail(c, GLRTX_EINVAL, "glrtx_read_accum: no accumulator");
+    const size_t row = (size_t)c->width * sizeof(float4);
+    if (dst_pitch_bytes < row) return fail(c, GLRTX_EINVAL, "glrtx_read_accum: dst pitch too small");
+    if (int rc = glrtx_sync(c)) return rc;
+    if (c->owned_rows == 0) return GLRTX_OK;
+    HIP_TRY(c, hipMemcpy2D(dst, dst_pitch_bytes, c->accum, c->pitch_bytes, row, (size_t)c->owned_rows, hipMemcpyDeviceToHost));
+    return GLRTX_OK;
+}
+
+int glrtx_accum_device_ptr(const glrtx_ctx *c, void **ptr_out, size_t *pitch_out) {
+    if (!c || !ptr_out || !pitch_out) return GLRTX_EINVAL;
+    *ptr_out = c->accum;
+    *pitch_out = c->pitch_bytes;
+    return GLRTX_OK;
+}
+
+int glrtx_resolve_rgba8(glrtx_ctx *c, uint8_t *dst, size_t dst_pitch_bytes, float gamma, int flip_y) {
+    if (!c || !dst) return GLRTX_EINVAL;
+    if (!c->accum) return fail(c, GLRTX_EINVAL, "glrtx_resolve_rgba8: no accumulator");
+    if (!(gamma > 0.f)) return fail(c, GLRTX_EINVAL, "glrtx_resolve_rgba8: gamma must be positive");
+    if (dst_pitch_bytes < (size_t)c->width * 4) return fail(c, GLRTX_EINVAL, "glrtx_resolve_rgba8: dst pitch too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->owned_rows == 0) return glrtx_sync(c);
+    const size_t bytes = (size_t)c->width * 4 * (size_t)c->owned_rows;
+    if (c->rgba8.bytes < bytes) {
+        dev_free(c->rgba8);
+        HIP_TRY(c, hipMalloc(&c->rgba8.p, bytes));
+        c->rgba8.bytes = bytes;
+    }
+    dim3 grid((c->width + 63) / 64, (c->owned_rows + 3) / 4);
+    hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, c->stream, (const float4 *)c->accum, (int)(c->pitch_bytes / sizeof(float4)),
+                       c->width, c->owned_rows, (uchar4 *)c->rgba8.p, c->width, 1.0f / gamma, flip_y ? 1 : 0);
+    HIP_TRY(c, hipGetLastError());
+    if (int rc = glrtx_sync(c)) return rc;
+    HIP_TRY(c, hipMemcpy2D(dst, dst_pitch_bytes, c->rgba8.p, (size_t)c->width * 4, (size_t)c->width * 4, (size_t)c->owned_rows,
+                           hipMemcpyDeviceToHost));
+    return GLRTX_OK;
+}
+
+int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
+    if (!c || !out) return GLRTX_EINVAL;
+    *out = c->st;
+    unsigned long long r = 0;
+    if (c->counter.p && hipMemcpy(&r, c->counter.p, sizeof r, hipMemcpyDeviceToHost) == hipSuccess) out->rays = r;
+    return GLRTX_OK;
+}
+
+int glrtx_reset_stats(glrtx_ctx *c) {
+    if (!c) return GLRTX_EINVAL;
+    if (int rc = glrtx_sync(c)) return rc;
+    HIP_TRY(c, hipMemset(c->counter.p, 0, sizeof(unsigned long long)));
+    c->st.rays = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_ms_total = 0.0; c->st.kernel_ms_last = 0.f;
+    return GLRTX_OK;
+}
+
+int glrtx_timer_begin(glrtx_ctx *c) {
+    if (!c) return GLRTX_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->tm0, c->stream));
+    return GLRTX_OK;
+}
+
+int glrtx_timer_end(glrtx_ctx *c, float *ms) {
+    if (!c || !ms) return GLRTX_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->tm1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->tm1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->tm0, c->tm1));
+    return GLRTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,602 @@
+// pt_kernel.hip.h -- the per-pixel path-tracing kernel for gfx950 (CDNA4, wave64).
+//
+// One work-item per pixel sample loop; this is the device-side replacement of the reference's
+// fullscreen-quad fragment shader (src/shaders/raytrace.frag, launched by glDrawArrays at
+// src/core/window.cpp:290).  Reference functions covered (raytrace.frag line ranges):
+//   rand :104-111, main :565-614, radiance :409-559, intersect(Ray,Intersection) :276-335,
+//   intersectBBox :259-274, intersect(Ray,Triangle) :226-257, sampleDirect :337-403,
+//   fresnelConductor :158-178, GGX :180-184, microfacetGGXBRDF :186-193,
+//   sampleGGXVNDF :195-214, weightedGGXPDF :216-219.
+//
+// Numerics contract: the reference image is a chaotic function of float32
+// rounding, so every expression keeps the association order the reference's GL implementation
+// evaluates (no contraction: this file is compiled with -ffp-contract=off; IEEE divide and sqrt;
+// 3-component dots summed z,y,x; min/max returning the non-NaN operand) and sin/cos are the
+// Cephes single-precision routines with explicit fused multiply-adds.  Nothing here uses
+// v_rcp/v_rsq/v_sin approximations.
+//
+// Device data layout (built by glrtx_upload_scene from the reference wire format):
+//   forks  : 2 x float4 per interior BVH node  {min.xyz, refL} {max.xyz, refR}
+//            ref >= 0 -> fork index, ref < 0 -> ~triangle (leaf nodes are folded into their
+//            parent's ref: the reference never tests a leaf's own box, raytrace.frag:310-331),
+//            ref == REF_ABSENT -> no child
+//   tris   : 3 x float4 per triangle {v0.xyz, materialId} {v1-v0, -} {v2-v0, -}
+//   nrms   : 3 x float4 per triangle {n0} {n1} {n2}   (read once per ray, for the closest hit only)
+//   mats   : 3 x float4 per material {emission.xyz, type} {param0.xyz, alpha.x} {param1.xyz, alpha.y}
+//   lights : 6 x float4 per light triangle {v0, materialId} {v1} {v2} {n0} {n1} {n2}
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace glrtx {
+
+constexpr int kBlockThreads = 256;      // 4 wavefronts: a 16x16-pixel tile, one 8x8 sub-tile per wave
+constexpr int kTile = 16;
+constexpr int REF_ABSENT = INT32_MIN;
+constexpr int kMaxLdsMaterials = 256;   // 12 KiB of LDS at most
+
+constexpr float PT_EPS = 1.0e-4f;
+constexpr float PT_INFTY = 1.0e8f;
+constexpr float PT_PI = 3.14159274101257324f;
+constexpr float PT_2PI = 6.28318548202514648f;  // the GLSL compiler folds 2.0*PI into one constant
+
+struct DevScene {
+    const float4 *forks;
+    const float4 *tris;
+    const float4 *nrms;
+    const float4 *mats;
+    const float4 *lights;
+    int root_ref;
+    int n_light;
+    int n_mat;
+    int stack_entries;  // per-lane traversal stack entries in LDS
+    int mats_in_lds;    // 1: materials staged into LDS at kernel start
+};
+
+struct KernelArgs {
+    DevScene sc;
+    float c2w[16];
+    float s2c[16];
+    float aperture, focal;
+    float seed_x, seed_y;
+    int n_samples, max_depth;
+    int width, height;       // full image
+    int owned_rows;          // rows in this partition
+    int rank, world, stripe; // row-stripe partition
+    float4 *accum;           // owned_rows x pitch
+    int pitch_f4;            // accumulator pitch in float4 units
+    unsigned long long *ray_counter;
+    int tiles_x, n_tiles;
+};
+
+#define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------ sin / cos
+// Cephes sinf/cosf with FMA, the routine the reference's GL implementation uses for sin()/cos().
+DEV float sincos_core(float xabs, int je, bool sin_poly) {
+    const float yf = (float)je;
+    float x = __builtin_fmaf(yf, -0.78515625f, xabs);
+    x = __builtin_fmaf(yf, -2.4187564849853515625e-4f, x);
+    x = __builtin_fmaf(yf, -3.77489497744594108e-8f, x);
+    const float z = x * x;
+    float s = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    s = __builtin_fmaf(s, z, -1.6666654611e-1f);
+    s = s * z;
+    s = __builtin_fmaf(s, x, x);
+    float c = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    c = __builtin_fmaf(c, z, 4.166664568298827e-2f);
+    c = c * z;
+    c = c * z;
+    c = c - z * 0.5f;
+    c = c + 1.0f;
+    return sin_poly ? s : c;
+}
+DEV float clamp_unit(float r, float x) {
+    if ((__float_as_uint(x) & 0x7f800000u) == 0x7f800000u) return __uint_as_float(0x7fc00000u);
+    r = r < 1.0f ? r : 1.0f;
+    r = r > -1.0f ? r : -1.0f;
+    return r;
+}
+DEV float pt_sin(float x) {
+    const float xabs = __builtin_fabsf(x);
+    const int j1 = (int)(xabs * 1.27323954473516f) + 1;
+    const int je = j1 & ~1;
+    const uint32_t sign = (__float_as_uint(x) ^ ((uint32_t)j1 << 29)) & 0x80000000u;
+    const float r = sincos_core(xabs, je, (je & 2) == 0);
+    return clamp_unit(__uint_as_float(__float_as_uint(r) ^ sign), x);
+}
+DEV float pt_cos(float x) {
+    const float xabs = __builtin_fabsf(x);
+    const int je = ((int)(xabs * 1.27323954473516f) + 1) & ~1;
+    const int j2 = je - 2;
+    const uint32_t sign = ((uint32_t)(~j2) & 4u) << 29;
+    const float r = sincos_core(xabs, je, (j2 & 2) == 0);
+    return clamp_unit(__uint_as_float(__float_as_uint(r) ^ sign), x);
+}
+// The RNG argument is bounded (|t| < 92: state, seed in [0,1)), so the inf/NaN guard and the
+// [-1,1] clamp of the general routine cannot trigger differently; keep the clamp, drop nothing.
+
+// ------------------------------------------------------------------------------------------ rand() :104-111
+struct Rng {
+    float x, y, sx, sy;
+};
+DEV float pt_rand(Rng &s) {
+    const float a = 12.9898f, b = 78.233f, c = 43758.5453f;
+    const float dy = (s.y - s.sy) * b;  // old state.y term, shared by both updates
+    float t = dy + (s.x - s.sx) * a;
+    float p = pt_sin(t) * c;
+    s.x = p - __builtin_floorf(p);
+    t = dy + (s.x - s.sx) * a;
+    p = pt_sin(t) * c;
+    s.y = p - __builtin_floorf(p);
+    return s.x;
+}
+
+// ------------------------------------------------------------------------------------------ helpers
+DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (az * bz + ay * by) + ax * bx; }
+DEV float rsq(float x) { return 1.0f / __builtin_sqrtf(x); }  // IEEE sqrt then IEEE divide
+// GLSL min/max as the reference's GL implementation lowers them (other operand on NaN):
+DEV float fmin_g(float a, float b) { return (b != b) ? a : (a < b ? a : b); }
+DEV float fmax_g(float a, float b) { return (b != b) ? a : (a > b ? a : b); }
+DEV float fmin_c(float x, float c) { return x < c ? x : c; }  // one operand constant
+DEV float fmax_c(float x, float c) { return x > c ? x : c; }
+
+struct Hit {
+    float t;    // INFTY on a miss
+    int tri;    // closest triangle, -1 on a miss
+    float u, v; // barycentrics of the closest hit
+};
+
+// ------------------------------------------------------------------------------------------ intersect :276-335
+// Iterative DFS in the reference's order (push children.x, push children.y, pop y first,
+// :299-307): "continue with y, stack x".  The per-lane stack lives in LDS, entry e of lane l at
+// stack[e * kBlockThreads + l] (bank = l mod 32: conflict-free ds_read/write_b32).
+template <bool CLOSEST>
+DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, float dx, float dy, float dz) {
+    Hit h;
+    h.t = PT_INFTY; h.tri = -1; h.u = 0.f; h.v = 0.f;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // :260 (loop-invariant there)
+    int sp = 0;
+    int cur = sc.root_ref;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 A = sc.forks[2 * cur];
+            const float4 B = sc.forks[2 * cur + 1];
+            // intersectBBox :259-274
+            const float fx = (B.x - ox) * ix, fy = (B.y - oy) * iy, fz = (B.z - oz) * iz;
+            const float nx = (A.x - ox) * ix, ny = (A.y - oy) * iy, nz = (A.z - oz) * iz;
+            // v_min/v_max return the non-NaN operand, which is the semantics needed here;
+            // the sign of a zero result cannot change the comparison below.
+            const float t1 = __builtin_fminf(__builtin_fmaxf(fx, nx),
+                                             __builtin_fminf(__builtin_fmaxf(fy, ny), __builtin_fmaxf(fz, nz)));
+            const float t0 = __builtin_fmaxf(__builtin_fminf(fx, nx),
+                                             __builtin_fmaxf(__builtin_fminf(fy, ny), __builtin_fminf(fz, nz)));
+            // (t1 >= t0 && t0 <= tHit) is evaluated as min(t1, tHit) >= t0
+            if (__builtin_fminf(t1, h.t) >= t0) {
+                const int l = __float_as_int(A.w), r = __float_as_int(B.w);
+                if (r != REF_ABSENT) {
+                    if (l != REF_ABSENT) {
+                        stack[sp * kBlockThreads] = l;
+                        sp++;
+                    }
+                    cur = r;
+                    continue;
+                }
+                if (l != REF_ABSENT) {
+                    cur = l;
+                    continue;
+                }
+            }
+        } else {
+            // leaf :310-331 with intersect(Ray, Triangle) :226-257
+            const int t = ~cur;
+            const float4 T0 = sc.tris[3 * t], T1 = sc.tris[3 * t + 1], T2 = sc.tris[3 * t + 2];
+            const float px = dy * T2.z - dz * T2.y;
+            const float py = dz * T2.x - dx * T2.z;
+            const float pz = dx * T2.y - dy * T2.x;
+            const float det = dot3(T1.x, T1.y, T1.z, px, py, pz);
+            if (!(-PT_EPS < det && det < PT_EPS)) {
+                const float inv = 1.0f / det;
+                const float tx = ox - T0.x, ty = oy - T0.y, tz = oz - T0.z;
+                const float U = dot3(tx, ty, tz, px, py, pz);
+                const float u = U * inv;
+                if (!(u < 0.0f || 1.0f < u)) {
+                    const float qx = ty * T1.z - tz * T1.y;
+                    const float qy = tz * T1.x - tx * T1.z;
+                    const float qz = tx * T1.y - ty * T1.x;
+                    const float V = dot3(dx, dy, dz, qx, qy, qz);
+                    const float v = V * inv;
+                    if (!(v < 0.0f || 1.0f < inv * (U + V))) {  // u+v>1 is evaluated as inv*(U+V)>1
+                        const float tt = dot3(T2.x, T2.y, T2.z, qx, qy, qz) * inv;
+                        if (!(PT_EPS >= tt)) {
+                            if (CLOSEST && tt < h.t) {
+                                h.tri = t; h.u = u; h.v = v;
+                            }
+                            if (!CLOSEST && tt < h.t) h.tri = t;
+                            h.t = __builtin_fminf(h.t, tt);
+                        }
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * kBlockThreads];
+    }
+    return h;
+}
+
+// fresnelConductor :158-178, one channel
+DEV float fresnel1(float c2, float s2, float cosI, float eta, float k) {
+    const float eta2 = eta * eta, k2 = k * k;
+    const float temp0 = (eta2 - s2) - k2;
+    const float a2pb2 = __builtin_sqrtf(fmax_c(temp0 * temp0 + (4.0f * k2) * eta2, 0.0f));
+    const float temp1 = a2pb2 + c2;
+    const float a = __builtin_sqrtf(fmax_c((a2pb2 + temp0) * 0.5f, 0.0f));
+    const float temp2 = (2.0f * a) * cosI;
+    const float Rs2 = (temp1 - temp2) / (temp1 + temp2);
+    const float temp3 = a2pb2 * c2 + s2 * s2;
+    const float temp4 = temp2 * s2;
+    const float Rp2 = (Rs2 * (temp3 - temp4)) / (temp3 + temp4);
+    return 0.5f * (Rp2 + Rs2);
+}
+// GGX :180-184, denominator associated as (PI*ax) * ((ay*l2)*l2)
+DEV float ggx(float hx, float hy, float hz, float ax, float ay) {
+    const float sx = hx / ax, sy = hy / ay;
+    const float l2 = (hz * hz + sy * sy) + sx * sx;
+    return 1.0f / ((PT_PI * ax) * ((ay * l2) * l2));
+}
+
+struct Mat {
+    float4 m0, m1, m2;  // {emission, type} {param0, alpha.x} {param1, alpha.y}
+};
+DEV Mat load_mat(const DevScene &sc, const float4 *lds_mats, int m) {
+    Mat r;
+    if (sc.mats_in_lds) {
+        r.m0 = lds_mats[3 * m]; r.m1 = lds_mats[3 * m + 1]; r.m2 = lds_mats[3 * m + 2];
+    } else {
+        r.m0 = sc.mats[3 * m]; r.m1 = sc.mats[3 * m + 1]; r.m2 = sc.mats[3 * m + 2];
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ radiance :409-559
+DEV void radiance(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rng, float ox, float oy, float oz,
+                  float dx, float dy, float dz, float &Lr, float &Lg, float &Lb, unsigned &rays) {
+    const DevScene &sc = a.sc;
+    float Lx = 0.f, Ly = 0.f, Lz = 0.f;
+    float bx = 1.f, by = 1.f, bz = 1.f;
+    const float nLf = (float)sc.n_light;
+
+    for (int depth = 0; depth < a.max_depth; depth++) {
+        const Hit h = traverse<true>(sc, stack, ox, oy, oz, dx, dy, dz);
+        rays++;
+        if (h.tri < 0) break;  // miss: nothing is added and the loop ends (:497-499)
+
+        // normal of the closest hit (:254), computed once instead of per candidate
+        const float4 T0 = sc.tris[3 * h.tri];
+        float nx, ny, nz;
+        {
+            const float4 N0 = sc.nrms[3 * h.tri], N1 = sc.nrms[3 * h.tri + 1], N2 = sc.nrms[3 * h.tri + 2];
+            const float w0 = (1.0f - h.u) - h.v;
+            const float tx = (w0 * N0.x + h.u * N1.x) + h.v * N2.x;
+            const float ty = (w0 * N0.y + h.u * N1.y) + h.v * N2.y;
+            const float tz = (w0 * N0.z + h.u * N1.z) + h.v * N2.z;
+            const float r = rsq(dot3(tx, ty, tz, tx, ty, tz));
+            nx = tx * r; ny = ty * r; nz = tz * r;
+        }
+        const int mtrl = __float_as_int(T0.w);
+        const Mat M = load_mat(sc, lds_mats, mtrl);
+        const int type = __float_as_int(M.m0.w);
+
+        // :420
+        const float tt = h.t + PT_EPS;
+        const float xx = ox + tt * dx, xy = oy + tt * dy, xz = oz + tt * dz;
+        const float woz = (-(dz * nz) - (dy * ny)) - (dx * nx);  // dot(-d, n), also woLocal.z
+
+        if (type == 5 && woz >= PT_EPS) {
+            // MTRL_MEDIA from the front: the volume branch is compiled out in the reference
+            // (ENABLE_VOLUME 0, :424-487); the ray is left unchanged.
+        } else {
+            if (depth == 0) {  // :490-494 (specularReflect / passedVolume are never set)
+                Lx = Lx + bx * M.m0.x; Ly = Ly + by * M.m0.y; Lz = Lz + bz * M.m0.z;
+            }
+            // :502-506 local frame; cross() with the selected axis kept as 0/1 multipliers
+            const float B = (0.1f < __builtin_fabsf(nx)) ? 1.0f : 0.0f, A = 1.0f - B;
+            const float ux = B * nz;
+            const float nuy = A * nz;  // = -u.y
+            const float uz = A * ny - B * nx;
+            const float vx = ny * uz + nuy * nz;
+            const float vy = nz * ux - nx * uz;
+            const float vz = -(nuy * nx) - (ny * ux);
+            const float wox = (-(dz * uz) + nuy * dy) - (dx * ux);
+            const float woy = (-(dz * vz) - (dy * vy)) - (dx * vx);
+
+            float fx = 0.f, fy = 0.f, fz = 0.f, pdf = 1.0f;
+            float wlx = 0.f, wly = 0.f, wlz = 1.0f;
+            if (type == 2) {
+                // diffuse :511-519
+                const float ra = pt_rand(rng);
+                const float rb = pt_rand(rng);
+                const float r1 = PT_2PI * ra;
+                const float r2s = __builtin_sqrtf(rb);
+                wlx = pt_cos(r1) * r2s;
+                wly = pt_sin(r1) * r2s;
+                wlz = __builtin_sqrtf(1.0f - rb);
+                fx = M.m1.x / PT_PI; fy = M.m1.y / PT_PI; fz = M.m1.z / PT_PI;
+                pdf = wlz / PT_PI;
+            } else if (type == 3) {
+                // conductor :520-532; param0 = kappa, param1 = eta
+                const float ax = M.m1.w, ay = M.m2.w;
+                const float u0 = pt_rand(rng);
+                const float u1 = pt_rand(rng);
+                // sampleGGXVNDF :195-214
+                const float sx = wox * ax, sy = woy * ay;
+                const float lw = (woz * woz + sy * sy) + sx * sx;
+                const float rw = rsq(lw);
+                const float vhx = sx * rw, vhy = sy * rw, vhz = woz * rw;
+                const float lensq = vhx * vhx + vhy * vhy;
+                const float q = rsq(lensq);
+                const float T1x = (0.0f < lensq) ? -(vhy * q) : 1.0f;
+                const float T1y = (0.0f < lensq) ? vhx * q : 0.0f;
+                const float rr = __builtin_sqrtf(u0);
+                const float phi = PT_2PI * u1;
+                const float t1 = rr * pt_cos(phi);
+                const float t2r = rr * pt_sin(phi);
+                const float s = 0.5f * (1.0f + vhz);
+                const float c1 = 1.0f - t1 * t1;
+                const float t2 = (1.0f - s) * __builtin_sqrtf(c1) + s * t2r;
+                const float T2y = vhz * T1x;
+                const float zq = vhz * T1y;  // = -T2.x
+                const float T2z = vhx * T1y - vhy * T1x;
+                float nhx = t1 * T1x - zq * t2;
+                float nhy = t1 * T1y + t2 * T2y;
+                float nhz = t2 * T2z;
+                const float sq2 = __builtin_sqrtf(fmax_c(c1 - t2 * t2, 0.0f));
+                nhx = nhx + sq2 * vhx; nhy = nhy + sq2 * vhy; nhz = nhz + sq2 * vhz;
+                const float nex = nhx * ax, ney = nhy * ay, nez = fmax_c(nhz, 0.0f);
+                const float rn = rsq((nez * nez + ney * ney) + nex * nex);
+                const float whx = nex * rn, why = ney * rn, whz = nez * rn;
+                // wiLocal = 2 dot(wh, wo) wh - wo :527
+                const float dwh = (whz * woz + why * woy) + whx * wox;
+                const float two = 2.0f * dwh;
+                const float hx2 = two * whx, hy2 = two * why, hz2 = two * whz;  // = wi + wo
+                wlx = hx2 - wox; wly = hy2 - woy; wlz = hz2 - woz;
+                const float c2 = wlz * wlz, s2 = 1.0f - c2;
+                const float Fx = fresnel1(c2, s2, wlz, M.m2.x, M.m1.x);
+                const float Fy = fresnel1(c2, s2, wlz, M.m2.y, M.m1.y);
+                const float Fz = fresnel1(c2, s2, wlz, M.m2.z, M.m1.z);
+                // microfacetGGXBRDF :186-193
+                const float rh = rsq((hz2 * hz2 + hy2 * hy2) + hx2 * hx2);
+                const float D = ggx(hx2 * rh, hy2 * rh, hz2 * rh, ax, ay);
+                const float wisx = wlx * ax, wisy = wly * ay;
+                const float len_wi = __builtin_sqrtf((c2 + wisy * wisy) + wisx * wisx);
+                const float len_wo = __builtin_sqrtf(lw);
+                const float den = 2.0f * (__builtin_fabsf(woz) * len_wi + __builtin_fabsf(wlz) * len_wo);
+                const float brdf = D / den;
+                fx = Fx * brdf; fy = Fy * brdf; fz = Fz * brdf;
+                // weightedGGXPDF :216-219
+                const float D2 = ggx(whx, why, whz, ax, ay);
+                const float g1 = 0.5f / (len_wo + woz);
+                const float pn = (g1 * D2) * fmax_c(dwh, 0.0f);
+                const float dwi = (wlz * whz + wly * why) + wlx * whx;
+                pdf = pn / fmax_c(dwi, PT_EPS);
+            }
+
+            // isBlack(f) || pdf == 0 :534, evaluated as min(|f|, |pdf|) == 0
+            {
+                const float lf = __builtin_sqrtf((fz * fz + fy * fy) + fx * fx);
+                if (fmin_g(lf, __builtin_fabsf(pdf)) == 0.0f) break;
+            }
+
+            // ---- sampleDirect :337-403
+            float cx = 0.f, cy = 0.f, cz = 0.f;
+            const float sox = xx + nx * PT_EPS, soy = xy + ny * PT_EPS, soz = xz + nz * PT_EPS;  // spawnRay :121-123
+            {
+                const float rl = pt_rand(rng);
+                int lid = (int)(rl * nLf);
+                lid = (sc.n_light - 1 < lid) ? sc.n_light - 1 : lid;
+                const float ua0 = pt_rand(rng);
+                const float ub0 = pt_rand(rng);
+                const bool flip = 1.0f < ua0 + ub0;
+                const float ua = flip ? 1.0f - ua0 : ua0;
+                const float ub = flip ? 1.0f - ub0 : ub0;
+                const float w0 = (1.0f - ua) - ub;
+                float4 V0, V1, V2, N0, N1, N2;
+                if (lid >= 0) {
+                    const float4 *Lp = sc.lights + 6 * lid;
+                    V0 = Lp[0]; V1 = Lp[1]; V2 = Lp[2]; N0 = Lp[3]; N1 = Lp[4]; N2 = Lp[5];
+                } else {  // u_nLights == 0: out-of-range texelFetch returns zeros in the reference's GL
+                    V0 = V1 = V2 = N0 = N1 = N2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                const float px = (w0 * V0.x + ua * V1.x) + ub * V2.x;
+                const float py = (w0 * V0.y + ua * V1.y) + ub * V2.y;
+                const float pz = (w0 * V0.z + ua * V1.z) + ub * V2.z;
+                const float nlx = (w0 * N0.x + ua * N1.x) + ub * N2.x;
+                const float nly = (w0 * N0.y + ua * N1.y) + ub * N2.y;
+                const float nlz = (w0 * N0.z + ua * N1.z) + ub * N2.z;
+                const float dvx = px - xx, dvy = py - xy, dvz = pz - xz;
+                const float dd = (dvz * dvz + dvy * dvy) + dvx * dvx;
+                const float rd = rsq(dd);
+                const float dirx = dvx * rd, diry = dvy * rd, dirz = dvz * rd;
+                const Hit sh = traverse<false>(sc, stack, sox, soy, soz, dirx, diry, dirz);
+                rays++;
+                const float dist = __builtin_sqrtf(dd);
+                if (sh.tri >= 0 && __builtin_fabsf(dist - sh.t) < PT_EPS) {  // :367
+                    float gx = 0.f, gy = 0.f, gz = 0.f;
+                    if (type == 2) {
+                        gx = M.m1.x; gy = M.m1.y; gz = M.m1.z;  // albedo without 1/PI :372
+                    } else if (type == 3) {
+                        const float ax = M.m1.w, ay = M.m2.w;
+                        const float cosI = fmax_c((-(dirz * nz) - (diry * ny)) - (dirx * nx), 0.0f);
+                        const float c2 = cosI * cosI, s2 = 1.0f - c2;
+                        const float Fx = fresnel1(c2, s2, cosI, M.m2.x, M.m1.x);
+                        const float Fy = fresnel1(c2, s2, cosI, M.m2.y, M.m1.y);
+                        const float Fz = fresnel1(c2, s2, cosI, M.m2.z, M.m1.z);
+                        const float ilx = (uz * dirz - nuy * diry) + ux * dirx;
+                        const float ily = (vz * dirz + vy * diry) + vx * dirx;
+                        const float ilz = (dirz * nz + diry * ny) + dirx * nx;
+                        const float hx = ilx + wox, hy = ily + woy, hz = ilz + woz;
+                        const float rh = rsq((hz * hz + hy * hy) + hx * hx);
+                        const float D = ggx(hx * rh, hy * rh, hz * rh, ax, ay);
+                        const float wisx = ilx * ax, wisy = ily * ay;
+                        const float len_wi = __builtin_sqrtf((ilz * ilz + wisy * wisy) + wisx * wisx);
+                        const float wosx = wox * ax, wosy = woy * ay;
+                        const float len_wo = __builtin_sqrtf((woz * woz + wosy * wosy) + wosx * wosx);
+                        const float den = 2.0f * (__builtin_fabsf(woz) * len_wi + __builtin_fabsf(ilz) * len_wo);
+                        const float brdf = D / den;
+                        gx = Fx * brdf; gy = Fy * brdf; gz = Fz * brdf;
+                    }
+                    const Mat LM = load_mat(sc, lds_mats, __float_as_int(V0.w));
+                    const float dot0 = (dirz * nz + diry * ny) + dirx * nx;
+                    const float dot1 = (-(dirz * nlz) - (diry * nly)) - (dirx * nlx);
+                    if (0.0f < fmin_g(dot0, dot1)) {
+                        const float e1x = V1.x - V0.x, e1y = V1.y - V0.y, e1z = V1.z - V0.z;
+                        const float e2x = V2.x - V0.x, e2y = V2.y - V0.y, e2z = V2.z - V0.z;
+                        const float kx = e1y * e2z - e1z * e2y;
+                        const float ky = e1z * e2x - e1x * e2z;
+                        const float kz = e1x * e2y - e1y * e2x;
+                        const float G = (dot0 * dot1) / dd;  // dist*dist is folded to dd
+                        const float area = 0.5f * __builtin_sqrtf((kz * kz + ky * ky) + kx * kx);
+                        const float lpdf = 1.0f / (area * nLf);
+                        cx = ((LM.m0.x * gx) * G) / lpdf;
+                        cy = ((LM.m0.y * gy) * G) / lpdf;
+                        cz = ((LM.m0.z * gz) * G) / lpdf;
+                    }
+                }
+            }
+            Lx = Lx + bx * cx; Ly = Ly + by * cy; Lz = Lz + bz * cz;  // :539
+            // :542-544; wi is not renormalised
+            const float wix = (ux * wlx + vx * wly) + nx * wlz;
+            const float wiy = (-(nuy * wlx) + vy * wly) + ny * wlz;
+            const float wiz = (uz * wlx + vz * wly) + nz * wlz;
+            ox = sox; oy = soy; oz = soz;
+            dx = wix; dy = wiy; dz = wiz;
+            const float cw = fmax_c((nz * wiz + ny * wiy) + nx * wix, 0.0f);
+            bx = bx * ((fx * cw) / pdf);
+            by = by * ((fy * cw) / pdf);
+            bz = bz * ((fz * cw) / pdf);
+        }
+
+        // Russian roulette :549-555
+        if (2 < depth) {
+            float pm = fmax_g(by, bz);
+            pm = fmax_g(bx, pm);
+            const float pq = fmin_c(pm, 0.95f);
+            const float rr = pt_rand(rng);
+            if (pq < rr) break;
+            bx = bx / pq; by = by / pq; bz = bz / pq;
+        }
+    }
+    Lr = fmin_c(Lx, 100.0f); Lg = fmin_c(Ly, 100.0f); Lb = fmin_c(Lz, 100.0f);  // :558
+}
+
+// Blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of screen tiles so
+// that neighbouring tiles (which walk the same BVH subtrees) share one L2.  Bijective for any n.
+DEV int xcd_swizzle(int bid, int n) {
+    constexpr int X = 8;
+    const int per = n / X, rem = n % X;
+    const int xcd = bid % X, k = bid / X;
+    // XCD x owns per + (x < rem) tiles; tiles of XCD x start at x*per + min(x, rem)
+    return xcd * per + (xcd < rem ? xcd : rem) + k;
+}
+
+// ------------------------------------------------------------------------------------------ main :565-614
+template <bool COUNT_RAYS>
+__global__ __launch_bounds__(kBlockThreads) void pt_render_kernel(const KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float4 *lds_mats = reinterpret_cast<float4 *>(lds_raw);
+    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    int *stack = reinterpret_cast<int *>(lds_raw + (size_t)mat_f4 * sizeof(float4)) + threadIdx.x;
+
+    if (a.sc.mats_in_lds) {
+        for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
+        __syncthreads();
+    }
+
+    const int tile = xcd_swizzle(blockIdx.x, a.n_tiles);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = (tile % a.tiles_x) * kTile + (wave & 1) * 8 + (lane & 7);
+    const int lrow = (tile / a.tiles_x) * kTile + (wave >> 1) * 8 + (lane >> 3);
+    unsigned rays = 0;
+    if (lx < a.width && lrow < a.owned_rows) {
+        // owned stripe s holds global stripe s*world + rank
+        const int gy = ((lrow / a.stripe) * a.world + a.rank) * a.stripe + lrow % a.stripe;
+        const float W = (float)a.width, H = (float)a.height;
+        const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
+        Rng rng;
+        rng.x = fcx / W; rng.y = fcy / H; rng.sx = a.seed_x; rng.sy = a.seed_y;  // :567
+        float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
+        float4 acc = *px;  // previous (L, count): read-modify-write replaces the ping-pong FBOs (:570-572)
+        const float *S = a.s2c, *C = a.c2w;
+        for (int i = 0; i < a.n_samples; i++) {
+            const float r0 = pt_rand(rng);
+            const float r1 = pt_rand(rng);
+            const float nx = ((fcx + r0) / W) * 2.0f + -1.0f;
+            const float ny = ((fcy + r1) / H) * 2.0f + -1.0f;
+            // u_s2cMat * (nx, ny, 0, 1), summed as (col0*nx + col3) + col1*ny
+            const float tx = (S[0] * nx + S[12]) + S[4] * ny;
+            const float ty = (S[1] * nx + S[13]) + S[5] * ny;
+            const float tz = (S[2] * nx + S[14]) + S[6] * ny;
+            const float tw = (S[3] * nx + S[15]) + S[7] * ny;
+            const float cx = tx / tw, cy = ty / tw, cz = tz / tw;
+            const float rn = rsq((cz * cz + cy * cy) + cx * cx);
+            float dx = cx * rn, dy = cy * rn, dz = cz * rn;
+            float lox = 0.0f, loy = 0.0f;
+            if (0.0f < a.aperture) {  // thin lens :589-598
+                const float ra = pt_rand(rng);
+                const float rb = pt_rand(rng);
+                const float r = __builtin_sqrtf(ra) * a.aperture;
+                const float th = PT_2PI * rb;
+                lox = r * pt_cos(th);
+                loy = r * pt_sin(th);
+                const float ft = (-a.focal) / dz;
+                const float fx = dx * ft - lox, fy = dy * ft - loy, fz = dz * ft;
+                const float rf = rsq((fz * fz + fy * fy) + fx * fx);
+                dx = fx * rf; dy = fy * rf; dz = fz * rf;
+            }
+            // u_c2wMat * (o, 1), divided by w; u_c2wMat * (d, 0), normalised (:601-607)
+            const float wx = (C[0] * lox + C[12]) + C[4] * loy;
+            const float wy = (C[1] * lox + C[13]) + C[5] * loy;
+            const float wz = (C[2] * lox + C[14]) + C[6] * loy;
+            const float ww = (C[3] * lox + C[15]) + C[7] * loy;
+            const float ex = (C[0] * dx + C[4] * dy) + C[8] * dz;
+            const float ey = (C[1] * dx + C[5] * dy) + C[9] * dz;
+            const float ez = (C[2] * dx + C[6] * dy) + C[10] * dz;
+            const float re = rsq((ez * ez + ey * ey) + ex * ex);
+            float Lr, Lg, Lb;
+            radiance(a, lds_mats, stack, rng, wx / ww, wy / ww, wz / ww, ex * re, ey * re, ez * re, Lr, Lg, Lb, rays);
+            acc.x = acc.x + Lr; acc.y = acc.y + Lg; acc.z = acc.z + Lb;
+            acc.w = acc.w + 1.0f;
+        }
+        *px = acc;  // 8 lanes x 16 B = one 128 B segment per tile row
+    }
+    if (COUNT_RAYS) {
+        // wave-level sum, one atomic per wavefront
+        unsigned long long r = rays;
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+        if ((threadIdx.x & 63) == 0 && r) atomicAdd(a.ray_counter, r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ resolve
+// screen.frag:15-25 (rgb/count, clamp, pow 1/gamma) + saveCurrentFrame's RGBA8 read-back with
+// optional vertical flip (window.cpp:383-414).  Bandwidth-bound: 16 B in, 4 B out per pixel.
+__global__ __launch_bounds__(256) void resolve_kernel(const float4 *accum, int pitch_f4, int width, int rows,
+                                                      uchar4 *out, int out_pitch_px, float inv_gamma, int flip) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= rows) return;
+    const float4 v = accum[(size_t)y * pitch_f4 + x];
+    float r = v.x / v.w, g = v.y / v.w, b = v.z / v.w;
+    r = __builtin_powf(__builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f), inv_gamma);
+    g = __builtin_powf(__builtin_fminf(__builtin_fmaxf(g, 0.f), 1.f), inv_gamma);
+    b = __builtin_powf(__builtin_fminf(__builtin_fmaxf(b, 0.f), 1.f), inv_gamma);
+    const int oy = flip ? rows - 1 - y : y;
+    // GL float -> unorm8 conversion: round(f * 255)
+    out[(size_t)oy * out_pitch_px + x] =
+        make_uchar4((unsigned char)(r * 255.0f + 0.5f), (unsigned char)(g * 255.0f + 0.5f),
+                    (unsigned char)(b * 255.0f + 0.5f), 255);
+}
+
+}  // namespace glrtx
