@@ -1,0 +1,59 @@
+// main.cpp -- headless render-loop entry point with the shape of the reference's main
+// (src/main.cpp:9-31): parse arguments -> Window() -> Scene::parse(-i file) -> Window::mainloop().
+// Extra flags drive what the reference hard-codes or leaves to the shader defaults.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "scene.h"
+#include "window.h"
+
+using namespace glrt;
+
+static void usage(const char *exe) {
+    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--out file.png] [--device G]\n"
+                "  -i, --input             scene description (JSON; schema: SURVEY.md Appendix C)            [required]\n"
+                "  -s, --sample-per-cycle  accepted for compatibility; like the reference (main.cpp:13) it is not read\n"
+                "      --max-depth D       u_maxDepth (default 16, the reference shader's default)\n"
+                "      --spp N             samples per pixel per frame, u_nSamples (default 1 as window.cpp:239)\n"
+                "      --frames F          frames to accumulate before exiting (default 16)\n"
+                "      --out file.png      tonemapped output (default output.png, written after the last frame)\n"
+                "      --device G          HIP device ordinal (default: current)\n", exe);
+}
+
+int main(int argc, char **argv) {
+    std::string input, out = "output.png";
+    int depth = 16, spp = 1, frames = 16, device = -1;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", name); std::exit(1); }
+            return argv[++i];
+        };
+        if (a == "-i" || a == "--input") input = next("--input");
+        else if (a == "-s" || a == "--sample-per-cycle") (void)next("--sample-per-cycle");
+        else if (a == "--max-depth") depth = std::atoi(next("--max-depth"));
+        else if (a == "--spp") spp = std::atoi(next("--spp"));
+        else if (a == "--frames") frames = std::atoi(next("--frames"));
+        else if (a == "--out") out = next("--out");
+        else if (a == "--device") device = std::atoi(next("--device"));
+        else { usage(argv[0]); return 1; }
+    }
+    if (input.empty()) { usage(argv[0]); return 1; }
+
+    auto window = std::make_unique<Window>();
+    window->setDevice(device);
+    window->setMaxDepth(depth);
+    window->setSamplesPerFrame(spp);
+    window->setFrameLimit(frames);
+    window->setOutput(out);
+
+    auto scene = std::make_shared<Scene>();
+    scene->parse(input);
+
+    window->mainloop(scene);
+    std::printf("[INFO] %d frames, last frame %.3f ms, %llu rays\n", frames, window->lastFrameMs(), window->raysTraced());
+    return 0;
+}

@@ -1,0 +1,226 @@
+// scene.cpp -- glrt::Scene::parse and helpers.  Behaviour follows the reference's parser
+// (src/core/scene.cpp:31-276) key by key: same required keys (abort on absence), same defaults and
+// warnings for optional ones, one material per shape, material id = shape order, light list =
+// triangles of shapes with non-zero emission.  Parsers are own code (json.h, loadObj below).
+#include "scene.h"
+
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "glrt_host.h"
+#include "json.h"
+
+namespace glrt {
+
+namespace {
+std::string dirOf(const std::string &path) {
+    const size_t p = path.find_last_of("/\\");
+    return p == std::string::npos ? std::string(".") : path.substr(0, p);
+}
+void vec3(const Json &j, float out[3]) {
+    for (int k = 0; k < 3; k++) out[k] = (float)j[(size_t)k].number_value();
+}
+void fill3(float out[3], float v) { out[0] = out[1] = out[2] = v; }
+}  // namespace
+
+Scene::Scene() {
+    std::memset(modelM, 0, sizeof modelM);
+    std::memset(viewM, 0, sizeof viewM);
+    std::memset(projM, 0, sizeof projM);
+    for (int i = 0; i < 4; i++) modelM[i * 5] = viewM[i * 5] = projM[i * 5] = 1.0f;
+}
+
+Scene::Scene(const std::string &filename) : Scene() { parse(filename); }
+
+void Scene::parse(const std::string &filename) {
+    std::ifstream reader(filename.c_str(), std::ios::in);
+    if (reader.fail()) GLRT_FatalError("Failed to open file: %s", filename.c_str());
+    std::stringstream ss;
+    ss << reader.rdbuf();
+    std::string err;
+    const Json json = Json::parse(ss.str(), err);
+    if (!err.empty()) GLRT_Warn("%s", err.c_str());
+    const std::string baseDir = dirOf(filename);
+
+    // film (scene.cpp:57-60)
+    width = json["film"]["width"].int_value();
+    height = json["film"]["height"].int_value();
+    GLRT_Info("window: %d x %d", width, height);
+
+    // camera (scene.cpp:62-114)
+    const std::string type = json["camera"]["type"].string_value();
+    GLRT_Info("Camera type: %s", type.c_str());
+    if (type == "perspective") {
+        const Json &cam = json["camera"];
+        apertureRadius = (float)cam["apertureRadius"].number_value();  // absent -> 0
+        focalLength = (float)cam["focalLength"].number_value();        // absent -> 0 (scene.cpp:71-74)
+        if (cam["lookAt"].is_null()) GLRT_FatalError("perspective camera node does not have \"lookAt\" key!");
+        float origin[3], target[3], up[3];
+        vec3(cam["lookAt"]["origin"], origin);
+        vec3(cam["lookAt"]["target"], target);
+        vec3(cam["lookAt"]["up"], up);
+        glrt_look_at(origin, target, up, viewM);
+        if (cam["fov"].is_null()) GLRT_FatalError("perspective camera node does not have \"fov\" key!");
+        if (cam["nearClip"].is_null()) GLRT_FatalError("perspective camera node does not have \"nearClip\" key!");
+        if (cam["farClip"].is_null()) GLRT_FatalError("perspective camera node does not have \"farClip\" key!");
+        glrt_perspective((float)cam["fov"].number_value(), (float)width / (float)height,
+                         (float)cam["nearClip"].number_value(), (float)cam["farClip"].number_value(), projM);
+    }
+
+    // shapes (scene.cpp:116-250)
+    vertices.clear(); triangles.clear(); lights.clear(); materials.clear(); nodes.clear();
+    const auto &shapes = json["scene"].array_items();
+    for (size_t i = 0; i < shapes.size(); i++) {
+        const Json &sh = shapes[i];
+        const std::string material = sh["material"].string_value();
+        Material m;
+        std::memset(&m, 0, sizeof m);
+        if (material == "diffuse") {
+            fill3(m.type, (float)MaterialType::Diffuse);
+            if (sh["reflectance"].is_null()) { GLRT_Warn("diffuse node does not have \"reflectance\" key!"); fill3(m.param0, 0.5f); }
+            else vec3(sh["reflectance"], m.param0);
+        } else if (material == "conductor") {
+            fill3(m.type, (float)MaterialType::Conductor);
+            if (sh["kappa"].is_null()) { GLRT_Warn("conductor node does not have \"kappa\" key!"); fill3(m.param0, 1.0f); }
+            else vec3(sh["kappa"], m.param0);
+            if (sh["eta"].is_null()) { GLRT_Warn("conductor node does not have \"eta\" key!"); fill3(m.param1, 1.0f); }
+            else vec3(sh["eta"], m.param1);
+            if (sh["alpha"].is_null()) { GLRT_Warn("conductor node does not have \"alpha\" key!"); fill3(m.param2, 0.0f); }
+            else fill3(m.param2, (float)sh["alpha"].number_value());
+        } else if (material == "emitter") {
+            fill3(m.type, (float)MaterialType::Emitter);
+            if (sh["emission"].is_null()) GLRT_Warn("emitter node does not have \"emission\" key!");
+            else vec3(sh["emission"], m.emission);
+        } else if (material == "media") {
+            // The reference uploads two 3D textures here, but its shader's volume branch is compiled
+            // out (raytrace.frag:4, :424-487): the material only marks the surface as pass-through.
+            fill3(m.type, (float)MaterialType::Media);
+        } else {
+            GLRT_FatalError("Unsupported material: %s", material.c_str());
+        }
+        materials.push_back(m);
+
+        if (sh["type"].string_value() == "obj") {
+            const std::string file = baseDir + "/" + sh["filename"].string_value();
+            std::vector<Vertex> mesh;
+            std::string oerr;
+            if (!loadObj(file, mesh, oerr)) GLRT_FatalError("Failed to load *.obj file: %s (%s)", file.c_str(), oerr.c_str());
+            const size_t base = vertices.size();
+            vertices.insert(vertices.end(), mesh.begin(), mesh.end());
+            for (size_t t = 0; t + 2 < mesh.size(); t += 3) {
+                Triangle tri;
+                tri.indices[0] = (float)(base + t);
+                tri.indices[1] = (float)(base + t + 1);
+                tri.indices[2] = (float)(base + t + 2);
+                tri.indices[3] = (float)(materials.size() - 1);
+                triangles.push_back(tri);
+            }
+        }
+    }
+    finalize();
+    GLRT_Info("Scene setup OK!");
+    GLRT_Info("#vertex: %d", (int)vertices.size());
+    GLRT_Info("#triangle: %d", (int)triangles.size());
+    GLRT_Info("#BVH node: %d", (int)nodes.size());
+}
+
+void Scene::setBuffers(int w, int h, const float view[16], const float proj[16], float aperture, float focal,
+                       std::vector<Vertex> v, std::vector<Triangle> t, std::vector<Material> m, std::vector<BVHNode> n) {
+    width = w; height = h; apertureRadius = aperture; focalLength = focal;
+    std::memcpy(viewM, view, sizeof viewM);
+    std::memcpy(projM, proj, sizeof projM);
+    vertices = std::move(v); triangles = std::move(t); materials = std::move(m); nodes = std::move(n);
+    finalize();
+}
+
+void Scene::finalize() {
+    lights.clear();
+    for (const Triangle &t : triangles) {
+        const size_t m = (size_t)t.indices[3];
+        if (m < materials.size()) {
+            const float *e = materials[m].emission;
+            if (std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) != 0.0f) lights.push_back(t);  // scene.cpp:246-248
+        }
+    }
+    if (nodes.empty() && !triangles.empty()) {
+        nodes.resize(glrt_bvh_node_count(triangles.size()));
+        const int rc = glrt_bvh_build_sah(&vertices[0].pos[0], vertices.size(), &triangles[0].indices[0], triangles.size(),
+                                          &nodes[0].bboxMin[0], &bvhDepth_);
+        if (rc != GLRT_HOST_OK) GLRT_FatalError("BVH construction failed (%d)", rc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ OBJ
+bool loadObj(const std::string &filename, std::vector<Vertex> &out, std::string &err) {
+    std::ifstream in(filename.c_str());
+    if (in.fail()) { err = "cannot open"; return false; }
+    std::vector<float> P, N, T;
+    struct Corner { int v, t, n; };
+    std::vector<Corner> corners;  // 3 per triangle
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag) || tag[0] == '#') continue;
+        if (tag == "v") { float x, y, z; ls >> x >> y >> z; P.insert(P.end(), {x, y, z}); }
+        else if (tag == "vn") { float x, y, z; ls >> x >> y >> z; N.insert(N.end(), {x, y, z}); }
+        else if (tag == "vt") { float u = 0, v = 0; ls >> u >> v; T.insert(T.end(), {u, v}); }
+        else if (tag == "f") {
+            std::vector<Corner> poly;
+            std::string tok;
+            while (ls >> tok) {
+                Corner c{-1, -1, -1};
+                int *slot[3] = {&c.v, &c.t, &c.n};
+                size_t s = 0;
+                for (int k = 0; k < 3 && s <= tok.size(); k++) {
+                    const size_t e = tok.find('/', s);
+                    const std::string part = tok.substr(s, e == std::string::npos ? std::string::npos : e - s);
+                    if (!part.empty()) {
+                        const int idx = std::atoi(part.c_str());
+                        const int count = (int)((k == 0 ? P.size() / 3 : k == 1 ? T.size() / 2 : N.size() / 3));
+                        *slot[k] = idx > 0 ? idx - 1 : count + idx;  // negative = relative to the end
+                    }
+                    if (e == std::string::npos) break;
+                    s = e + 1;
+                }
+                poly.push_back(c);
+            }
+            for (size_t k = 1; k + 1 < poly.size(); k++) {  // fan triangulation
+                corners.push_back(poly[0]); corners.push_back(poly[k]); corners.push_back(poly[k + 1]);
+            }
+        }
+    }
+    bool hasNorm = !corners.empty();
+    out.clear();
+    out.reserve(corners.size());
+    for (const Corner &c : corners) {
+        Vertex v;
+        std::memset(&v, 0, sizeof v);
+        if (c.v < 0 || (size_t)c.v * 3 + 2 >= P.size()) { err = "vertex index out of range"; return false; }
+        std::memcpy(v.pos, &P[(size_t)c.v * 3], 12);
+        if (c.n >= 0 && (size_t)c.n * 3 + 2 < N.size()) {
+            const float *n = &N[(size_t)c.n * 3];
+            const float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            for (int k = 0; k < 3; k++) v.normal[k] = n[k] / l;  // normalised on load (trimesh.cpp:162)
+        } else {
+            hasNorm = false;
+        }
+        if (c.t >= 0 && (size_t)c.t * 2 + 1 < T.size()) { v.uv[0] = T[(size_t)c.t * 2]; v.uv[1] = T[(size_t)c.t * 2 + 1]; }
+        out.push_back(v);
+    }
+    if (!hasNorm) {  // face normals accumulated per vertex (trimesh.cpp:38-64); vertices are not shared
+        for (size_t t = 0; t + 2 < out.size(); t += 3) {
+            const float *a = out[t].pos, *b = out[t + 1].pos, *c = out[t + 2].pos;
+            const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            for (int k = 0; k < 3; k++) n[k] = l != 0.0f ? n[k] / l : 0.0f;
+            for (int q = 0; q < 3; q++) std::memcpy(out[t + q].normal, n, 12);
+        }
+    }
+    return true;
+}
+
+}  // namespace glrt

@@ -1,0 +1,164 @@
+// window.cpp -- headless glrt::Window over the C-ABI HIP layer.  Structure follows the reference's
+// Window (src/core/window.cpp): mainloop :105-182, render :213-318, resetBuffer :366-381,
+// saveCurrentFrame :383-414; every GL call is replaced by its glrtx_* counterpart.
+#include "window.h"
+
+#include <chrono>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+#include "glrt_host.h"
+#include "glrtx.h"
+
+namespace glrt {
+
+#define GLRTX_CHECK(call)                                                                        \
+    do {                                                                                         \
+        if ((call) != GLRTX_OK) GLRT_FatalError("%s: %s", #call, glrtx_last_error(ctx_));        \
+    } while (0)
+
+Window::Window() {
+    if (const char *e = std::getenv("GLRT_FRAMES")) frameLimit_ = std::atoi(e);
+    if (const char *e = std::getenv("GLRT_MAX_DEPTH")) maxDepth_ = std::atoi(e);
+}
+
+Window::~Window() {
+    if (ctx_) glrtx_destroy(ctx_);
+}
+
+unsigned long long Window::raysTraced() const {
+    glrtx_stats st;
+    if (!ctx_ || glrtx_get_stats(ctx_, &st) != GLRTX_OK) return 0;
+    return st.rays;
+}
+
+void Window::mainloop(const std::shared_ptr<Scene> &scene_, double fps) {
+    (void)fps;  // the reference's default fps = -1 renders every iteration (window.cpp:126); so do we
+    scene = scene_;
+    if (!ctx_ && glrtx_create(&ctx_, device_) != GLRTX_OK) GLRT_FatalError("glrtx_create: %s", glrtx_last_error(nullptr));
+    // scene upload: the five buffers Scene::parse handed to TextureBuffer::setData (scene.cpp:254-269)
+    GLRTX_CHECK(glrtx_upload_scene(
+        ctx_, scene->vertices.empty() ? nullptr : &scene->vertices[0].pos[0], scene->vertices.size(),
+        scene->triangles.empty() ? nullptr : &scene->triangles[0].indices[0], scene->triangles.size(),
+        scene->materials.empty() ? nullptr : &scene->materials[0].type[0], scene->materials.size(),
+        scene->lights.empty() ? nullptr : &scene->lights[0].indices[0], scene->lights.size(),
+        scene->nodes.empty() ? nullptr : &scene->nodes[0].bboxMin[0], scene->nodes.size()));
+    resize(scene->width, scene->height);
+    initialize();
+    for (int i = 0; i < frameLimit_; i++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        render();
+        GLRTX_CHECK(glrtx_sync(ctx_));
+        lastMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (saveEveryFrame_ && !output_.empty()) saveCurrentFrame(output_, true);  // window.cpp:164
+    }
+    if (!saveEveryFrame_ && !output_.empty() && frameLimit_ > 0) saveCurrentFrame(output_, true);
+}
+
+void Window::initialize() { GLRTX_CHECK(glrtx_count_rays(ctx_, 1)); }
+
+void Window::render() {
+    // window.cpp:230-243: the per-frame uniforms
+    glrtx_params p;
+    float cam[16];
+    glrt_mat4_mul(scene->viewM, scene->modelM, cam);
+    if (glrt_mat4_inverse(cam, p.c2w) != GLRT_HOST_OK || glrt_mat4_inverse(scene->projM, p.s2c) != GLRT_HOST_OK)
+        GLRT_FatalError("camera matrix is singular");
+    p.aperture = scene->apertureRadius;
+    p.focal = scene->focalLength;
+    glrt_frame_seed(frame_++, p.seed);
+    p.n_samples = samplesPerFrame_;
+    p.max_depth = maxDepth_;
+    GLRTX_CHECK(glrtx_render(ctx_, &p));  // window.cpp:290, the draw that runs the path tracer
+}
+
+void Window::resizeDefault(int w, int h) {
+    width_ = w;
+    height_ = h;
+    resetBuffer();
+}
+
+void Window::resetBuffer() { GLRTX_CHECK(glrtx_resize(ctx_, width_, height_)); }  // window.cpp:366-381
+
+void Window::saveCurrentFrame(const std::string &filename, bool overwrite) const {
+    std::vector<unsigned char> bytes((size_t)width_ * height_ * 4);
+    // resolve = screen.frag (rgb/count, clamp, gamma 2.2) + the vertical flip of window.cpp:391-398
+    if (glrtx_resolve_rgba8(ctx_, bytes.data(), (size_t)width_ * 4, 2.2f, 1) != GLRTX_OK)
+        GLRT_FatalError("glrtx_resolve_rgba8: %s", glrtx_last_error(ctx_));
+    std::string path = filename;
+    if (!overwrite) {
+        int count = 0;
+        const size_t dot = filename.find_last_of('.');
+        const std::string base = filename.substr(0, dot), ext = dot == std::string::npos ? "" : filename.substr(dot);
+        while (std::ifstream(path).good()) path = base + "_" + std::to_string(count++) + ext;
+    }
+    if (!writePng(path, width_, height_, bytes.data())) GLRT_Warn("Failed to save: %s", path.c_str());
+    else GLRT_Info("Save: %s", path.c_str());
+}
+
+// ---------------------------------------------------------------------------------------------- PNG
+namespace {
+uint32_t crc32(const unsigned char *d, size_t n, uint32_t c = 0) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t r = i;
+            for (int k = 0; k < 8; k++) r = (r & 1) ? 0xEDB88320u ^ (r >> 1) : r >> 1;
+            table[i] = r;
+        }
+        init = true;
+    }
+    c = ~c;
+    for (size_t i = 0; i < n; i++) c = table[(c ^ d[i]) & 0xFF] ^ (c >> 8);
+    return ~c;
+}
+void be32(std::vector<unsigned char> &v, uint32_t x) {
+    v.push_back((unsigned char)(x >> 24)); v.push_back((unsigned char)(x >> 16));
+    v.push_back((unsigned char)(x >> 8)); v.push_back((unsigned char)x);
+}
+void chunk(std::vector<unsigned char> &out, const char *type, const std::vector<unsigned char> &data) {
+    be32(out, (uint32_t)data.size());
+    std::vector<unsigned char> td(type, type + 4);
+    td.insert(td.end(), data.begin(), data.end());
+    out.insert(out.end(), td.begin(), td.end());
+    be32(out, crc32(td.data(), td.size()));
+}
+}  // namespace
+
+bool writePng(const std::string &filename, int w, int h, const unsigned char *rgba) {
+    std::vector<unsigned char> raw;
+    raw.reserve((size_t)h * ((size_t)w * 4 + 1));
+    for (int y = 0; y < h; y++) {
+        raw.push_back(0);  // filter: none
+        raw.insert(raw.end(), rgba + (size_t)y * w * 4, rgba + (size_t)(y + 1) * w * 4);
+    }
+    std::vector<unsigned char> z = {0x78, 0x01};  // zlib header, stored blocks
+    uint32_t a = 1, b = 0;
+    for (unsigned char c : raw) { a = (a + c) % 65521u; b = (b + a) % 65521u; }
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back((unsigned char)(n & 0xFF)); z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 0xFF)); z.push_back((unsigned char)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + (long)off, raw.begin() + (long)(off + n));
+        if (raw.empty()) break;
+    }
+    be32(z, (b << 16) | a);
+    std::vector<unsigned char> png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<unsigned char> ihdr;
+    be32(ihdr, (uint32_t)w); be32(ihdr, (uint32_t)h);
+    ihdr.insert(ihdr.end(), {8, 6, 0, 0, 0});  // 8-bit RGBA
+    chunk(png, "IHDR", ihdr);
+    chunk(png, "IDAT", z);
+    chunk(png, "IEND", {});
+    std::ofstream f(filename.c_str(), std::ios::binary);
+    if (f.fail()) return false;
+    f.write((const char *)png.data(), (std::streamsize)png.size());
+    return f.good();
+}
+
+}  // namespace glrt

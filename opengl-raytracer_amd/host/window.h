@@ -1,0 +1,65 @@
+// window.h -- glrt::Window, the drop-in render-loop class (reference: src/core/window.h:14-58).
+// Same public surface -- Window(), mainloop(scene, fps = -1), width(), height() -- and the same
+// protected virtual hooks (initialize/render/resize/mouse/keyboard), but headless: no GLFW window,
+// no GL context, no ImGui.  render() forwards to the C-ABI HIP layer (include/glrtx.h) where the
+// reference's render() issued GL calls (window.cpp:213-318).  Because nothing ever closes a headless
+// window, the loop runs for a fixed number of frames (setFrameLimit / GLRT_FRAMES, default 16).
+#pragma once
+#include <memory>
+#include <string>
+
+#include "common.h"
+#include "scene.h"
+
+struct glrtx_ctx;
+
+namespace glrt {
+
+struct MouseEvent { int button = 0, action = 0, mods = 0; double x = 0, y = 0; };  // event.h stand-in (never raised)
+
+class GLRT_API Window {
+public:
+    Window();
+    virtual ~Window();
+    void mainloop(const std::shared_ptr<Scene> &scene, double fps = -1.0);
+    int width() const { return width_; }
+    int height() const { return height_; }
+
+    // Headless controls (the reference hard-codes these: u_nSamples = 1 at window.cpp:239, u_maxDepth
+    // left at the shader default 16, a fresh random u_seed per frame at :226-238, output.png every frame).
+    void setFrameLimit(int frames) { frameLimit_ = frames; }
+    void setMaxDepth(int depth) { maxDepth_ = depth; }
+    void setSamplesPerFrame(int spp) { samplesPerFrame_ = spp; }
+    void setOutput(const std::string &file, bool everyFrame = false) { output_ = file; saveEveryFrame_ = everyFrame; }
+    void setDevice(int hipDevice) { device_ = hipDevice; }
+    void setFirstFrame(unsigned f) { frame_ = f; }
+    double lastFrameMs() const { return lastMs_; }
+    unsigned long long raysTraced() const;
+
+protected:
+    virtual void initialize();
+    virtual void render();
+    virtual void resize(int width, int height) { resizeDefault(width, height); }
+    virtual void mouse(const MouseEvent &) {}
+    virtual void keyboard(int, int, int, int) {}
+
+private:
+    void resizeDefault(int width, int height);
+    void resetBuffer();
+    void saveCurrentFrame(const std::string &filename, bool overwrite = true) const;
+
+    glrtx_ctx *ctx_ = nullptr;
+    int device_ = -1;
+    int width_ = 0, height_ = 0;
+    int frameLimit_ = 16, maxDepth_ = 16, samplesPerFrame_ = 1;
+    unsigned frame_ = 0;
+    bool saveEveryFrame_ = false;
+    std::string output_ = "output.png";
+    double lastMs_ = 0.0;
+    std::shared_ptr<Scene> scene = nullptr;
+};
+
+// RGBA8 -> PNG (stored deflate blocks; own encoder, the reference uses stb_image_write).
+bool writePng(const std::string &filename, int w, int h, const unsigned char *rgba);
+
+}  // namespace glrt

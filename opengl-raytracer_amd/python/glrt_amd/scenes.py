@@ -262,3 +262,49 @@ def scene_bytes(scene) -> int:
     n_mat = scene["mat"].reshape(-1, 18).shape[0]
     n_light = scene["light"].reshape(-1, 4).shape[0]
     return 88 * n_tri + 36 * n_node + 72 * n_mat + 16 * n_light
+
+
+# --------------------------------------------------------------------------- JSON + OBJ export (Scene::parse input)
+def export_json_obj(builder: SceneBuilder, directory, width, height, origin, target, up, fov_deg, near=0.1, far=100.0,
+                    aperture=None, focal=None, name="scene.json"):
+    """Write `builder`'s meshes as one OBJ per add_mesh() call plus the JSON scene description the
+    reference's Scene::parse reads (schema: SURVEY.md Appendix C).  Floats are written with 9 significant
+    digits, which round-trips float32 exactly.  Returns the JSON path."""
+    import json
+    import pathlib
+
+    d = pathlib.Path(directory)
+    d.mkdir(parents=True, exist_ok=True)
+    shapes = []
+    for k, (pos, nrm, mid) in enumerate(zip(builder._pos, builder._nrm, builder._mid)):
+        assert np.all(mid == mid[0]), "one material per shape (scene.cpp:124-219)"
+        m = builder.materials[int(mid[0])]
+        lines = []
+        for p in pos.reshape(-1, 3):
+            lines.append("v %.9g %.9g %.9g" % tuple(p))
+        for n in nrm.reshape(-1, 3):
+            lines.append("vn %.9g %.9g %.9g" % tuple(n))
+        for t in range(pos.shape[0]):
+            a = 3 * t + 1
+            lines.append(f"f {a}//{a} {a + 1}//{a + 1} {a + 2}//{a + 2}")
+        (d / f"shape{k}.obj").write_text("\n".join(lines) + "\n")
+        sh = {"type": "obj", "filename": f"shape{k}.obj"}
+        if m["type"] == MTRL_DIFFUSE:
+            sh.update(material="diffuse", reflectance=[float(v) for v in m["param0"]])
+        elif m["type"] == MTRL_CONDUCTOR:
+            sh.update(material="conductor", kappa=[float(v) for v in m["param0"]], eta=[float(v) for v in m["param1"]],
+                      alpha=float(m["param2"][0]))
+        elif m["type"] == MTRL_EMITTER:
+            sh.update(material="emitter", emission=[float(v) for v in m["emission"]])
+        else:
+            raise ValueError("export supports diffuse / conductor / emitter shapes")
+        shapes.append(sh)
+    cam = {"type": "perspective", "fov": fov_deg, "nearClip": near, "farClip": far,
+           "lookAt": {"origin": list(origin), "target": list(target), "up": list(up)}}
+    if aperture is not None:
+        cam["apertureRadius"] = aperture
+    if focal is not None:
+        cam["focalLength"] = focal
+    doc = {"film": {"width": width, "height": height}, "camera": cam, "scene": shapes}
+    (d / name).write_text(json.dumps(doc, indent=1))
+    return d / name

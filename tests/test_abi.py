@@ -1,0 +1,54 @@
+"""The C-ABI libraries load without a GPU and export every function include/*.h declares."""
+import ctypes as C
+import pathlib
+import re
+
+import pytest
+
+from conftest import PKG, ROOT
+
+HEADERS = {"glrtx.h": "libglrtx.so", "glrt_host.h": "libglrt_host.so"}
+
+
+def declared_functions(header: pathlib.Path):
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    text = re.sub(r"#.*", "", text)
+    text = re.sub(r"typedef struct [^{;]*\{.*?\}[^;]*;", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(glrtx?_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("header,libname", sorted(HEADERS.items()))
+def test_library_exports_every_declared_symbol(header, libname):
+    lib = PKG / "lib" / libname
+    assert lib.exists(), f"{lib} not built: run __graft_entry__.build()"
+    L = C.CDLL(str(lib))
+    names = declared_functions(ROOT / "include" / header)
+    assert len(names) >= 7
+    for n in names:
+        assert hasattr(L, n), f"{libname} does not export {n} declared in {header}"
+
+
+def test_glrtx_abi_version_and_no_device_error_path():
+    L = C.CDLL(str(PKG / "lib" / "libglrtx.so"))
+    assert L.glrtx_abi_version() == 1
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("error path is for boxes without a GPU")
+    h = C.c_void_p()
+    rc = L.glrtx_create(C.byref(h), 0)
+    assert rc == -2 and not h  # GLRTX_EDEVICE: fails loudly, no CPU fallback
+    L.glrtx_last_error.restype = C.c_char_p
+    L.glrtx_last_error.argtypes = [C.c_void_p]
+    assert b"HIP device" in L.glrtx_last_error(None)
+
+
+def test_python_binding_lists_the_same_exports():
+    from glrt_amd import device
+    names = declared_functions(ROOT / "include" / "glrtx.h")
+    assert set(device.EXPORTS) | {"glrtx_check_scene"} == set(names)
+
+
+def test_struct_layouts_match_header():
+    from glrt_amd import device
+    assert C.sizeof(device.Params) == 16 * 4 * 2 + 4 * 4 + 8
+    assert C.sizeof(device.Stats) == 72

@@ -1,0 +1,193 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libglrtx.so), against
+ (1) the committed golden images from the reference's own shader (tests/golden),
+ (2) the CPU oracle on seeded inputs at sizes it finishes in seconds,
+ (3) size-independent properties at BASELINE.json's full sizes.
+Bar: bit-exact float32 (stricter than north_star's 1e-4; the tolerance is asserted too)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal, golden_names, load_golden
+from glrt_amd import device, dist, host, scenes
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: "pixels within 1e-4 of the GL reference"
+
+
+def gpu_render(d, scene, params, frames=None, count_rays=True):
+    d.upload_scene(scene)
+    d.set_partition(0, 1, 16)
+    d.resize(params["width"], params["height"])
+    d.reset_stats()
+    d.count_rays(count_rays)
+    for sd in (frames or [params["seed"]]):
+        d.render(dict(params, seed=sd))
+    d.sync()
+    return d.read_accum(), d.stats()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_matches_reference_golden(gpu_device, name):
+    scene, params, rows, frames, rgb, cnt = load_golden(name)
+    acc, st = gpu_render(gpu_device, scene, params, frames)
+    acc = acc[rows[0]:rows[1]]
+    assert np.nanmax(np.abs(acc[..., :3] - rgb)) <= TOL
+    assert_bit_equal(acc[..., :3], rgb, f"{name} rgb")
+    assert_bit_equal(acc[..., 3], cnt, f"{name} count")
+
+
+ORACLE_CASES = [
+    ("c1", dict(width=256, height=256, max_depth=1, n_samples=1)),                  # BASELINE configs[0] at full size
+    ("c1", dict(width=200, height=120, max_depth=16, n_samples=4)),
+    ("c2", dict(width=480, height=270, max_depth=4, n_samples=1)),
+    ("headline", dict(width=480, height=270)),
+    ("c3", dict(width=240, height=135, max_depth=1, n=10_000)),                      # 10k triangles, chain BVH
+    ("c3", dict(width=240, height=135, max_depth=1, n=10_000, bvh="sah")),
+    ("c4", dict(width=384, height=216, max_depth=8, n_samples=16)),
+    ("c5", dict(width=480, height=270, max_depth=4, n=100_000)),                     # 100k triangles
+]
+
+
+@pytest.mark.parametrize("cfg,kw", ORACLE_CASES)
+def test_hip_bit_exact_vs_oracle(gpu_device, cfg, kw):
+    from oracle import pt_oracle
+    scene, params = scenes.CONFIGS[cfg](**kw)
+    ref, ref_rays = pt_oracle.render(scene, params)
+    acc, st = gpu_render(gpu_device, scene, params)
+    assert st.rays == ref_rays
+    assert_bit_equal(acc, ref, f"{cfg} {kw}")
+
+
+def test_dof_and_seed_sweep_vs_oracle(gpu_device):
+    from oracle import pt_oracle
+    scene, params = scenes.config_c1(128, 96, max_depth=6, n_samples=2)
+    rng = np.random.default_rng(11)
+    for i in range(4):
+        p = dict(params, seed=tuple(float(np.float32(v)) for v in rng.uniform(0, 1, 2)),
+                 aperture=0.25 * (i % 2), focal=8.0)
+        ref, _ = pt_oracle.render(scene, p)
+        acc, _ = gpu_render(gpu_device, scene, p)
+        assert_bit_equal(acc, ref, f"seed {p['seed']} aperture {p['aperture']}")
+
+
+# ---------------------------------------------------------------- full-size properties (no oracle at 1080p/4K)
+def test_full_size_determinism_and_partition_invariance(gpu_device):
+    """1920x1080, 8 bounces (the headline config): two runs agree bitwise, and stitching the row-stripe
+    partitions of world 2 and 8 reproduces the single-partition image bitwise (global pixel coordinates)."""
+    d = gpu_device
+    scene, params = scenes.config_headline()
+    full, st = gpu_render(d, scene, params)
+    again, _ = gpu_render(d, scene, params)
+    assert_bit_equal(full, again, "run-to-run")
+    assert st.rays > 2 * 1920 * 1080 and np.all(full[..., 3] == 1.0)
+    assert np.isfinite(full).all() and full[..., :3].max() <= 100.0 and full[..., :3].min() >= 0.0
+    h = params["height"]
+    for world in (2, 8):
+        stitched = np.zeros_like(full)
+        total_rays = 0
+        for rank in range(world):
+            d.set_partition(rank, world, 16)
+            d.resize(params["width"], h)
+            d.reset_stats()
+            d.count_rays(True)
+            d.render(params)
+            d.sync()
+            ys = dist.owned_rows(rank, world, 16, h)
+            assert np.array_equal(d.local_rows_y(), ys)
+            stitched[ys] = d.read_accum()
+            total_rays += d.stats().rays
+        assert_bit_equal(stitched, full, f"world {world}")
+        assert total_rays == st.rays
+    d.set_partition(0, 1, 16)
+
+
+def test_accumulation_is_additive_over_frames(gpu_device):
+    """Frames accumulate by read-modify-write: count == number of frames, and the sum of two single-frame
+    images equals the two-frame accumulator up to one rounding per add (exactly: a + b in float32)."""
+    d = gpu_device
+    scene, params = scenes.config_c2(640, 360, max_depth=4)
+    s0, s1 = host.frame_seed(0), host.frame_seed(1)
+    a, _ = gpu_render(d, scene, dict(params, seed=s0))
+    b, _ = gpu_render(d, scene, dict(params, seed=s1))
+    both, _ = gpu_render(d, scene, params, frames=[s0, s1])
+    assert np.all(both[..., 3] == 2.0)
+    assert_bit_equal(both[..., :3], a[..., :3] + b[..., :3], "two-frame accumulation")
+    assert not np.array_equal(a, b)
+
+
+def test_4k_16spp_one_pass_equals_16_counts(gpu_device):
+    d = gpu_device
+    scene, params = scenes.config_c4(3840, 2160, max_depth=8, n_samples=2)
+    acc, st = gpu_render(d, scene, params)
+    assert acc.shape == (2160, 3840, 4) and np.all(acc[..., 3] == 2.0)
+    assert st.paths == 3840 * 2160 * 2 and st.rays >= st.paths
+    assert np.isfinite(acc).all() and acc[..., :3].max() <= 200.0
+
+
+def test_resolve_rgba8_matches_numpy(gpu_device):
+    d = gpu_device
+    scene, params = scenes.config_c1(256, 128, max_depth=4, n_samples=4)
+    acc, _ = gpu_render(d, scene, params)
+    img = d.resolve_rgba8(gamma=2.2, flip_y=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = np.clip(acc[..., :3] / acc[..., 3:4], 0.0, 1.0) ** np.float32(1.0 / 2.2)
+    ref8 = np.floor(ref * 255.0 + 0.5).astype(np.int32)[::-1]
+    assert img.shape == (128, 256, 4) and np.all(img[..., 3] == 255)
+    assert np.abs(img[..., :3].astype(np.int32) - ref8).max() <= 1  # pow() implementations differ by ulps
+    assert np.array_equal(d.resolve_rgba8(gamma=2.2, flip_y=False), img[::-1])
+
+
+def test_bound_torch_accumulator_and_stream(gpu_device):
+    """glrtx_bind_accum / glrtx_set_stream: render straight into a torch CUDA tensor on torch's stream
+    (how bench.py hands rows to RCCL)."""
+    import torch
+    d = gpu_device
+    scene, params = scenes.config_c1(160, 96, max_depth=3, n_samples=1)
+    ref, _ = gpu_render(d, scene, params)
+    t = torch.zeros((96, 160, 4), dtype=torch.float32, device="cuda")
+    d.bind_accum(t.data_ptr(), 160 * 16)
+    d.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        d.render(params)
+        d.sync()
+        torch.cuda.synchronize()
+        assert_bit_equal(t.cpu().numpy(), ref, "bound accumulator")
+    finally:
+        d.set_stream(0)
+        d.bind_accum(0, 0)
+
+
+def test_error_behaviour(gpu_device):
+    d2 = device.Device()
+    try:
+        with pytest.raises(device.GlrtxError) as e:
+            d2.render(scenes.config_c1(32, 32, subdiv=1)[1])
+        assert e.value.code == device.GLRTX_EINVAL and "no scene" in str(e.value)
+        scene, params = scenes.config_c1(32, 32, subdiv=1)
+        bad = dict(scene, tri=scene["tri"].copy())
+        bad["tri"][0, 0] = -5
+        with pytest.raises(device.GlrtxError) as e:
+            d2.upload_scene(bad)
+        assert e.value.code == device.GLRTX_ESCENE
+        d2.upload_scene(scene)
+        with pytest.raises(device.GlrtxError):
+            d2.render(params)  # no resize yet
+        with pytest.raises(device.GlrtxError):
+            d2.set_partition(2, 2, 16)
+        with pytest.raises(device.GlrtxError):
+            d2.set_partition(0, 2, 10)  # not a multiple of the tile height
+    finally:
+        d2.close()
+
+
+def test_empty_and_edge_scenes(gpu_device):
+    d = gpu_device
+    empty = dict(vert=np.zeros((0, 3), np.float32), tri=np.zeros((0, 4), np.float32), mat=np.zeros((6, 3), np.float32),
+                 light=np.zeros((0, 4), np.float32), bvh=np.zeros((0, 3), np.float32))
+    _, params = scenes.config_c1(33, 17, subdiv=1)
+    acc, st = gpu_render(d, empty, params)
+    assert acc.shape == (17, 33, 4) and np.all(acc[..., :3] == 0) and np.all(acc[..., 3] == 1)
+    assert st.rays == 33 * 17
+    scene, params = scenes.config_c1(17, 9, max_depth=0, subdiv=1)  # max_depth 0: no rays, count still advances
+    acc, st = gpu_render(d, scene, params)
+    assert st.rays == 0 and np.all(acc[..., 3] == 1) and np.all(acc[..., :3] == 0)

@@ -1,0 +1,161 @@
+"""Host logic: BVH builders, camera matrices, scene validation/repacking, row partition."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from glrt_amd import device, dist, host, scenes
+
+
+def _nodes(scene):
+    return np.asarray(scene["bvh"], np.float32).reshape(-1, 9)
+
+
+def _tri_boxes(scene):
+    v = scene["vert"].reshape(-1, 5, 3)[:, 0]
+    idx = scene["tri"][:, :3].astype(np.int64)
+    p = v[idx]
+    return p.min(1), p.max(1)
+
+
+@pytest.mark.parametrize("kind", ["sah", "chain"])
+def test_bvh_is_a_valid_tree_over_all_triangles(kind):
+    sc, _ = scenes.config_c3(32, 32, n=700, bvh=kind)
+    nodes = _nodes(sc)
+    n_tri = sc["tri"].shape[0]
+    assert nodes.shape[0] == 2 * n_tri - 1
+    lo, hi = _tri_boxes(sc)
+    seen_tri = np.zeros(n_tri, bool)
+    seen_node = np.zeros(nodes.shape[0], bool)
+    stack = [(0, None)]
+    while stack:
+        n, parent_box = stack.pop()
+        assert not seen_node[n]
+        seen_node[n] = True
+        bmin, bmax, ch = nodes[n, 0:3], nodes[n, 3:6], nodes[n, 6:9]
+        if parent_box is not None and kind == "sah":
+            assert np.all(bmin >= parent_box[0]) and np.all(bmax <= parent_box[1])
+        if ch[2] < 0:
+            for c in ch[:2]:
+                assert c >= 0
+                stack.append((int(c), (bmin, bmax)))
+        else:
+            t = int(ch[2])
+            assert ch[0] == -1 and ch[1] == -1 and not seen_tri[t]
+            seen_tri[t] = True
+            assert np.all(bmin <= lo[t]) and np.all(bmax >= hi[t])
+    assert seen_tri.all() and seen_node.all()
+
+
+def test_chain_bvh_visits_triangles_in_order_with_reference_traversal():
+    sc, _ = scenes.config_c3(16, 16, n=50, bvh="chain")
+    nodes = _nodes(sc)
+    order, stack, depth = [], [0], 0
+    while stack:  # push children.x then .y, pop .y first (raytrace.frag:299-307)
+        n = stack.pop()
+        ch = nodes[n, 6:9]
+        if ch[2] < 0:
+            stack.extend(int(c) for c in ch[:2] if c >= 0)
+            depth = max(depth, len(stack))
+        else:
+            order.append(int(ch[2]))
+    assert order == list(range(50)) and depth == 2
+
+
+def test_sah_depth_bounded():
+    sc, _ = scenes.config_c2(32, 32, subdiv=2)
+    assert sc["bvh_depth"] < 40
+
+
+def test_camera_matrices_match_numpy():
+    eye, tgt, up = np.array([0, 3, 9.0]), np.array([0, 1, 0.0]), np.array([0, 1, 0.0])
+    v = host.look_at(eye, tgt, up).reshape(4, 4).T  # to row-major
+    f = (tgt - eye) / np.linalg.norm(tgt - eye)
+    s = np.cross(f, up); s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    ref = np.eye(4)
+    ref[0, :3], ref[1, :3], ref[2, :3] = s, u, -f
+    ref[:3, 3] = [-s @ eye, -u @ eye, f @ eye]
+    assert np.allclose(v, ref, atol=1e-6)
+    p = host.perspective(40.0, 16 / 9, 0.1, 100.0).reshape(4, 4).T
+    t = np.tan(np.radians(40.0) / 2)
+    assert np.isclose(p[0, 0], 1 / (16 / 9 * t), rtol=1e-6) and np.isclose(p[1, 1], 1 / t, rtol=1e-6)
+    assert np.isclose(p[3, 2], -1.0) and np.isclose(p[2, 3], -2 * 100 * 0.1 / (100 - 0.1), rtol=1e-6)
+    inv = host.mat4_inverse(host.look_at(eye, tgt, up)).reshape(4, 4).T
+    assert np.allclose(inv @ v, np.eye(4), atol=1e-5)
+    assert np.allclose(host.mat4_mul(host.look_at(eye, tgt, up), host.mat4_inverse(host.look_at(eye, tgt, up))).reshape(4, 4),
+                       np.eye(4), atol=1e-5)
+
+
+def test_frame_seeds_in_unit_interval():
+    s = [host.frame_seed(f) for f in range(100)]
+    assert all(0 <= a < 1 and 0 <= b < 1 for a, b in s) and len(set(s)) == 100
+    assert s[0] == (float(np.float32(0.137)), float(np.float32(0.731)))
+
+
+# ---- scene validation / repacking (glrtx_check_scene: host-only entry of the device library)
+def _check(sc):
+    L = device.lib()
+    fp = C.POINTER(C.c_float)
+    L.glrtx_check_scene.argtypes = [fp, C.c_size_t] * 5 + [C.POINTER(C.c_int)] * 2
+    arrs = [np.ascontiguousarray(sc[k], np.float32) for k in ("vert", "tri", "mat", "light", "bvh")]
+    per = (15, 4, 18, 4, 9)
+    args = []
+    for a, n in zip(arrs, per):
+        args += [a.ctypes.data_as(fp), a.size // n]
+    nf, se = C.c_int(), C.c_int()
+    rc = L.glrtx_check_scene(*args, C.byref(nf), C.byref(se))
+    return rc, nf.value, se.value, L.glrtx_last_error(None).decode()
+
+
+def test_check_scene_accepts_generated_scenes():
+    for name in ("c1", "c2"):
+        sc, _ = scenes.CONFIGS[name](32, 32)
+        rc, n_fork, need, _ = _check(sc)
+        assert rc == 0 and n_fork == sc["tri"].shape[0] - 1 and 0 < need <= sc["bvh_depth"]
+    sc, _ = scenes.config_c3(32, 32, n=300, bvh="chain")
+    assert _check(sc)[:3] == (0, 299, 1)
+
+
+def test_check_scene_rejects_malformed_scenes():
+    sc, _ = scenes.config_c1(32, 32, subdiv=1)
+    bad = dict(sc, tri=sc["tri"].copy()); bad["tri"][5, 1] = 1e9
+    assert _check(bad)[0] == device.GLRTX_ESCENE
+    bad = dict(sc, tri=sc["tri"].copy()); bad["tri"][7, 3] = 99
+    assert _check(bad)[0] == device.GLRTX_ESCENE
+    bad = dict(sc, bvh=sc["bvh"].copy()); bad["bvh"].reshape(-1, 9)[0, 6] = 0  # root's left child = root: a cycle
+    rc, _, _, msg = _check(bad)
+    assert rc == device.GLRTX_ESCENE and "more than once" in msg
+    bad = dict(sc, bvh=sc["bvh"].copy()); bad["bvh"].reshape(-1, 9)[0, 7] = 1e7
+    assert _check(bad)[0] == device.GLRTX_ESCENE
+
+
+def test_check_scene_rejects_too_deep_tree():
+    # a right-leaning comb: every fork = (leaf, next fork) keeps one entry per level on the stack
+    n = 80
+    sc, _ = scenes.config_c3(16, 16, n=n, bvh="chain")
+    nodes = sc["bvh"].reshape(-1, 9).copy()
+    forks = nodes[nodes[:, 8] < 0]
+    for f in range(nodes.shape[0]):
+        if nodes[f, 8] < 0:
+            nodes[f, 6], nodes[f, 7] = nodes[f, 7], nodes[f, 6]  # leaf becomes children.x (stacked), chain continues in .y
+    rc, _, _, msg = _check(dict(sc, bvh=nodes))
+    assert rc == device.GLRTX_EDEPTH and "stack" in msg
+    assert len(forks) == n - 1
+
+
+def test_empty_scene_is_valid():
+    sc = dict(vert=np.zeros((0, 3), np.float32), tri=np.zeros((0, 4), np.float32), mat=np.zeros((6, 3), np.float32),
+              light=np.zeros((0, 4), np.float32), bvh=np.zeros((0, 3), np.float32))
+    assert _check(sc)[0] == 0
+
+
+# ---- partition
+@pytest.mark.parametrize("world,stripe,height", [(1, 16, 1080), (2, 16, 1080), (8, 16, 1080), (8, 16, 2160), (3, 32, 100), (8, 16, 40)])
+def test_row_partition_is_a_bijection(world, stripe, height):
+    allrows = np.concatenate([dist.owned_rows(r, world, stripe, height) for r in range(world)])
+    assert sorted(allrows.tolist()) == list(range(height))
+    for r in range(world):
+        ys = dist.owned_rows(r, world, stripe, height)
+        for i, y in enumerate(ys):  # same formula as the kernel / glrtx_local_row_to_y
+            assert y == ((i // stripe) * world + r) * stripe + i % stripe

@@ -1,0 +1,46 @@
+"""Oracle vs the reference's own shader run live on llvmpipe (only where /root/reference and Mesa's
+swrast_dri.so exist, i.e. the build container; skipped on the GPU box)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from glrt_amd import scenes
+from oracle import glref, pt_oracle
+
+pytestmark = pytest.mark.skipif(not glref.reference_available(), reason="reference checkout / Mesa llvmpipe not present")
+
+
+@pytest.fixture(scope="module")
+def gl():
+    return glref.GLRef()
+
+
+CASES = [
+    ("c1", dict(width=96, height=64, max_depth=6, n_samples=2), {}),
+    ("c1", dict(width=64, height=64, max_depth=3, n_samples=1), dict(aperture=0.2, focal=9.0, seed=(0.91, 0.33))),
+    ("c2", dict(width=96, height=54, max_depth=8, n_samples=1, subdiv=1), dict(seed=(0.5, 0.25))),
+    ("c3", dict(width=64, height=36, max_depth=2, n=800), {}),
+    ("c4", dict(width=64, height=36, max_depth=8, n_samples=4, subdiv=1), {}),
+    ("c5", dict(width=64, height=36, max_depth=4, n=5000), dict(seed=(0.123, 0.987))),
+]
+
+
+@pytest.mark.parametrize("cfg,kw,over", CASES)
+def test_oracle_bit_exact_vs_live_reference(gl, cfg, kw, over):
+    sc, pr = scenes.CONFIGS[cfg](**kw)
+    pr = dict(pr, **over)
+    rgb, cnt = gl.render_reference(sc, pr)
+    acc, rays = pt_oracle.render(sc, pr)
+    assert rays >= pr["width"] * pr["height"] * pr["n_samples"]
+    assert_bit_equal(acc[..., :3], rgb, "rgb")
+    assert_bit_equal(acc[..., 3], cnt, "count")
+
+
+def test_random_seeds_sweep(gl):
+    sc, pr = scenes.config_c1(48, 48, max_depth=5, n_samples=1, subdiv=1)
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        p = dict(pr, seed=tuple(float(np.float32(v)) for v in rng.uniform(0, 1, 2)))
+        rgb, cnt = gl.render_reference(sc, p)
+        acc, _ = pt_oracle.render(sc, p)
+        assert_bit_equal(acc[..., :3], rgb, f"seed {p['seed']}")
