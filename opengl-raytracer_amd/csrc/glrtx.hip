@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,7 +39,10 @@ struct glrtx_ctx {
     hipEvent_t tm0 = nullptr, tm1 = nullptr;      // glrtx_timer_*
     std::string err;
 
-    DevBuf forks, tris, nrms, mats, lights, accum_own, counter, rgba8;
+    DevBuf forks, tris, nrms, mats, lights, accum_own, counter, rgba8, work;
+    int variant = 1;          // 0 = tile kernel, 1 = persistent kernel with path regeneration
+    int n_cu = 256;
+    int resident_wg[2] = {0, 0};  // persistent grid size per COUNT_RAYS instantiation (0 = not yet queried)
     DevScene sc{};
     bool have_scene = false;
     int n_tri = 0, n_fork = 0, n_mat = 0, n_light = 0;
@@ -110,7 +114,7 @@ int fold_launch_time(glrtx_ctx *c) {
 }
 
 int lds_bytes_for(const DevScene &sc) {
-    return (sc.mats_in_lds ? 3 * sc.n_mat * (int)sizeof(float4) : 0) + sc.stack_entries * kBlockThreads * (int)sizeof(int);
+    return (sc.mats_in_lds ? 3 * sc.n_mat * (int)sizeof(float4) : 0) + 2 * sc.stack_entries * kBlockThreads * (int)sizeof(int);
 }
 
 int pfail(glrtx_ctx *c, std::string *err_out, int code, const char *fmt, ...) {
@@ -129,6 +133,7 @@ int pfail(glrtx_ctx *c, std::string *err_out, int code, const char *fmt, ...) {
 // exercised without a GPU through glrtx_check_scene.
 struct Packed {
     std::vector<float4> forks, tris, nrms, mats, lights;
+    float4 root_lo = make_float4(0.f, 0.f, 0.f, 0.f), root_hi = make_float4(0.f, 0.f, 0.f, 0.f);
     int root_ref = REF_ABSENT;
     int stack_need = 0;
 };
@@ -225,9 +230,8 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
                     st.pop_back();
                     continue;
                 }
-                ref_of[n] = (int)(forks.size() / 2);
-                forks.push_back(make_float4(bvh[9 * (size_t)n + 0], bvh[9 * (size_t)n + 1], bvh[9 * (size_t)n + 2], as_float(REF_ABSENT)));
-                forks.push_back(make_float4(bvh[9 * (size_t)n + 3], bvh[9 * (size_t)n + 4], bvh[9 * (size_t)n + 5], as_float(REF_ABSENT)));
+                ref_of[n] = (int)(forks.size() / 4);
+                for (int k = 0; k < 4; k++) forks.push_back(make_float4(0.f, 0.f, 0.f, as_float(REF_ABSENT)));
                 f.stage = 1;
                 int l;
                 if (!child(n, 0, l)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
@@ -245,8 +249,13 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
             child(n, 0, l);
             child(n, 1, r);
             const int fi = ref_of[n];
-            if (l >= 0) forks[2 * fi].w = as_float(ref_of[l]);
-            if (r >= 0) forks[2 * fi + 1].w = as_float(ref_of[r]);
+            auto put_box = [&](int slot, int child) {  // child box into the parent's record
+                const float *b = bvh + 9 * (size_t)child;
+                forks[4 * fi + slot].x = b[0]; forks[4 * fi + slot].y = b[1]; forks[4 * fi + slot].z = b[2];
+                forks[4 * fi + slot + 1].x = b[3]; forks[4 * fi + slot + 1].y = b[4]; forks[4 * fi + slot + 1].z = b[5];
+            };
+            if (l >= 0) { put_box(0, l); forks[4 * fi].w = as_float(ref_of[l]); }
+            if (r >= 0) { put_box(2, r); forks[4 * fi + 1].w = as_float(ref_of[r]); }
             // traversal continues with the right child while the left one waits on the stack
             if (l >= 0 && r >= 0) need[n] = std::max(1 + need[r], need[l]);
             else if (r >= 0) need[n] = need[r];
@@ -258,8 +267,13 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         stack_need = need[0];
     }
     if (root_ref == REF_ABSENT) {  // empty scene: one childless fork, every ray misses
-        forks.assign(2, make_float4(0.f, 0.f, 0.f, as_float(REF_ABSENT)));
+        forks.assign(4, make_float4(0.f, 0.f, 0.f, as_float(REF_ABSENT)));
         root_ref = 0;
+        P.root_lo = make_float4(0.f, 0.f, 0.f, 0.f);
+        P.root_hi = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (root_ref >= 0) {
+        P.root_lo = make_float4(bvh[0], bvh[1], bvh[2], 0.f);
+        P.root_hi = make_float4(bvh[3], bvh[4], bvh[5], 0.f);
     }
     if (stack_need > 63)
         return pfail(c, err_out, GLRTX_EDEPTH, "BVH needs %d traversal stack entries; the reference shader's stack holds 64", stack_need + 1);
@@ -300,12 +314,15 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipEventCreate(&c->tm0)) != hipSuccess || (e = hipEventCreate(&c->tm1)) != hipSuccess ||
         (e = hipMalloc(&c->counter.p, sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMemset(c->counter.p, 0, sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMemset(c->counter.p, 0, sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc(&c->work.p, 64)) != hipSuccess) {
         fail(nullptr, GLRTX_EDEVICE, "context setup failed: %s", hipGetErrorString(e));
         glrtx_destroy(c);
         return GLRTX_EDEVICE;
     }
     c->stream = c->own_stream;
+    c->n_cu = prop.multiProcessorCount;
+    if (const char *v = std::getenv("GLRTX_VARIANT")) c->variant = std::atoi(v) != 0;
     *out = c;
     return GLRTX_OK;
 }
@@ -315,7 +332,7 @@ void glrtx_destroy(glrtx_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     dev_free(c->forks); dev_free(c->tris); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights);
-    dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8);
+    dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->tm0) (void)hipEventDestroy(c->tm0);
@@ -348,11 +365,12 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     sc.mats = (const float4 *)c->mats.p;
     sc.lights = (const float4 *)c->lights.p;
     sc.root_ref = root_ref;
+    sc.root_lo = P.root_lo; sc.root_hi = P.root_hi;
     sc.n_light = (int)n_light;
     sc.n_mat = (int)n_mat;
     sc.stack_entries = stack_need;
     sc.mats_in_lds = (n_mat > 0 && n_mat <= (size_t)kMaxLdsMaterials) ? 1 : 0;
-    c->n_tri = (int)n_tri; c->n_fork = (int)(forks.size() / 2); c->n_mat = (int)n_mat; c->n_light = (int)n_light;
+    c->n_tri = (int)n_tri; c->n_fork = (int)(forks.size() / 4); c->n_mat = (int)n_mat; c->n_light = (int)n_light;
     c->have_scene = true;
     c->st.stack_entries = stack_need;
     c->st.lds_bytes = lds_bytes_for(sc);
@@ -367,7 +385,7 @@ int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t
                       int *stack_entries_out) {
     Packed P;
     if (int rc = pack_scene(nullptr, &g_create_error, P, vert, n_vert, tri, n_tri, mat, n_mat, light, n_light, bvh, n_nodes)) return rc;
-    if (n_fork_out) *n_fork_out = (int)(P.forks.size() / 2);
+    if (n_fork_out) *n_fork_out = (int)(P.forks.size() / 4);
     if (stack_entries_out) *stack_entries_out = P.stack_need;
     return GLRTX_OK;
 }
@@ -443,6 +461,13 @@ int glrtx_set_stream(glrtx_ctx *c, void *hip_stream) {
     return GLRTX_OK;
 }
 
+int glrtx_set_variant(glrtx_ctx *c, int variant) {
+    if (!c) return GLRTX_EINVAL;
+    if (variant != 0 && variant != 1) return fail(c, GLRTX_EINVAL, "glrtx_set_variant: unknown variant %d", variant);
+    c->variant = variant;
+    return GLRTX_OK;
+}
+
 int glrtx_count_rays(glrtx_ctx *c, int enable) {
     if (!c) return GLRTX_EINVAL;
     c->count_rays = enable != 0;
@@ -481,6 +506,31 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "render kernel needs %d B of LDS (> 160 KiB)", lds);
     if (a.pitch_f4 < c->width) return fail(c, GLRTX_EINVAL, "accumulator pitch smaller than a row");
 
+    if ((size_t)a.pitch_f4 * (size_t)c->owned_rows >= (size_t)INT32_MAX)
+        return fail(c, GLRTX_EINVAL, "accumulator too large for 32-bit pixel offsets");
+
+    if (c->variant == 1) {
+        // persistent kernel: grid = what is resident at once (occupancy x CUs), capped by the work available
+        const int ci = c->count_rays ? 1 : 0;
+        if (lds > 64 * 1024) {
+            HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_persistent<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_persistent<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        }
+        int per_cu = 0;
+        if (ci) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_persistent<true>, kBlockThreads, lds));
+        else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_persistent<false>, kBlockThreads, lds));
+        if (per_cu < 1) per_cu = 1;
+        const int tiles8 = ((c->width + 7) / 8) * ((c->owned_rows + 7) / 8);
+        const int n_chunks = (tiles8 * 64 + kChunk - 1) / kChunk;
+        const int waves_per_wg = kBlockThreads / 64;
+        int grid = std::min(per_cu * c->n_cu, (n_chunks + waves_per_wg - 1) / waves_per_wg);
+        if (grid < 1) grid = 1;
+        c->resident_wg[ci] = grid;
+        HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        if (ci) hipLaunchKernelGGL(pt_render_persistent<true>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, (unsigned *)c->work.p);
+        else hipLaunchKernelGGL(pt_render_persistent<false>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, (unsigned *)c->work.p);
+    } else {
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     if (c->count_rays) {
         if (lds > 64 * 1024)
@@ -490,6 +540,7 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
         if (lds > 64 * 1024)
             HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(pt_render_kernel<false>, dim3(a.n_tiles), dim3(kBlockThreads), lds, c->stream, a);
+    }
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

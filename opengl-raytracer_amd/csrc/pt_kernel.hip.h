@@ -16,10 +16,11 @@
 // v_rcp/v_rsq/v_sin approximations.
 //
 // Device data layout (built by glrtx_upload_scene from the reference wire format):
-//   forks  : 2 x float4 per interior BVH node  {min.xyz, refL} {max.xyz, refR}
+//   forks  : 4 x float4 (64 B) per interior BVH node, holding its CHILDREN's boxes:
+//            {minL.xyz, refL} {maxL.xyz, refR} {minR.xyz, -} {maxR.xyz, -}
 //            ref >= 0 -> fork index, ref < 0 -> ~triangle (leaf nodes are folded into their
 //            parent's ref: the reference never tests a leaf's own box, raytrace.frag:310-331),
-//            ref == REF_ABSENT -> no child
+//            ref == REF_ABSENT -> no child.  The root's own box is in DevScene.
 //   tris   : 3 x float4 per triangle {v0.xyz, materialId} {v1-v0, -} {v2-v0, -}
 //   nrms   : 3 x float4 per triangle {n0} {n1} {n2}   (read once per ray, for the closest hit only)
 //   mats   : 3 x float4 per material {emission.xyz, type} {param0.xyz, alpha.x} {param1.xyz, alpha.y}
@@ -46,6 +47,7 @@ struct DevScene {
     const float4 *nrms;
     const float4 *mats;
     const float4 *lights;
+    float4 root_lo, root_hi;  // the root fork's own box
     int root_ref;
     int n_light;
     int n_mat;
@@ -151,6 +153,25 @@ struct Hit {
 // Iterative DFS in the reference's order (push children.x, push children.y, pop y first,
 // :299-307): "continue with y, stack x".  The per-lane stack lives in LDS, entry e of lane l at
 // stack[e * kBlockThreads + l] (bank = l mod 32: conflict-free ds_read/write_b32).
+// Box test of one child, intersectBBox :259-274 + the cull of :298.  v_min/v_max return the non-NaN
+// operand, which is the NaN rule needed here; the sign of a zero cannot change the comparison.
+DEV bool box_pass(float4 lo, float4 hi, float ox, float oy, float oz, float ix, float iy, float iz, float tHit, float &t0) {
+    const float fx = (hi.x - ox) * ix, fy = (hi.y - oy) * iy, fz = (hi.z - oz) * iz;
+    const float nx = (lo.x - ox) * ix, ny = (lo.y - oy) * iy, nz = (lo.z - oz) * iz;
+    const float t1 = __builtin_fminf(__builtin_fmaxf(fx, nx), __builtin_fminf(__builtin_fmaxf(fy, ny), __builtin_fmaxf(fz, nz)));
+    t0 = __builtin_fmaxf(__builtin_fminf(fx, nx), __builtin_fmaxf(__builtin_fminf(fy, ny), __builtin_fminf(fz, nz)));
+    return __builtin_fminf(t1, tHit) >= t0;  // (t1 >= t0 && t0 <= tHit) is evaluated as min(t1, tHit) >= t0
+}
+
+// Iterative DFS in the reference's order (push children.x, push children.y, pop y first, :299-307):
+// "continue with y, stack x".  A fork node carries the boxes of its two children, so one 64-byte
+// fetch decides both (the reference fetches a child, then tests the child's own box: the same two
+// tests, one dependent memory round trip earlier).  Testing the stacked child early uses a tHit that
+// may still shrink; the entry keeps its entry distance t0 and is re-checked against the current tHit
+// when popped, which reproduces the reference's visit set exactly (its test at pop time is
+// t1 >= t0 -- independent of tHit -- and t0 <= tHit).  Leaf children are never box-tested, as in the
+// reference (:310-331).  The per-lane stack lives in LDS: entry e of lane l at
+// stack[(2e + {0,1}) * kBlockThreads + l] (bank = l mod 32: conflict-free ds_read/write_b32).
 template <bool CLOSEST>
 DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, float dx, float dy, float dz) {
     Hit h;
@@ -158,34 +179,30 @@ DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, f
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // :260 (loop-invariant there)
     int sp = 0;
     int cur = sc.root_ref;
+    if (cur >= 0) {  // the root fork's own box
+        float t0;
+        if (!box_pass(sc.root_lo, sc.root_hi, ox, oy, oz, ix, iy, iz, h.t, t0)) return h;
+    }
     for (;;) {
         if (cur >= 0) {
-            const float4 A = sc.forks[2 * cur];
-            const float4 B = sc.forks[2 * cur + 1];
-            // intersectBBox :259-274
-            const float fx = (B.x - ox) * ix, fy = (B.y - oy) * iy, fz = (B.z - oz) * iz;
-            const float nx = (A.x - ox) * ix, ny = (A.y - oy) * iy, nz = (A.z - oz) * iz;
-            // v_min/v_max return the non-NaN operand, which is the semantics needed here;
-            // the sign of a zero result cannot change the comparison below.
-            const float t1 = __builtin_fminf(__builtin_fmaxf(fx, nx),
-                                             __builtin_fminf(__builtin_fmaxf(fy, ny), __builtin_fmaxf(fz, nz)));
-            const float t0 = __builtin_fmaxf(__builtin_fminf(fx, nx),
-                                             __builtin_fmaxf(__builtin_fminf(fy, ny), __builtin_fminf(fz, nz)));
-            // (t1 >= t0 && t0 <= tHit) is evaluated as min(t1, tHit) >= t0
-            if (__builtin_fminf(t1, h.t) >= t0) {
-                const int l = __float_as_int(A.w), r = __float_as_int(B.w);
-                if (r != REF_ABSENT) {
-                    if (l != REF_ABSENT) {
-                        stack[sp * kBlockThreads] = l;
-                        sp++;
-                    }
-                    cur = r;
-                    continue;
+            const float4 *N = sc.forks + 4 * (size_t)cur;
+            const float4 L0 = N[0], L1 = N[1], R0 = N[2], R1 = N[3];
+            const int l = __float_as_int(L0.w), r = __float_as_int(L1.w);
+            float t0l = -PT_INFTY, t0r;
+            const bool pl = l != REF_ABSENT && (l < 0 || box_pass(L0, L1, ox, oy, oz, ix, iy, iz, h.t, t0l));
+            const bool pr = r != REF_ABSENT && (r < 0 || box_pass(R0, R1, ox, oy, oz, ix, iy, iz, h.t, t0r));
+            if (pr) {
+                if (pl) {
+                    stack[(2 * sp) * kBlockThreads] = l;
+                    stack[(2 * sp + 1) * kBlockThreads] = __float_as_int(t0l);
+                    sp++;
                 }
-                if (l != REF_ABSENT) {
-                    cur = l;
-                    continue;
-                }
+                cur = r;
+                continue;
+            }
+            if (pl) {
+                cur = l;
+                continue;
             }
         } else {
             // leaf :310-331 with intersect(Ray, Triangle) :226-257
@@ -219,11 +236,15 @@ DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, f
                 }
             }
         }
-        if (sp == 0) break;
-        sp--;
-        cur = stack[sp * kBlockThreads];
+        // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298
+        for (;;) {
+            if (sp == 0) return h;
+            sp--;
+            cur = stack[(2 * sp) * kBlockThreads];
+            const float t0 = __int_as_float(stack[(2 * sp + 1) * kBlockThreads]);
+            if (h.t >= t0) break;
+        }
     }
-    return h;
 }
 
 // fresnelConductor :158-178, one channel
@@ -261,14 +282,35 @@ DEV Mat load_mat(const DevScene &sc, const float4 *lds_mats, int m) {
 }
 
 // ------------------------------------------------------------------------------------------ radiance :409-559
-DEV void radiance(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rng, float ox, float oy, float oz,
-                  float dx, float dy, float dz, float &Lr, float &Lg, float &Lb, unsigned &rays) {
-    const DevScene &sc = a.sc;
-    float Lx = 0.f, Ly = 0.f, Lz = 0.f;
-    float bx = 1.f, by = 1.f, bz = 1.f;
-    const float nLf = (float)sc.n_light;
+// Path state between bounces.  The reference's depth loop (:416-556) is split so that one call to
+// bounce() executes one iteration of it; that lets the persistent kernel keep lanes at different
+// depths (and of different pixels) side by side in one wavefront.
+struct Path {
+    float ox, oy, oz, dx, dy, dz;  // current ray
+    float bx, by, bz;              // beta (path throughput)
+    float Lx, Ly, Lz;              // radiance gathered so far
+    int depth;
+};
 
-    for (int depth = 0; depth < a.max_depth; depth++) {
+DEV void path_begin(Path &P, float ox, float oy, float oz, float dx, float dy, float dz) {
+    P.ox = ox; P.oy = oy; P.oz = oz; P.dx = dx; P.dy = dy; P.dz = dz;
+    P.bx = P.by = P.bz = 1.f;
+    P.Lx = P.Ly = P.Lz = 0.f;
+    P.depth = 0;
+}
+
+// One iteration of the depth loop.  Returns true when the loop ends (a `break`, or depth reaching
+// u_maxDepth).  Precondition: P.depth < a.max_depth.
+DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rng, Path &P, unsigned &rays) {
+    const DevScene &sc = a.sc;
+    float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+    float bx = P.bx, by = P.by, bz = P.bz;
+    float Lx = P.Lx, Ly = P.Ly, Lz = P.Lz;
+    const int depth = P.depth;
+    const float nLf = (float)sc.n_light;
+    bool done = true;  // every `break` of the reference loop leaves this set
+
+    do {
         const Hit h = traverse<true>(sc, stack, ox, oy, oz, dx, dy, dz);
         rays++;
         if (h.tri < 0) break;  // miss: nothing is added and the loop ends (:497-499)
@@ -487,8 +529,55 @@ DEV void radiance(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &
             if (pq < rr) break;
             bx = bx / pq; by = by / pq; bz = bz / pq;
         }
+        done = false;
+    } while (false);
+
+    P.ox = ox; P.oy = oy; P.oz = oz; P.dx = dx; P.dy = dy; P.dz = dz;
+    P.bx = bx; P.by = by; P.bz = bz;
+    P.Lx = Lx; P.Ly = Ly; P.Lz = Lz;
+    P.depth = depth + 1;
+    return done || P.depth >= a.max_depth;
+}
+
+// primary ray of one sample, main() :577-607
+DEV void camera_ray(const KernelArgs &a, Rng &rng, float fcx, float fcy, Path &P) {
+    const float W = (float)a.width, H = (float)a.height;
+    const float *S = a.s2c, *C = a.c2w;
+    const float r0 = pt_rand(rng);
+    const float r1 = pt_rand(rng);
+    const float nx = ((fcx + r0) / W) * 2.0f + -1.0f;
+    const float ny = ((fcy + r1) / H) * 2.0f + -1.0f;
+    // u_s2cMat * (nx, ny, 0, 1), summed as (col0*nx + col3) + col1*ny
+    const float tx = (S[0] * nx + S[12]) + S[4] * ny;
+    const float ty = (S[1] * nx + S[13]) + S[5] * ny;
+    const float tz = (S[2] * nx + S[14]) + S[6] * ny;
+    const float tw = (S[3] * nx + S[15]) + S[7] * ny;
+    const float cx = tx / tw, cy = ty / tw, cz = tz / tw;
+    const float rn = rsq((cz * cz + cy * cy) + cx * cx);
+    float dx = cx * rn, dy = cy * rn, dz = cz * rn;
+    float lox = 0.0f, loy = 0.0f;
+    if (0.0f < a.aperture) {  // thin lens :589-598
+        const float ra = pt_rand(rng);
+        const float rb = pt_rand(rng);
+        const float r = __builtin_sqrtf(ra) * a.aperture;
+        const float th = PT_2PI * rb;
+        lox = r * pt_cos(th);
+        loy = r * pt_sin(th);
+        const float ft = (-a.focal) / dz;
+        const float fx = dx * ft - lox, fy = dy * ft - loy, fz = dz * ft;
+        const float rf = rsq((fz * fz + fy * fy) + fx * fx);
+        dx = fx * rf; dy = fy * rf; dz = fz * rf;
     }
-    Lr = fmin_c(Lx, 100.0f); Lg = fmin_c(Ly, 100.0f); Lb = fmin_c(Lz, 100.0f);  // :558
+    // u_c2wMat * (o, 1), divided by w; u_c2wMat * (d, 0), normalised (:601-607)
+    const float wx = (C[0] * lox + C[12]) + C[4] * loy;
+    const float wy = (C[1] * lox + C[13]) + C[5] * loy;
+    const float wz = (C[2] * lox + C[14]) + C[6] * loy;
+    const float ww = (C[3] * lox + C[15]) + C[7] * loy;
+    const float ex = (C[0] * dx + C[4] * dy) + C[8] * dz;
+    const float ey = (C[1] * dx + C[5] * dy) + C[9] * dz;
+    const float ez = (C[2] * dx + C[6] * dy) + C[10] * dz;
+    const float re = rsq((ez * ez + ey * ey) + ex * ex);
+    path_begin(P, wx / ww, wy / ww, wz / ww, ex * re, ey * re, ez * re);
 }
 
 // Blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of screen tiles so
@@ -502,17 +591,38 @@ DEV int xcd_swizzle(int bid, int n) {
 }
 
 // ------------------------------------------------------------------------------------------ main :565-614
-template <bool COUNT_RAYS>
-__global__ __launch_bounds__(kBlockThreads) void pt_render_kernel(const KernelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float4 *lds_mats = reinterpret_cast<float4 *>(lds_raw);
-    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
-    int *stack = reinterpret_cast<int *>(lds_raw + (size_t)mat_f4 * sizeof(float4)) + threadIdx.x;
+DEV int local_row_to_y(const KernelArgs &a, int lrow) {  // owned stripe s holds global stripe s*world + rank
+    return ((lrow / a.stripe) * a.world + a.rank) * a.stripe + lrow % a.stripe;
+}
 
+DEV void lds_setup(const KernelArgs &a, unsigned char *lds_raw, float4 *&lds_mats, int *&stack) {
+    lds_mats = reinterpret_cast<float4 *>(lds_raw);
+    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    stack = reinterpret_cast<int *>(lds_raw + (size_t)mat_f4 * sizeof(float4)) + threadIdx.x;
     if (a.sc.mats_in_lds) {
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
         __syncthreads();
     }
+}
+
+template <bool COUNT_RAYS>
+DEV void flush_rays(const KernelArgs &a, unsigned rays) {
+    if (COUNT_RAYS) {  // wave-level sum, one atomic per wavefront
+        unsigned long long r = rays;
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+        if ((threadIdx.x & 63) == 0 && r) atomicAdd(a.ray_counter, r);
+    }
+}
+
+// Variant A ("tile"): one work-item per pixel, a 16x16 tile per workgroup, the whole sample/depth loop
+// nest in one lane.  Simple, but lanes whose path ended early idle until the longest path of the wave
+// is done (measured SIMD lane utilisation ~12 % on the headline config, profiles/r01a).
+template <bool COUNT_RAYS>
+__global__ __launch_bounds__(kBlockThreads) void pt_render_kernel(const KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float4 *lds_mats;
+    int *stack;
+    lds_setup(a, lds_raw, lds_mats, stack);
 
     const int tile = xcd_swizzle(blockIdx.x, a.n_tiles);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -520,63 +630,124 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_kernel(const KernelAr
     const int lrow = (tile / a.tiles_x) * kTile + (wave >> 1) * 8 + (lane >> 3);
     unsigned rays = 0;
     if (lx < a.width && lrow < a.owned_rows) {
-        // owned stripe s holds global stripe s*world + rank
-        const int gy = ((lrow / a.stripe) * a.world + a.rank) * a.stripe + lrow % a.stripe;
-        const float W = (float)a.width, H = (float)a.height;
+        const int gy = local_row_to_y(a, lrow);
         const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
         Rng rng;
-        rng.x = fcx / W; rng.y = fcy / H; rng.sx = a.seed_x; rng.sy = a.seed_y;  // :567
+        rng.x = fcx / (float)a.width; rng.y = fcy / (float)a.height; rng.sx = a.seed_x; rng.sy = a.seed_y;  // :567
         float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
         float4 acc = *px;  // previous (L, count): read-modify-write replaces the ping-pong FBOs (:570-572)
-        const float *S = a.s2c, *C = a.c2w;
         for (int i = 0; i < a.n_samples; i++) {
-            const float r0 = pt_rand(rng);
-            const float r1 = pt_rand(rng);
-            const float nx = ((fcx + r0) / W) * 2.0f + -1.0f;
-            const float ny = ((fcy + r1) / H) * 2.0f + -1.0f;
-            // u_s2cMat * (nx, ny, 0, 1), summed as (col0*nx + col3) + col1*ny
-            const float tx = (S[0] * nx + S[12]) + S[4] * ny;
-            const float ty = (S[1] * nx + S[13]) + S[5] * ny;
-            const float tz = (S[2] * nx + S[14]) + S[6] * ny;
-            const float tw = (S[3] * nx + S[15]) + S[7] * ny;
-            const float cx = tx / tw, cy = ty / tw, cz = tz / tw;
-            const float rn = rsq((cz * cz + cy * cy) + cx * cx);
-            float dx = cx * rn, dy = cy * rn, dz = cz * rn;
-            float lox = 0.0f, loy = 0.0f;
-            if (0.0f < a.aperture) {  // thin lens :589-598
-                const float ra = pt_rand(rng);
-                const float rb = pt_rand(rng);
-                const float r = __builtin_sqrtf(ra) * a.aperture;
-                const float th = PT_2PI * rb;
-                lox = r * pt_cos(th);
-                loy = r * pt_sin(th);
-                const float ft = (-a.focal) / dz;
-                const float fx = dx * ft - lox, fy = dy * ft - loy, fz = dz * ft;
-                const float rf = rsq((fz * fz + fy * fy) + fx * fx);
-                dx = fx * rf; dy = fy * rf; dz = fz * rf;
-            }
-            // u_c2wMat * (o, 1), divided by w; u_c2wMat * (d, 0), normalised (:601-607)
-            const float wx = (C[0] * lox + C[12]) + C[4] * loy;
-            const float wy = (C[1] * lox + C[13]) + C[5] * loy;
-            const float wz = (C[2] * lox + C[14]) + C[6] * loy;
-            const float ww = (C[3] * lox + C[15]) + C[7] * loy;
-            const float ex = (C[0] * dx + C[4] * dy) + C[8] * dz;
-            const float ey = (C[1] * dx + C[5] * dy) + C[9] * dz;
-            const float ez = (C[2] * dx + C[6] * dy) + C[10] * dz;
-            const float re = rsq((ez * ez + ey * ey) + ex * ex);
-            float Lr, Lg, Lb;
-            radiance(a, lds_mats, stack, rng, wx / ww, wy / ww, wz / ww, ex * re, ey * re, ez * re, Lr, Lg, Lb, rays);
-            acc.x = acc.x + Lr; acc.y = acc.y + Lg; acc.z = acc.z + Lb;
+            Path P;
+            camera_ray(a, rng, fcx, fcy, P);
+            if (a.max_depth > 0)
+                while (!bounce(a, lds_mats, stack, rng, P, rays)) {}
+            acc.x = acc.x + fmin_c(P.Lx, 100.0f);  // :558, :608
+            acc.y = acc.y + fmin_c(P.Ly, 100.0f);
+            acc.z = acc.z + fmin_c(P.Lz, 100.0f);
             acc.w = acc.w + 1.0f;
         }
         *px = acc;  // 8 lanes x 16 B = one 128 B segment per tile row
     }
-    if (COUNT_RAYS) {
-        // wave-level sum, one atomic per wavefront
-        unsigned long long r = rays;
-        for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
-        if ((threadIdx.x & 63) == 0 && r) atomicAdd(a.ray_counter, r);
+    flush_rays<COUNT_RAYS>(a, rays);
+}
+
+// Variant B ("persistent"): wavefronts stay resident and pull pixels from a global work counter in
+// chunks of kChunk; a lane whose pixel is finished takes the next pixel of its wave's chunk at once
+// (path regeneration), so lanes at different depths -- and of different pixels -- run side by side
+// and a wave's SIMD lanes stay occupied until the image runs out.  Per-pixel arithmetic, RNG stream
+// and accumulation order are untouched, so results are bit-identical to variant A.
+// Work order: pixel id -> 8x8 tile (row-major over the tile grid) -> pixel within the tile.
+constexpr int kChunk = 256;
+
+template <bool COUNT_RAYS>
+__global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const KernelArgs a, unsigned *work_counter) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float4 *lds_mats;
+    int *stack;
+    lds_setup(a, lds_raw, lds_mats, stack);
+
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int tiles8_x = (a.width + 7) >> 3, tiles8_y = (a.owned_rows + 7) >> 3;
+    const int total = tiles8_x * tiles8_y * 64;
+
+    // wave-uniform work state
+    int chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+    // per-lane state
+    bool alive = false, fresh = false;
+    int px_off = 0, sample = 0;
+    float fcx = 0.f, fcy = 0.f;
+    Rng rng = {0.f, 0.f, a.seed_x, a.seed_y};
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    Path P;
+    path_begin(P, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
+    unsigned rays = 0;
+
+    for (;;) {
+        // ---- regeneration: idle lanes take the next pixels of the wave's chunk
+        unsigned long long idle = __ballot(!alive);
+        while (idle != 0ull && !exhausted) {
+            if (chunk_next >= chunk_end) {
+                int base = 0;
+                if (lane == 0) base = (int)atomicAdd(work_counter, (unsigned)kChunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= total) { exhausted = true; break; }
+                chunk_next = base;
+                chunk_end = base + kChunk < total ? base + kChunk : total;
+            }
+            const int n = __popcll(idle);
+            const int avail = chunk_end - chunk_next;
+            const int take = n < avail ? n : avail;
+            const int rank = __popcll(idle & lt_mask);
+            if (!alive && rank < take) {
+                const int id = chunk_next + rank;
+                const int t = id >> 6, w = id & 63;
+                const int lx = (t % tiles8_x) * 8 + (w & 7);
+                const int lrow = (t / tiles8_x) * 8 + (w >> 3);
+                if (lx < a.width && lrow < a.owned_rows && a.n_samples > 0) {
+                    const int gy = local_row_to_y(a, lrow);
+                    fcx = (float)lx + 0.5f; fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
+                    rng.x = fcx / (float)a.width; rng.y = fcy / (float)a.height;  // :567
+                    px_off = lrow * a.pitch_f4 + lx;
+                    acc = a.accum[px_off];  // previous (L, count) (:570-572)
+                    sample = 0;
+                    alive = true; fresh = true;
+                }
+            }
+            chunk_next += take;
+            // still-idle lanes (chunk ran short, or the pixel drawn lies outside the image) go round again;
+            // every round consumes at least one id, so the loop ends when the image is exhausted
+            idle = __ballot(!alive);
+        }
+        if (!__any(alive)) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- one step for every live lane: (new sample ->) one bounce
+        if (alive) {
+            if (fresh) {
+                camera_ray(a, rng, fcx, fcy, P);
+                fresh = false;
+            }
+            bool finished = true;
+            if (a.max_depth > 0) finished = bounce(a, lds_mats, stack, rng, P, rays);
+            if (finished) {
+                acc.x = acc.x + fmin_c(P.Lx, 100.0f);  // :558, :608
+                acc.y = acc.y + fmin_c(P.Ly, 100.0f);
+                acc.z = acc.z + fmin_c(P.Lz, 100.0f);
+                acc.w = acc.w + 1.0f;
+                sample++;
+                if (sample >= a.n_samples) {
+                    a.accum[px_off] = acc;
+                    alive = false;
+                } else {
+                    fresh = true;
+                }
+            }
+        }
     }
+    flush_rays<COUNT_RAYS>(a, rays);
 }
 
 // ------------------------------------------------------------------------------------------ resolve

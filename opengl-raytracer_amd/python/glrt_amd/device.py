@@ -31,7 +31,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_error", "glrtx_upload_scene",
            "glrtx_resize", "glrtx_clear", "glrtx_set_partition", "glrtx_local_row_to_y", "glrtx_bind_accum",
-           "glrtx_set_stream", "glrtx_count_rays", "glrtx_render", "glrtx_sync", "glrtx_read_accum",
+           "glrtx_set_stream", "glrtx_set_variant", "glrtx_count_rays", "glrtx_render", "glrtx_sync", "glrtx_read_accum",
            "glrtx_accum_device_ptr", "glrtx_resolve_rgba8", "glrtx_get_stats", "glrtx_reset_stats",
            "glrtx_timer_begin", "glrtx_timer_end"]
 
@@ -65,6 +65,7 @@ def lib():
         L.glrtx_local_row_to_y.argtypes = [vp, C.c_int]
         L.glrtx_bind_accum.argtypes = [vp, vp, C.c_size_t]
         L.glrtx_set_stream.argtypes = [vp, vp]
+        L.glrtx_set_variant.argtypes = [vp, C.c_int]
         L.glrtx_count_rays.argtypes = [vp, C.c_int]
         L.glrtx_render.argtypes = [vp, C.POINTER(Params)]
         L.glrtx_sync.argtypes = [vp]
@@ -149,6 +150,9 @@ class Device:
 
     def set_stream(self, hip_stream):
         self._ck(self.L.glrtx_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def set_variant(self, variant: int):
+        self._ck(self.L.glrtx_set_variant(self.h, int(variant)))
 
     def count_rays(self, enable=True):
         self._ck(self.L.glrtx_count_rays(self.h, int(enable)))
