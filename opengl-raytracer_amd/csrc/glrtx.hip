@@ -613,6 +613,16 @@ int glrtx_reset_stats(glrtx_ctx *c) {
     return GLRTX_OK;
 }
 
+#ifdef GLRTX_TRAV_STATS
+// diagnostic build only: read and clear the traversal statistics
+int glrtx_debug_trav_stats(unsigned long long out[8]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return GLRTX_EDEVICE;
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
+    return GLRTX_OK;
+}
+#endif
+
 int glrtx_timer_begin(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));

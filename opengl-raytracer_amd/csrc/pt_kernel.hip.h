@@ -172,6 +172,22 @@ DEV bool box_pass(float4 lo, float4 hi, float ox, float oy, float oz, float ix, 
 // t1 >= t0 -- independent of tHit -- and t0 <= tHit).  Leaf children are never box-tested, as in the
 // reference (:310-331).  The per-lane stack lives in LDS: entry e of lane l at
 // stack[(2e + {0,1}) * kBlockThreads + l] (bank = l mod 32: conflict-free ds_read/write_b32).
+#ifdef GLRTX_TRAV_STATS
+// Diagnostic build only (-DGLRTX_TRAV_STATS): [0] wave loop iterations, [1] active lanes summed over
+// iterations, [2] lanes on the fork path, [3] lanes on the leaf path, [4] iterations with both paths live
+__device__ unsigned long long g_trav_stats[8];
+DEV void trav_stats_iter(int cur) {
+    const unsigned long long m = __ballot(1), mf = __ballot(cur >= 0);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+        atomicAdd(&g_trav_stats[0], 1ull);
+        atomicAdd(&g_trav_stats[1], (unsigned long long)__popcll(m));
+        atomicAdd(&g_trav_stats[2], (unsigned long long)__popcll(mf));
+        atomicAdd(&g_trav_stats[3], (unsigned long long)__popcll(m & ~mf));
+        if (mf != 0 && (m & ~mf) != 0) atomicAdd(&g_trav_stats[4], 1ull);
+    }
+}
+#endif
+
 template <bool CLOSEST>
 DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, float dx, float dy, float dz) {
     Hit h;
@@ -179,11 +195,17 @@ DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, f
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // :260 (loop-invariant there)
     int sp = 0;
     int cur = sc.root_ref;
+#ifdef GLRTX_TRAV_STATS
+#define TS_ITER trav_stats_iter(cur)
+#else
+#define TS_ITER
+#endif
     if (cur >= 0) {  // the root fork's own box
         float t0;
         if (!box_pass(sc.root_lo, sc.root_hi, ox, oy, oz, ix, iy, iz, h.t, t0)) return h;
     }
     for (;;) {
+        TS_ITER;
         if (cur >= 0) {
             const float4 *N = sc.forks + 4 * (size_t)cur;
             const float4 L0 = N[0], L1 = N[1], R0 = N[2], R1 = N[3];

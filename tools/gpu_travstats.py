@@ -1,0 +1,14 @@
+import sys, ctypes as C; sys.path.insert(0,'.'); sys.path.insert(0,'opengl-raytracer_amd/python')
+import numpy as np
+from glrt_amd import scenes, device, host
+device.lib_path = lambda: device.LIB_DIR / "libglrtx_stats.so"
+cfg = sys.argv[1] if len(sys.argv) > 1 else "headline"
+sc, pr = scenes.CONFIGS[cfg]()
+d = device.Device(); d.upload_scene(sc); d.resize(pr["width"], pr["height"]); d.count_rays(True)
+L = device.lib()
+for v in (0, 1):
+    d.set_variant(v); d.reset_stats()
+    out = (C.c_ulonglong * 8)(); L.glrtx_debug_trav_stats(out)
+    d.render(dict(pr, seed=host.frame_seed(0))); d.sync()
+    L.glrtx_debug_trav_stats(out); o = list(out); rays = d.stats().rays
+    print(f"variant {v}: rays {rays} wave_iters {o[0]} lane_iters {o[1]} simd_eff {o[1]/(64*o[0]):.3f} fork_lane {o[2]} leaf_lane {o[3]} mixed_iters {o[4]/o[0]:.3f} iters/ray {o[1]/rays:.1f} forks/ray {o[2]/rays:.1f} leaves/ray {o[3]/rays:.1f}")
