@@ -40,7 +40,10 @@ struct glrtx_ctx {
     std::string err;
 
     DevBuf forks, tris, nrms, mats, lights, accum_own, counter, rgba8, work;
-    int variant = 1;          // 0 = tile kernel, 1 = persistent kernel with path regeneration
+    DevBuf wfA[6], wfH, wfHS, wfQT[2], wfQS[2], wfCnt;  // wavefront pipeline state (variant 2)
+    int wf_total = 0, wf_cnt_trips = 0;
+    uint64_t wf_rays = 0;        // rays counted by wavefront launches (host-side sum of queue lengths)
+    int variant = 2;          // 0 = tile kernel, 1 = persistent kernel with path regeneration, 2 = wavefront pipeline
     int n_cu = 256;
     int resident_wg[2] = {0, 0};  // persistent grid size per COUNT_RAYS instantiation (0 = not yet queried)
     DevScene sc{};
@@ -283,6 +286,76 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
     return GLRTX_OK;
 }
 
+
+int ensure(glrtx_ctx *c, DevBuf &b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return GLRTX_OK;
+    dev_free(b);
+    HIP_TRY(c, hipMalloc(&b.p, std::max<size_t>(bytes, 64)));
+    b.bytes = std::max<size_t>(bytes, 64);
+    return GLRTX_OK;
+}
+
+// Variant 2: generate, then n_samples*(max_depth+1) trips of {traverse, shade}.  All launches go to the
+// ctx stream; queue lengths live on the device, so every kernel is launched with a fixed grid.
+int launch_wavefront(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
+    const int tiles8_x = (c->width + 7) / 8, tiles8_y = (c->owned_rows + 7) / 8;
+    const size_t total = (size_t)tiles8_x * tiles8_y * 64;
+    if (total * 2 >= (size_t)INT32_MAX) return fail(c, GLRTX_EINVAL, "image too large for the wavefront variant");
+    const long long trips_ll = (long long)p->n_samples * ((long long)p->max_depth + 1);
+    if (trips_ll > 100000) return fail(c, GLRTX_EINVAL, "n_samples * (max_depth + 1) too large for the wavefront variant");
+    const int trips = (int)trips_ll;
+    int rc;
+    for (auto &b : c->wfA) if ((rc = ensure(c, b, total * sizeof(float4)))) return rc;
+    if ((rc = ensure(c, c->wfH, total * sizeof(float4)))) return rc;
+    if ((rc = ensure(c, c->wfHS, total * sizeof(float2)))) return rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = ensure(c, c->wfQT[k], 2 * total * sizeof(unsigned)))) return rc;
+        if ((rc = ensure(c, c->wfQS[k], total * sizeof(unsigned)))) return rc;
+    }
+    const size_t cnt_bytes = (size_t)(trips + 2) * 4 * sizeof(unsigned);
+    if ((rc = ensure(c, c->wfCnt, cnt_bytes))) return rc;
+
+    WfArgs w;
+    w.A0 = (float4 *)c->wfA[0].p; w.A1 = (float4 *)c->wfA[1].p; w.A2 = (float4 *)c->wfA[2].p;
+    w.A3 = (float4 *)c->wfA[3].p; w.A4 = (float4 *)c->wfA[4].p; w.A5 = (float4 *)c->wfA[5].p;
+    w.H = (float4 *)c->wfH.p; w.HS = (float2 *)c->wfHS.p;
+    for (int k = 0; k < 2; k++) { w.qT[k] = (unsigned *)c->wfQT[k].p; w.qS[k] = (unsigned *)c->wfQS[k].p; }
+    w.cnt = (unsigned *)c->wfCnt.p;
+    w.total = (int)total;
+    w.tiles8_x = tiles8_x;
+
+    const int lds_trav = 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int);
+    const int lds_shade = c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0;
+    if (lds_trav > 160 * 1024) return fail(c, GLRTX_EDEVICE, "traversal kernel needs %d B of LDS", lds_trav);
+    if (lds_trav > 64 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute((const void *)wf_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, lds_trav));
+    int per_cu = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_traverse, kBlockThreads, lds_trav));
+    if (per_cu < 1) per_cu = 1;
+    const int blocks_all = (int)((total + kBlockThreads - 1) / kBlockThreads);
+    const int grid_trav = std::max(1, std::min(per_cu * c->n_cu, (int)((2 * total + kRayChunk * 4 - 1) / (kRayChunk * 4))));
+    const int grid_flat = std::max(1, std::min(blocks_all, 8 * c->n_cu));
+
+    HIP_TRY(c, hipMemsetAsync(c->wfCnt.p, 0, cnt_bytes, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(wf_generate, dim3(grid_flat), dim3(256), 0, c->stream, a, w);
+    for (int it = 0; it < trips; it++) {
+        hipLaunchKernelGGL(wf_traverse, dim3(grid_trav), dim3(kBlockThreads), lds_trav, c->stream, a, w, it);
+        hipLaunchKernelGGL(wf_shade, dim3(grid_flat), dim3(kBlockThreads), lds_shade, c->stream, a, w, it);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->launch_pending = true;
+    c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples;
+    if (c->count_rays) {  // rays traced = sum of the ray-queue lengths (no atomics in the kernels)
+        std::vector<unsigned> cnt((size_t)(trips + 2) * 4);
+        HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->wfCnt.p, cnt_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int it = 0; it < trips; it++) c->wf_rays += cnt[(size_t)4 * it];
+    }
+    return GLRTX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -322,7 +395,7 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
     }
     c->stream = c->own_stream;
     c->n_cu = prop.multiProcessorCount;
-    if (const char *v = std::getenv("GLRTX_VARIANT")) c->variant = std::atoi(v) != 0;
+    if (const char *v = std::getenv("GLRTX_VARIANT")) { const int x = std::atoi(v); if (x >= 0 && x <= 2) c->variant = x; }
     *out = c;
     return GLRTX_OK;
 }
@@ -333,6 +406,9 @@ void glrtx_destroy(glrtx_ctx *c) {
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     dev_free(c->forks); dev_free(c->tris); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights);
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
+    for (auto &b : c->wfA) dev_free(b);
+    dev_free(c->wfH); dev_free(c->wfHS); dev_free(c->wfCnt);
+    for (int k = 0; k < 2; k++) { dev_free(c->wfQT[k]); dev_free(c->wfQS[k]); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->tm0) (void)hipEventDestroy(c->tm0);
@@ -463,7 +539,7 @@ int glrtx_set_stream(glrtx_ctx *c, void *hip_stream) {
 
 int glrtx_set_variant(glrtx_ctx *c, int variant) {
     if (!c) return GLRTX_EINVAL;
-    if (variant != 0 && variant != 1) return fail(c, GLRTX_EINVAL, "glrtx_set_variant: unknown variant %d", variant);
+    if (variant < 0 || variant > 2) return fail(c, GLRTX_EINVAL, "glrtx_set_variant: unknown variant %d", variant);
     c->variant = variant;
     return GLRTX_OK;
 }
@@ -509,6 +585,7 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     if ((size_t)a.pitch_f4 * (size_t)c->owned_rows >= (size_t)INT32_MAX)
         return fail(c, GLRTX_EINVAL, "accumulator too large for 32-bit pixel offsets");
 
+    if (c->variant == 2) return launch_wavefront(c, a, p);
     if (c->variant == 1) {
         // persistent kernel: grid = what is resident at once (occupancy x CUs), capped by the work available
         const int ci = c->count_rays ? 1 : 0;
@@ -601,7 +678,7 @@ int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
     if (!c || !out) return GLRTX_EINVAL;
     *out = c->st;
     unsigned long long r = 0;
-    if (c->counter.p && hipMemcpy(&r, c->counter.p, sizeof r, hipMemcpyDeviceToHost) == hipSuccess) out->rays = r;
+    if (c->counter.p && hipMemcpy(&r, c->counter.p, sizeof r, hipMemcpyDeviceToHost) == hipSuccess) out->rays = r + c->wf_rays;
     return GLRTX_OK;
 }
 
@@ -609,6 +686,7 @@ int glrtx_reset_stats(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
     if (int rc = glrtx_sync(c)) return rc;
     HIP_TRY(c, hipMemset(c->counter.p, 0, sizeof(unsigned long long)));
+    c->wf_rays = 0;
     c->st.rays = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_ms_total = 0.0; c->st.kernel_ms_last = 0.f;
     return GLRTX_OK;
 }

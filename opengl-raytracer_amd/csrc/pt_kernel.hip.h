@@ -188,85 +188,105 @@ DEV void trav_stats_iter(int cur) {
 }
 #endif
 
-template <bool CLOSEST>
-DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, float dx, float dy, float dz) {
+// Traversal state of one ray: the DFS above as an explicit state machine, so that the megakernels
+// (run it to completion) and the wavefront traversal kernel (one step per loop trip, lanes refilled
+// with fresh rays as they finish) execute literally the same code.
+struct Trav {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
     Hit h;
-    h.t = PT_INFTY; h.tri = -1; h.u = 0.f; h.v = 0.f;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // :260 (loop-invariant there)
-    int sp = 0;
-    int cur = sc.root_ref;
-#ifdef GLRTX_TRAV_STATS
-#define TS_ITER trav_stats_iter(cur)
-#else
-#define TS_ITER
-#endif
-    if (cur >= 0) {  // the root fork's own box
+    int cur, sp;
+};
+
+// Returns false if the ray is finished before the first step (root box missed).
+DEV bool trav_init(const DevScene &sc, Trav &T, float ox, float oy, float oz, float dx, float dy, float dz) {
+    T.ox = ox; T.oy = oy; T.oz = oz; T.dx = dx; T.dy = dy; T.dz = dz;
+    T.ix = 1.0f / dx; T.iy = 1.0f / dy; T.iz = 1.0f / dz;  // :260 (loop-invariant there)
+    T.h.t = PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
+    T.sp = 0;
+    T.cur = sc.root_ref;
+    if (T.cur >= 0) {  // the root fork's own box
         float t0;
-        if (!box_pass(sc.root_lo, sc.root_hi, ox, oy, oz, ix, iy, iz, h.t, t0)) return h;
+        if (!box_pass(sc.root_lo, sc.root_hi, ox, oy, oz, T.ix, T.iy, T.iz, T.h.t, t0)) return false;
     }
-    for (;;) {
-        TS_ITER;
-        if (cur >= 0) {
-            const float4 *N = sc.forks + 4 * (size_t)cur;
-            const float4 L0 = N[0], L1 = N[1], R0 = N[2], R1 = N[3];
-            const int l = __float_as_int(L0.w), r = __float_as_int(L1.w);
-            float t0l = -PT_INFTY, t0r;
-            const bool pl = l != REF_ABSENT && (l < 0 || box_pass(L0, L1, ox, oy, oz, ix, iy, iz, h.t, t0l));
-            const bool pr = r != REF_ABSENT && (r < 0 || box_pass(R0, R1, ox, oy, oz, ix, iy, iz, h.t, t0r));
-            if (pr) {
-                if (pl) {
-                    stack[(2 * sp) * kBlockThreads] = l;
-                    stack[(2 * sp + 1) * kBlockThreads] = __float_as_int(t0l);
-                    sp++;
-                }
-                cur = r;
-                continue;
-            }
+    return true;
+}
+
+// One trip of the traversal loop: process T.cur (fork or leaf), then pick the next node.
+// Returns true when the ray is finished (stack empty).
+template <bool CLOSEST>
+DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
+#ifdef GLRTX_TRAV_STATS
+    trav_stats_iter(T.cur);
+#endif
+    const int cur = T.cur;
+    if (cur >= 0) {
+        const float4 *N = sc.forks + 4 * (size_t)cur;
+        const float4 L0 = N[0], L1 = N[1], R0 = N[2], R1 = N[3];
+        const int l = __float_as_int(L0.w), r = __float_as_int(L1.w);
+        float t0l = -PT_INFTY, t0r;
+        const bool pl = l != REF_ABSENT && (l < 0 || box_pass(L0, L1, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0l));
+        const bool pr = r != REF_ABSENT && (r < 0 || box_pass(R0, R1, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0r));
+        if (pr) {
             if (pl) {
-                cur = l;
-                continue;
+                stack[(2 * T.sp) * kBlockThreads] = l;
+                stack[(2 * T.sp + 1) * kBlockThreads] = __float_as_int(t0l);
+                T.sp++;
             }
-        } else {
-            // leaf :310-331 with intersect(Ray, Triangle) :226-257
-            const int t = ~cur;
-            const float4 T0 = sc.tris[3 * t], T1 = sc.tris[3 * t + 1], T2 = sc.tris[3 * t + 2];
-            const float px = dy * T2.z - dz * T2.y;
-            const float py = dz * T2.x - dx * T2.z;
-            const float pz = dx * T2.y - dy * T2.x;
-            const float det = dot3(T1.x, T1.y, T1.z, px, py, pz);
-            if (!(-PT_EPS < det && det < PT_EPS)) {
-                const float inv = 1.0f / det;
-                const float tx = ox - T0.x, ty = oy - T0.y, tz = oz - T0.z;
-                const float U = dot3(tx, ty, tz, px, py, pz);
-                const float u = U * inv;
-                if (!(u < 0.0f || 1.0f < u)) {
-                    const float qx = ty * T1.z - tz * T1.y;
-                    const float qy = tz * T1.x - tx * T1.z;
-                    const float qz = tx * T1.y - ty * T1.x;
-                    const float V = dot3(dx, dy, dz, qx, qy, qz);
-                    const float v = V * inv;
-                    if (!(v < 0.0f || 1.0f < inv * (U + V))) {  // u+v>1 is evaluated as inv*(U+V)>1
-                        const float tt = dot3(T2.x, T2.y, T2.z, qx, qy, qz) * inv;
-                        if (!(PT_EPS >= tt)) {
-                            if (CLOSEST && tt < h.t) {
-                                h.tri = t; h.u = u; h.v = v;
-                            }
-                            if (!CLOSEST && tt < h.t) h.tri = t;
-                            h.t = __builtin_fminf(h.t, tt);
+            T.cur = r;
+            return false;
+        }
+        if (pl) {
+            T.cur = l;
+            return false;
+        }
+    } else {
+        // leaf :310-331 with intersect(Ray, Triangle) :226-257
+        const int t = ~cur;
+        const float4 T0 = sc.tris[3 * t], T1 = sc.tris[3 * t + 1], T2 = sc.tris[3 * t + 2];
+        const float px = T.dy * T2.z - T.dz * T2.y;
+        const float py = T.dz * T2.x - T.dx * T2.z;
+        const float pz = T.dx * T2.y - T.dy * T2.x;
+        const float det = dot3(T1.x, T1.y, T1.z, px, py, pz);
+        if (!(-PT_EPS < det && det < PT_EPS)) {
+            const float inv = 1.0f / det;
+            const float tx = T.ox - T0.x, ty = T.oy - T0.y, tz = T.oz - T0.z;
+            const float U = dot3(tx, ty, tz, px, py, pz);
+            const float u = U * inv;
+            if (!(u < 0.0f || 1.0f < u)) {
+                const float qx = ty * T1.z - tz * T1.y;
+                const float qy = tz * T1.x - tx * T1.z;
+                const float qz = tx * T1.y - ty * T1.x;
+                const float V = dot3(T.dx, T.dy, T.dz, qx, qy, qz);
+                const float v = V * inv;
+                if (!(v < 0.0f || 1.0f < inv * (U + V))) {  // u+v>1 is evaluated as inv*(U+V)>1
+                    const float tt = dot3(T2.x, T2.y, T2.z, qx, qy, qz) * inv;
+                    if (!(PT_EPS >= tt)) {
+                        if (tt < T.h.t) {
+                            T.h.tri = t;
+                            if (CLOSEST) { T.h.u = u; T.h.v = v; }
                         }
+                        T.h.t = __builtin_fminf(T.h.t, tt);
                     }
                 }
             }
         }
-        // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298
-        for (;;) {
-            if (sp == 0) return h;
-            sp--;
-            cur = stack[(2 * sp) * kBlockThreads];
-            const float t0 = __int_as_float(stack[(2 * sp + 1) * kBlockThreads]);
-            if (h.t >= t0) break;
-        }
     }
+    // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298
+    for (;;) {
+        if (T.sp == 0) return true;
+        T.sp--;
+        T.cur = stack[(2 * T.sp) * kBlockThreads];
+        const float t0 = __int_as_float(stack[(2 * T.sp + 1) * kBlockThreads]);
+        if (T.h.t >= t0) return false;
+    }
+}
+
+template <bool CLOSEST>
+DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, float dx, float dy, float dz) {
+    Trav T;
+    if (trav_init(sc, T, ox, oy, oz, dx, dy, dz))
+        while (!trav_step<CLOSEST>(sc, stack, T)) {}
+    return T.h;
 }
 
 // fresnelConductor :158-178, one channel
@@ -321,9 +341,24 @@ DEV void path_begin(Path &P, float ox, float oy, float oz, float dx, float dy, f
     P.depth = 0;
 }
 
-// One iteration of the depth loop.  Returns true when the loop ends (a `break`, or depth reaching
-// u_maxDepth).  Precondition: P.depth < a.max_depth.
-DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rng, Path &P, unsigned &rays) {
+// Everything one iteration of the depth loop does EXCEPT its two BVH traversals: given the closest hit
+// `h` of the current ray it applies emission, samples the BSDF, prepares next-event estimation (the
+// shadow ray and both possible values of L: light sample accepted or rejected), advances the ray /
+// beta / depth and plays Russian roulette.  None of that depends on the shadow ray's result: in the
+// reference the acceptance test (:367) only selects whether e*f*G/pdf or 0 is added (:539), and every
+// rand() call is made regardless.  The megakernels and the wavefront pipeline share this one copy of
+// the shading arithmetic.  On return P holds the next ray / beta / depth; P.L is NOT updated: the
+// caller sets it to Lpass or Lfail.
+struct Shade {
+    bool ended;           // the depth loop ends after this iteration (break, depth limit, roulette)
+    bool has_shadow;      // a shadow ray must be traced from P.o along sd: L = accepted ? Lpass : Lfail
+    float sdx, sdy, sdz;  // shadow ray direction
+    float dist;           // |p - x| for the acceptance test |dist - tHit| < EPS
+    float Lpx, Lpy, Lpz;  // L with the light sample accepted (== L itself when !has_shadow)
+    float Lfx, Lfy, Lfz;  // L with it rejected
+};
+
+DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &P, const Hit &h, Shade &out) {
     const DevScene &sc = a.sc;
     float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
     float bx = P.bx, by = P.by, bz = P.bz;
@@ -331,10 +366,12 @@ DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rn
     const int depth = P.depth;
     const float nLf = (float)sc.n_light;
     bool done = true;  // every `break` of the reference loop leaves this set
+    bool has_shadow = false;
+    float sdx = 0.f, sdy = 0.f, sdz = 0.f, sdist = 0.f;
+    float px_ = 0.f, py_ = 0.f, pz_ = 0.f;  // beta * candidate contribution
+    float zx_ = 0.f, zy_ = 0.f, zz_ = 0.f;  // beta * 0
 
     do {
-        const Hit h = traverse<true>(sc, stack, ox, oy, oz, dx, dy, dz);
-        rays++;
         if (h.tri < 0) break;  // miss: nothing is added and the loop ends (:497-499)
 
         // normal of the closest hit (:254), computed once instead of per candidate
@@ -483,10 +520,10 @@ DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rn
                 const float dd = (dvz * dvz + dvy * dvy) + dvx * dvx;
                 const float rd = rsq(dd);
                 const float dirx = dvx * rd, diry = dvy * rd, dirz = dvz * rd;
-                const Hit sh = traverse<false>(sc, stack, sox, soy, soz, dirx, diry, dirz);
-                rays++;
-                const float dist = __builtin_sqrtf(dd);
-                if (sh.tri >= 0 && __builtin_fabsf(dist - sh.t) < PT_EPS) {  // :367
+                has_shadow = true;
+                sdx = dirx; sdy = diry; sdz = dirz;
+                sdist = __builtin_sqrtf(dd);
+                {  // the contribution IF the shadow ray passes the test at :367
                     float gx = 0.f, gy = 0.f, gz = 0.f;
                     if (type == 2) {
                         gx = M.m1.x; gy = M.m1.y; gz = M.m1.z;  // albedo without 1/PI :372
@@ -529,7 +566,9 @@ DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rn
                     }
                 }
             }
-            Lx = Lx + bx * cx; Ly = Ly + by * cy; Lz = Lz + bz * cz;  // :539
+            // :539 L += beta * sampleDirect(): both outcomes of the acceptance test
+            px_ = bx * cx; py_ = by * cy; pz_ = bz * cz;
+            zx_ = bx * 0.0f; zy_ = by * 0.0f; zz_ = bz * 0.0f;
             // :542-544; wi is not renormalised
             const float wix = (ux * wlx + vx * wly) + nx * wlz;
             const float wiy = (-(nuy * wlx) + vy * wly) + ny * wlz;
@@ -556,9 +595,36 @@ DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rn
 
     P.ox = ox; P.oy = oy; P.oz = oz; P.dx = dx; P.dy = dy; P.dz = dz;
     P.bx = bx; P.by = by; P.bz = bz;
-    P.Lx = Lx; P.Ly = Ly; P.Lz = Lz;
     P.depth = depth + 1;
-    return done || P.depth >= a.max_depth;
+    out.ended = done || P.depth >= a.max_depth;
+    out.has_shadow = has_shadow;
+    out.sdx = sdx; out.sdy = sdy; out.sdz = sdz; out.dist = sdist;
+    if (has_shadow) {
+        out.Lpx = Lx + px_; out.Lpy = Ly + py_; out.Lpz = Lz + pz_;
+        out.Lfx = Lx + zx_; out.Lfy = Ly + zy_; out.Lfz = Lz + zz_;
+    } else {
+        out.Lpx = out.Lfx = Lx; out.Lpy = out.Lfy = Ly; out.Lpz = out.Lfz = Lz;
+    }
+}
+
+// The acceptance test of sampleDirect (:367): the shadow ray hit something at the light sample's distance.
+DEV bool nee_accepted(float dist, float tS, bool hit) { return hit && __builtin_fabsf(dist - tS) < PT_EPS; }
+
+// One iteration of the depth loop (megakernel form).  Returns true when the loop ends (a `break`, or
+// depth reaching u_maxDepth).  Precondition: P.depth < a.max_depth.
+DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rng, Path &P, unsigned &rays) {
+    const Hit h = traverse<true>(a.sc, stack, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz);
+    rays++;
+    Shade sh;
+    shade_hit(a, lds_mats, rng, P, h, sh);
+    bool ok = false;
+    if (sh.has_shadow) {
+        const Hit s = traverse<false>(a.sc, stack, P.ox, P.oy, P.oz, sh.sdx, sh.sdy, sh.sdz);
+        rays++;
+        ok = nee_accepted(sh.dist, s.t, s.tri >= 0);
+    }
+    P.Lx = ok ? sh.Lpx : sh.Lfx; P.Ly = ok ? sh.Lpy : sh.Lfy; P.Lz = ok ? sh.Lpz : sh.Lfz;
+    return sh.ended;
 }
 
 // primary ray of one sample, main() :577-607
@@ -770,6 +836,256 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
         }
     }
     flush_rays<COUNT_RAYS>(a, rays);
+}
+
+// ------------------------------------------------------------------------------------------ wavefront pipeline
+// Variant C ("wavefront"): the depth loop is cut at its two traversals.  Per frame:
+//     wf_generate                      camera rays of sample 0 for every owned pixel
+//     repeat  n_samples*(u_maxDepth+1) times:
+//         wf_traverse(it)              all rays queued for this trip: the paths' next rays AND the shadow
+//                                      rays of the previous bounce (both are closest-hit queries, :363)
+//         wf_shade(it)                 per live path: resolve the pending shadow ray (:367), then shade_hit()
+//                                      on the new hit, queue next + shadow ray; finished paths add their
+//                                      sample to the accumulator and start the pixel's next sample
+// wf_traverse is a small-register kernel whose lanes pull RAYS from the queue one at a time (a lane
+// whose ray is finished takes the next queued ray), so SIMD lanes stay full although traversal length
+// varies 10x between rays; wf_shade runs on a compacted list of live paths.  Path state lives in HBM
+// as float4 SoA, indexed by the pixel's tile-order id.  Per-path arithmetic, RNG call order and the
+// order in which samples are added to a pixel are exactly those of the megakernels: bit-identical.
+struct WfArgs {
+    float4 *A0;  // {next ray origin (= shadow ray origin), rng.x}
+    float4 *A1;  // {next ray direction, rng.y}
+    float4 *A2;  // {beta, meta}           meta = depth | sample << 8 | flags
+    float4 *A3;  // {L if the pending light sample is accepted (or L), dist}
+    float4 *A4;  // {L if it is rejected, -}
+    float4 *A5;  // {shadow ray direction, -}
+    float4 *H;   // closest hit of the path's ray {t, tri, u, v}
+    float2 *HS;  // closest hit of the shadow ray {t, tri}
+    unsigned *qT[2];  // ray queues (ping-pong): id*2 + kind (0 = path ray, 1 = shadow ray)
+    unsigned *qS[2];  // path queues (ping-pong): ids to shade after the traversal
+    unsigned *cnt;    // per trip: [4*it + 0] rays queued, [+1] paths queued, [+2] traversal work head
+    int total;        // tile-order ids: tiles8_x * tiles8_y * 64
+    int tiles8_x;
+};
+constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
+constexpr unsigned WF_FINISHING = 1u << 29;  // the path has ended; only that shadow ray is awaited
+
+DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lrow) {
+    const int t = id >> 6, k = id & 63;
+    lx = (t % w.tiles8_x) * 8 + (k & 7);
+    lrow = (t / w.tiles8_x) * 8 + (k >> 3);
+    return lx < a.width && lrow < a.owned_rows;
+}
+
+// Wave-aggregated append: lanes with `want` get consecutive slots of a device queue counter.
+DEV unsigned wf_reserve(unsigned *counter, bool want) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return 0u;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+    base = (unsigned)__shfl((int)base, leader);  // the leader wants a slot, so it is an active lane
+    return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// Start the pixel's next sample(s): camera ray -> state; returns true if a ray must be traced.
+// With u_maxDepth <= 0 a sample is finished as soon as it starts (main() still draws its jitter).
+DEV bool wf_start(const KernelArgs &a, Rng &rng, float fcx, float fcy, Path &P, unsigned &sample, float4 *px) {
+    for (;;) {
+        if ((int)sample >= a.n_samples) return false;
+        camera_ray(a, rng, fcx, fcy, P);
+        if (a.max_depth > 0) return true;
+        float4 acc = *px;
+        acc.x = acc.x + 0.0f; acc.y = acc.y + 0.0f; acc.z = acc.z + 0.0f;  // min(L, 100) of L = 0
+        acc.w = acc.w + 1.0f;
+        *px = acc;
+        sample++;
+    }
+}
+
+__global__ __launch_bounds__(256) void wf_generate(const KernelArgs a, const WfArgs w) {
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < w.total; id += gridDim.x * 256) {
+        int lx, lrow;
+        bool go = false;
+        Rng rng = {0.f, 0.f, a.seed_x, a.seed_y};
+        Path P;
+        unsigned sample = 0;
+        if (wf_pixel(a, w, id, lx, lrow)) {
+            const int gy = local_row_to_y(a, lrow);
+            const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
+            rng.x = fcx / (float)a.width; rng.y = fcy / (float)a.height;  // :567
+            go = wf_start(a, rng, fcx, fcy, P, sample, a.accum + (size_t)lrow * a.pitch_f4 + lx);
+        }
+        if (go) {
+            w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
+            w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
+            w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
+            w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const unsigned ir = wf_reserve(w.cnt + 0, go);
+        const unsigned is = wf_reserve(w.cnt + 1, go);
+        if (go) {
+            w.qT[0][ir] = (unsigned)id * 2u;
+            w.qS[0][is] = (unsigned)id;
+        }
+    }
+}
+
+constexpr int kRayChunk = 256;  // rays a wavefront reserves per global atomic
+
+__global__ __launch_bounds__(kBlockThreads) void wf_traverse(const KernelArgs a, const WfArgs w, int it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int *stack = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
+    const unsigned *q = w.qT[it & 1];
+    const int n_rays = (int)w.cnt[4 * it + 0];
+    unsigned *head = w.cnt + 4 * it + 2;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    int chunk_next = 0, chunk_end = 0;  // wave-uniform
+    bool exhausted = false;
+    bool active = false;
+    unsigned rid = 0;
+    Trav T;
+    T.cur = 0; T.sp = 0;
+
+    for (;;) {
+        // ---- refill idle lanes with queued rays
+        unsigned long long idle = __ballot(!active);
+        while (idle != 0ull && !exhausted) {
+            if (chunk_next >= chunk_end) {
+                int base = 0;
+                if (lane == 0) base = (int)atomicAdd(head, (unsigned)kRayChunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n_rays) { exhausted = true; break; }
+                chunk_next = base;
+                chunk_end = base + kRayChunk < n_rays ? base + kRayChunk : n_rays;
+            }
+            const int n = __popcll(idle);
+            const int avail = chunk_end - chunk_next;
+            const int take = n < avail ? n : avail;
+            const int rank = __popcll(idle & lt_mask);
+            if (!active && rank < take) {
+                rid = q[chunk_next + rank];
+                const unsigned id = rid >> 1;
+                const float4 o = w.A0[id];
+                const float4 d = (rid & 1u) ? w.A5[id] : w.A1[id];
+                active = trav_init(a.sc, T, o.x, o.y, o.z, d.x, d.y, d.z);
+                if (!active) {  // the root box was missed: result known at once
+                    if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(-1));
+                    else w.H[id] = make_float4(T.h.t, __int_as_float(-1), 0.f, 0.f);
+                }
+            }
+            chunk_next += take;
+            idle = __ballot(!active);
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- one traversal step per live lane
+        if (active) {
+            if (trav_step<true>(a.sc, stack, T)) {
+                const unsigned id = rid >> 1;
+                if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(T.h.tri));
+                else w.H[id] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
+                active = false;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void wf_shade(const KernelArgs a, const WfArgs w, int it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float4 *lds_mats = reinterpret_cast<float4 *>(lds_raw);
+    if (a.sc.mats_in_lds) {
+        for (int i = threadIdx.x; i < 3 * a.sc.n_mat; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
+        __syncthreads();
+    }
+    const unsigned *qs = w.qS[it & 1];
+    unsigned *qt_next = w.qT[(it + 1) & 1], *qs_next = w.qS[(it + 1) & 1];
+    unsigned *cnt_next = w.cnt + 4 * (it + 1);
+    const int n_paths = (int)w.cnt[4 * it + 1];
+    const int stride = gridDim.x * kBlockThreads;
+    // whole waves iterate together so that the wave-aggregated queue appends see uniform control flow
+    for (int base = blockIdx.x * kBlockThreads + (threadIdx.x & ~63); base < n_paths; base += stride) {
+        const int i = base + (threadIdx.x & 63);
+        bool push_ext = false, push_sh = false;
+        unsigned id = 0;
+        if (i < n_paths) {
+            id = qs[i];
+            int lx, lrow;
+            wf_pixel(a, w, (int)id, lx, lrow);
+            const int gy = local_row_to_y(a, lrow);
+            const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
+            float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
+            const float4 s0 = w.A0[id], s1 = w.A1[id], s2 = w.A2[id], s3 = w.A3[id];
+            Rng rng = {s0.w, s1.w, a.seed_x, a.seed_y};
+            const unsigned meta = __float_as_uint(s2.w);
+            unsigned sample = (meta >> 8) & 0xFFFFFu;
+            Path P;
+            P.ox = s0.x; P.oy = s0.y; P.oz = s0.z; P.dx = s1.x; P.dy = s1.y; P.dz = s1.z;
+            P.bx = s2.x; P.by = s2.y; P.bz = s2.z;
+            P.depth = (int)(meta & 0xFFu);
+            // resolve the light sample of the previous bounce (:367, :539)
+            P.Lx = s3.x; P.Ly = s3.y; P.Lz = s3.z;
+            if (meta & WF_PENDING) {
+                const float2 hs = w.HS[id];
+                if (!nee_accepted(s3.w, hs.x, __float_as_int(hs.y) >= 0)) {
+                    const float4 s4 = w.A4[id];
+                    P.Lx = s4.x; P.Ly = s4.y; P.Lz = s4.z;
+                }
+            }
+            bool ended = (meta & WF_FINISHING) != 0u;
+            Shade sh;
+            sh.has_shadow = false;
+            if (!ended) {
+                const float4 hh = w.H[id];
+                Hit h;
+                h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
+                shade_hit(a, lds_mats, rng, P, h, sh);
+                if (sh.ended && !sh.has_shadow) { P.Lx = sh.Lpx; P.Ly = sh.Lpy; P.Lz = sh.Lpz; }
+                ended = sh.ended && !sh.has_shadow;  // with a shadow ray in flight the sample closes next trip
+            }
+            if (ended) {
+                // radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609)
+                float4 acc = *px;
+                acc.x = acc.x + fmin_c(P.Lx, 100.0f);
+                acc.y = acc.y + fmin_c(P.Ly, 100.0f);
+                acc.z = acc.z + fmin_c(P.Lz, 100.0f);
+                acc.w = acc.w + 1.0f;
+                *px = acc;
+                sample++;
+                push_ext = wf_start(a, rng, fcx, fcy, P, sample, px);  // the pixel's next sample, if any
+                if (push_ext) {
+                    w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
+                    w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
+                    w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
+                    w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                // shade_hit ran and the path goes on and/or awaits its shadow ray
+                push_sh = sh.has_shadow;
+                push_ext = !sh.ended;
+                const unsigned m2 = (unsigned)P.depth | (sample << 8) | (push_sh ? WF_PENDING : 0u) | (sh.ended ? WF_FINISHING : 0u);
+                w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
+                w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
+                w.A2[id] = make_float4(P.bx, P.by, P.bz, __uint_as_float(m2));
+                w.A3[id] = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist);
+                if (push_sh) {
+                    w.A4[id] = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f);
+                    w.A5[id] = make_float4(sh.sdx, sh.sdy, sh.sdz, 0.f);
+                }
+            }
+        }
+        const unsigned ie = wf_reserve(cnt_next + 0, push_ext);
+        const unsigned ih = wf_reserve(cnt_next + 0, push_sh);
+        const unsigned is = wf_reserve(cnt_next + 1, push_ext || push_sh);
+        if (push_ext) qt_next[ie] = id * 2u;
+        if (push_sh) qt_next[ih] = id * 2u + 1u;
+        if (push_ext || push_sh) qs_next[is] = id;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ resolve
