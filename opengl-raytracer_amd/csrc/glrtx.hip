@@ -312,7 +312,7 @@ int launch_wavefront(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
         if ((rc = ensure(c, c->wfQT[k], 2 * total * sizeof(unsigned)))) return rc;
         if ((rc = ensure(c, c->wfQS[k], total * sizeof(unsigned)))) return rc;
     }
-    const size_t cnt_bytes = (size_t)(trips + 2) * 4 * sizeof(unsigned);
+    const size_t cnt_bytes = (size_t)(trips + 2) * kCntStride * sizeof(unsigned);
     if ((rc = ensure(c, c->wfCnt, cnt_bytes))) return rc;
 
     WfArgs w;
@@ -325,34 +325,34 @@ int launch_wavefront(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
     w.tiles8_x = tiles8_x;
 
     const int lds_trav = 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int);
-    const int lds_shade = c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0;
+    const int lds_shade = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + (3 * kShadeBlock + 8) * (int)sizeof(unsigned);
     if (lds_trav > 160 * 1024) return fail(c, GLRTX_EDEVICE, "traversal kernel needs %d B of LDS", lds_trav);
     if (lds_trav > 64 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute((const void *)wf_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, lds_trav));
-    int per_cu = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_traverse, kBlockThreads, lds_trav));
+        HIP_TRY(c, hipFuncSetAttribute((const void *)wf_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_trav));
+    if (lds_trav > 64 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute((const void *)wf_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_trav));
+    int per_cu = 0, per_cu_shade = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_traverse<false>, kBlockThreads, lds_trav));
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, wf_shade, kBlockThreads, lds_shade));
+    if (per_cu_shade < 1) per_cu_shade = 1;
     if (per_cu < 1) per_cu = 1;
     const int blocks_all = (int)((total + kBlockThreads - 1) / kBlockThreads);
     const int grid_trav = std::max(1, std::min(per_cu * c->n_cu, (int)((2 * total + kRayChunk * 4 - 1) / (kRayChunk * 4))));
     const int grid_flat = std::max(1, std::min(blocks_all, 8 * c->n_cu));
+    const int grid_shade = std::max(1, std::min(per_cu_shade * c->n_cu, (int)((total + kShadeBlock - 1) / kShadeBlock)));
 
     HIP_TRY(c, hipMemsetAsync(c->wfCnt.p, 0, cnt_bytes, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     hipLaunchKernelGGL(wf_generate, dim3(grid_flat), dim3(256), 0, c->stream, a, w);
     for (int it = 0; it < trips; it++) {
-        hipLaunchKernelGGL(wf_traverse, dim3(grid_trav), dim3(kBlockThreads), lds_trav, c->stream, a, w, it);
-        hipLaunchKernelGGL(wf_shade, dim3(grid_flat), dim3(kBlockThreads), lds_shade, c->stream, a, w, it);
+        if (c->count_rays) hipLaunchKernelGGL(wf_traverse<true>, dim3(grid_trav), dim3(kBlockThreads), lds_trav, c->stream, a, w, it);
+        else hipLaunchKernelGGL(wf_traverse<false>, dim3(grid_trav), dim3(kBlockThreads), lds_trav, c->stream, a, w, it);
+        hipLaunchKernelGGL(wf_shade, dim3(grid_shade), dim3(kBlockThreads), lds_shade, c->stream, a, w, it);
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->launch_pending = true;
     c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples;
-    if (c->count_rays) {  // rays traced = sum of the ray-queue lengths (no atomics in the kernels)
-        std::vector<unsigned> cnt((size_t)(trips + 2) * 4);
-        HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->wfCnt.p, cnt_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        for (int it = 0; it < trips; it++) c->wf_rays += cnt[(size_t)4 * it];
-    }
     return GLRTX_OK;
 }
 

@@ -877,17 +877,19 @@ DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lr
     return lx < a.width && lrow < a.owned_rows;
 }
 
-// Wave-aggregated append: lanes with `want` get consecutive slots of a device queue counter.
-DEV unsigned wf_reserve(unsigned *counter, bool want) {
-    const unsigned long long m = __ballot(want);
-    if (m == 0ull) return 0u;
-    const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    const int leader = __ffsll((long long)m) - 1;
-    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
-    base = (unsigned)__shfl((int)base, leader);  // the leader wants a slot, so it is an active lane
-    return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-}
+// Queue bookkeeping.  A single contended device counter sustains only ~88 atomics/us on MI355X, so
+// the queues are built to need very few of them: wf_generate writes its queue densely (slot = id,
+// out-of-image ids carry WF_INVALID), wf_shade collects the appends of 2048 paths in LDS and reserves
+// global space once per super-block, and wf_traverse pulls 256-ray chunks from 16 sharded heads.
+constexpr unsigned WF_INVALID = 0xFFFFFFFFu;  // queue entry to skip
+// Counters of one trip; every contended word sits in its own 128-byte line (atomics to one line serialise).
+constexpr int kTravShards = 16;
+constexpr int kCntLine = 32;  // unsigned words per 128-byte line
+constexpr int kCntRays = 0, kCntPaths = kCntLine, kCntShadeHead = 2 * kCntLine, kCntTravHead = 3 * kCntLine /* + shard*kCntLine */;
+constexpr int kCntStride = (3 + kTravShards) * kCntLine;  // unsigned words of counters per trip
+constexpr int kRayChunk = 256;    // rays a wavefront reserves per global atomic
+constexpr int kRefillMin = 16;    // refill a traversal wave once this many lanes are idle
+constexpr int kShadeBlock = 2048; // paths per wf_shade super-block (8 per thread)
 
 // Start the pixel's next sample(s): camera ray -> state; returns true if a ray must be traced.
 // With u_maxDepth <= 0 a sample is finished as soon as it starts (main() still draws its jitter).
@@ -905,6 +907,10 @@ DEV bool wf_start(const KernelArgs &a, Rng &rng, float fcx, float fcy, Path &P, 
 }
 
 __global__ __launch_bounds__(256) void wf_generate(const KernelArgs a, const WfArgs w) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // dense queues: one slot per tile-order id
+        w.cnt[kCntRays] = (unsigned)w.total;
+        w.cnt[kCntPaths] = (unsigned)w.total;
+    }
     for (int id = blockIdx.x * 256 + threadIdx.x; id < w.total; id += gridDim.x * 256) {
         int lx, lrow;
         bool go = false;
@@ -923,62 +929,76 @@ __global__ __launch_bounds__(256) void wf_generate(const KernelArgs a, const WfA
             w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
             w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const unsigned ir = wf_reserve(w.cnt + 0, go);
-        const unsigned is = wf_reserve(w.cnt + 1, go);
-        if (go) {
-            w.qT[0][ir] = (unsigned)id * 2u;
-            w.qS[0][is] = (unsigned)id;
-        }
+        w.qT[0][id] = go ? (unsigned)id * 2u : WF_INVALID;
+        w.qS[0][id] = go ? (unsigned)id : WF_INVALID;
     }
 }
 
-constexpr int kRayChunk = 256;  // rays a wavefront reserves per global atomic
-
+template <bool COUNT_RAYS>
 __global__ __launch_bounds__(kBlockThreads) void wf_traverse(const KernelArgs a, const WfArgs w, int it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int *stack = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
     const unsigned *q = w.qT[it & 1];
-    const int n_rays = (int)w.cnt[4 * it + 0];
-    unsigned *head = w.cnt + 4 * it + 2;
+    unsigned *cnt = w.cnt + (size_t)kCntStride * it;
+    const int n_rays = (int)cnt[kCntRays];
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // the queue is cut into kTravShards ranges, each with its own head: a wave starts on its home
+    // shard and moves to the next one when a shard runs dry
+    const int per = ((n_rays + kTravShards - 1) / kTravShards + kRayChunk - 1) / kRayChunk * kRayChunk;
+    int shard = (int)((blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)) % kTravShards);
+    int shards_left = kTravShards;
 
     int chunk_next = 0, chunk_end = 0;  // wave-uniform
-    bool exhausted = false;
+    bool exhausted = n_rays == 0;
     bool active = false;
-    unsigned rid = 0;
+    unsigned rid = 0, rays = 0;
     Trav T;
     T.cur = 0; T.sp = 0;
 
     for (;;) {
-        // ---- refill idle lanes with queued rays
+        // ---- refill idle lanes with queued rays, once enough of them are idle
         unsigned long long idle = __ballot(!active);
-        while (idle != 0ull && !exhausted) {
-            if (chunk_next >= chunk_end) {
-                int base = 0;
-                if (lane == 0) base = (int)atomicAdd(head, (unsigned)kRayChunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n_rays) { exhausted = true; break; }
-                chunk_next = base;
-                chunk_end = base + kRayChunk < n_rays ? base + kRayChunk : n_rays;
-            }
-            const int n = __popcll(idle);
-            const int avail = chunk_end - chunk_next;
-            const int take = n < avail ? n : avail;
-            const int rank = __popcll(idle & lt_mask);
-            if (!active && rank < take) {
-                rid = q[chunk_next + rank];
-                const unsigned id = rid >> 1;
-                const float4 o = w.A0[id];
-                const float4 d = (rid & 1u) ? w.A5[id] : w.A1[id];
-                active = trav_init(a.sc, T, o.x, o.y, o.z, d.x, d.y, d.z);
-                if (!active) {  // the root box was missed: result known at once
-                    if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(-1));
-                    else w.H[id] = make_float4(T.h.t, __int_as_float(-1), 0.f, 0.f);
+        if (__popcll(idle) >= kRefillMin || idle == ~0ull) {
+            while (idle != 0ull && !exhausted) {
+                if (chunk_next >= chunk_end) {
+                    const int lo = shard * per, hi = lo + per < n_rays ? lo + per : n_rays;
+                    int base = hi;
+                    unsigned *head = cnt + kCntTravHead + shard * kCntLine;
+                    // peek before the atomic: a dry shard costs a load, not a contended read-modify-write
+                    if (lo < hi && lo + (int)__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hi) {
+                        if (lane == 0) base = lo + (int)atomicAdd(head, (unsigned)kRayChunk);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                    }
+                    if (base >= hi) {  // this shard is dry: next one
+                        shard = (shard + 1) % kTravShards;
+                        if (--shards_left == 0) exhausted = true;
+                        continue;
+                    }
+                    chunk_next = base;
+                    chunk_end = base + kRayChunk < hi ? base + kRayChunk : hi;
                 }
+                const int n = __popcll(idle);
+                const int avail = chunk_end - chunk_next;
+                const int take = n < avail ? n : avail;
+                const int rank = __popcll(idle & lt_mask);
+                if (!active && rank < take) {
+                    rid = q[chunk_next + rank];
+                    if (rid != WF_INVALID) {
+                        const unsigned id = rid >> 1;
+                        const float4 o = w.A0[id];
+                        const float4 d = (rid & 1u) ? w.A5[id] : w.A1[id];
+                        rays++;
+                        active = trav_init(a.sc, T, o.x, o.y, o.z, d.x, d.y, d.z);
+                        if (!active) {  // the root box was missed: result known at once
+                            if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(-1));
+                            else w.H[id] = make_float4(T.h.t, __int_as_float(-1), 0.f, 0.f);
+                        }
+                    }
+                }
+                chunk_next += take;
+                idle = __ballot(!active);
             }
-            chunk_next += take;
-            idle = __ballot(!active);
         }
         if (!__any(active)) {
             if (exhausted) break;
@@ -994,97 +1014,135 @@ __global__ __launch_bounds__(kBlockThreads) void wf_traverse(const KernelArgs a,
             }
         }
     }
+    flush_rays<COUNT_RAYS>(a, rays);
 }
 
 __global__ __launch_bounds__(kBlockThreads) void wf_shade(const KernelArgs a, const WfArgs w, int it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // LDS: materials | out_rays[2*kShadeBlock] | out_paths[kShadeBlock] | {n_rays, n_paths, block, gbase_r, gbase_p}
     float4 *lds_mats = reinterpret_cast<float4 *>(lds_raw);
-    if (a.sc.mats_in_lds) {
-        for (int i = threadIdx.x; i < 3 * a.sc.n_mat; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
-        __syncthreads();
-    }
+    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    unsigned *out_rays = reinterpret_cast<unsigned *>(lds_raw + (size_t)mat_f4 * sizeof(float4));
+    unsigned *out_paths = out_rays + 2 * kShadeBlock;
+    unsigned *ctl = out_paths + kShadeBlock;
+    if (a.sc.mats_in_lds)
+        for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
+    if (threadIdx.x == 0) { ctl[0] = 0u; ctl[1] = 0u; }
+    __syncthreads();
+
     const unsigned *qs = w.qS[it & 1];
     unsigned *qt_next = w.qT[(it + 1) & 1], *qs_next = w.qS[(it + 1) & 1];
-    unsigned *cnt_next = w.cnt + 4 * (it + 1);
-    const int n_paths = (int)w.cnt[4 * it + 1];
-    const int stride = gridDim.x * kBlockThreads;
-    // whole waves iterate together so that the wave-aggregated queue appends see uniform control flow
-    for (int base = blockIdx.x * kBlockThreads + (threadIdx.x & ~63); base < n_paths; base += stride) {
-        const int i = base + (threadIdx.x & 63);
-        bool push_ext = false, push_sh = false;
-        unsigned id = 0;
-        if (i < n_paths) {
-            id = qs[i];
-            int lx, lrow;
-            wf_pixel(a, w, (int)id, lx, lrow);
-            const int gy = local_row_to_y(a, lrow);
-            const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
-            float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
-            const float4 s0 = w.A0[id], s1 = w.A1[id], s2 = w.A2[id], s3 = w.A3[id];
-            Rng rng = {s0.w, s1.w, a.seed_x, a.seed_y};
-            const unsigned meta = __float_as_uint(s2.w);
-            unsigned sample = (meta >> 8) & 0xFFFFFu;
-            Path P;
-            P.ox = s0.x; P.oy = s0.y; P.oz = s0.z; P.dx = s1.x; P.dy = s1.y; P.dz = s1.z;
-            P.bx = s2.x; P.by = s2.y; P.bz = s2.z;
-            P.depth = (int)(meta & 0xFFu);
-            // resolve the light sample of the previous bounce (:367, :539)
-            P.Lx = s3.x; P.Ly = s3.y; P.Lz = s3.z;
-            if (meta & WF_PENDING) {
-                const float2 hs = w.HS[id];
-                if (!nee_accepted(s3.w, hs.x, __float_as_int(hs.y) >= 0)) {
-                    const float4 s4 = w.A4[id];
-                    P.Lx = s4.x; P.Ly = s4.y; P.Lz = s4.z;
+    unsigned *cnt = w.cnt + (size_t)kCntStride * it, *cnt_next = cnt + kCntStride;
+    const int n_paths = (int)cnt[kCntPaths];
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (;;) {
+        // ---- next super-block of kShadeBlock queue entries (dynamic: shading cost varies)
+        if (threadIdx.x == 0) ctl[2] = atomicAdd(cnt + kCntShadeHead, 1u);
+        __syncthreads();
+        const int sb = (int)ctl[2];
+        if ((long long)sb * kShadeBlock >= n_paths) break;
+
+        for (int j = 0; j < kShadeBlock / kBlockThreads; j++) {
+            const int i = sb * kShadeBlock + j * kBlockThreads + (int)threadIdx.x;
+            bool push_ext = false, push_sh = false;
+            unsigned id = WF_INVALID;
+            if (i < n_paths) id = qs[i];
+            if (id != WF_INVALID) {
+                int lx, lrow;
+                wf_pixel(a, w, (int)id, lx, lrow);
+                const int gy = local_row_to_y(a, lrow);
+                const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
+                float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
+                const float4 s0 = w.A0[id], s1 = w.A1[id], s2 = w.A2[id], s3 = w.A3[id];
+                Rng rng = {s0.w, s1.w, a.seed_x, a.seed_y};
+                const unsigned meta = __float_as_uint(s2.w);
+                unsigned sample = (meta >> 8) & 0xFFFFFu;
+                Path P;
+                P.ox = s0.x; P.oy = s0.y; P.oz = s0.z; P.dx = s1.x; P.dy = s1.y; P.dz = s1.z;
+                P.bx = s2.x; P.by = s2.y; P.bz = s2.z;
+                P.depth = (int)(meta & 0xFFu);
+                // resolve the light sample of the previous bounce (:367, :539)
+                P.Lx = s3.x; P.Ly = s3.y; P.Lz = s3.z;
+                if (meta & WF_PENDING) {
+                    const float2 hs = w.HS[id];
+                    if (!nee_accepted(s3.w, hs.x, __float_as_int(hs.y) >= 0)) {
+                        const float4 s4 = w.A4[id];
+                        P.Lx = s4.x; P.Ly = s4.y; P.Lz = s4.z;
+                    }
                 }
-            }
-            bool ended = (meta & WF_FINISHING) != 0u;
-            Shade sh;
-            sh.has_shadow = false;
-            if (!ended) {
-                const float4 hh = w.H[id];
-                Hit h;
-                h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
-                shade_hit(a, lds_mats, rng, P, h, sh);
-                if (sh.ended && !sh.has_shadow) { P.Lx = sh.Lpx; P.Ly = sh.Lpy; P.Lz = sh.Lpz; }
-                ended = sh.ended && !sh.has_shadow;  // with a shadow ray in flight the sample closes next trip
-            }
-            if (ended) {
-                // radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609)
-                float4 acc = *px;
-                acc.x = acc.x + fmin_c(P.Lx, 100.0f);
-                acc.y = acc.y + fmin_c(P.Ly, 100.0f);
-                acc.z = acc.z + fmin_c(P.Lz, 100.0f);
-                acc.w = acc.w + 1.0f;
-                *px = acc;
-                sample++;
-                push_ext = wf_start(a, rng, fcx, fcy, P, sample, px);  // the pixel's next sample, if any
-                if (push_ext) {
+                bool ended = (meta & WF_FINISHING) != 0u;
+                Shade sh;
+                sh.has_shadow = false;
+                if (!ended) {
+                    const float4 hh = w.H[id];
+                    Hit h;
+                    h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
+                    shade_hit(a, lds_mats, rng, P, h, sh);
+                    if (sh.ended && !sh.has_shadow) { P.Lx = sh.Lpx; P.Ly = sh.Lpy; P.Lz = sh.Lpz; }
+                    ended = sh.ended && !sh.has_shadow;  // with a shadow ray in flight the sample closes next trip
+                }
+                if (ended) {
+                    // radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609)
+                    float4 acc = *px;
+                    acc.x = acc.x + fmin_c(P.Lx, 100.0f);
+                    acc.y = acc.y + fmin_c(P.Ly, 100.0f);
+                    acc.z = acc.z + fmin_c(P.Lz, 100.0f);
+                    acc.w = acc.w + 1.0f;
+                    *px = acc;
+                    sample++;
+                    push_ext = wf_start(a, rng, fcx, fcy, P, sample, px);  // the pixel's next sample, if any
+                    if (push_ext) {
+                        w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
+                        w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
+                        w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
+                        w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+                    // shade_hit ran and the path goes on and/or awaits its shadow ray
+                    push_sh = sh.has_shadow;
+                    push_ext = !sh.ended;
+                    const unsigned m2 = (unsigned)P.depth | (sample << 8) | (push_sh ? WF_PENDING : 0u) | (sh.ended ? WF_FINISHING : 0u);
                     w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
                     w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
-                    w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
-                    w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            } else {
-                // shade_hit ran and the path goes on and/or awaits its shadow ray
-                push_sh = sh.has_shadow;
-                push_ext = !sh.ended;
-                const unsigned m2 = (unsigned)P.depth | (sample << 8) | (push_sh ? WF_PENDING : 0u) | (sh.ended ? WF_FINISHING : 0u);
-                w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
-                w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
-                w.A2[id] = make_float4(P.bx, P.by, P.bz, __uint_as_float(m2));
-                w.A3[id] = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist);
-                if (push_sh) {
-                    w.A4[id] = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f);
-                    w.A5[id] = make_float4(sh.sdx, sh.sdy, sh.sdz, 0.f);
+                    w.A2[id] = make_float4(P.bx, P.by, P.bz, __uint_as_float(m2));
+                    w.A3[id] = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist);
+                    if (push_sh) {
+                        w.A4[id] = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f);
+                        w.A5[id] = make_float4(sh.sdx, sh.sdy, sh.sdz, 0.f);
+                    }
                 }
             }
+            // ---- append to the workgroup's LDS buffers: one LDS atomic per wave and buffer
+            {
+                const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
+                unsigned br = 0, bp = 0;
+                if (lane == 0) {
+                    if (me | ms) br = atomicAdd(&ctl[0], (unsigned)(__popcll(me) + __popcll(ms)));
+                    if (mp) bp = atomicAdd(&ctl[1], (unsigned)__popcll(mp));
+                }
+                br = __builtin_amdgcn_readfirstlane(br);
+                bp = __builtin_amdgcn_readfirstlane(bp);
+                if (push_ext) out_rays[br + __popcll(me & lt_mask)] = id * 2u;
+                if (push_sh) out_rays[br + __popcll(me) + __popcll(ms & lt_mask)] = id * 2u + 1u;
+                if (push_ext || push_sh) out_paths[bp + __popcll(mp & lt_mask)] = id;
+            }
         }
-        const unsigned ie = wf_reserve(cnt_next + 0, push_ext);
-        const unsigned ih = wf_reserve(cnt_next + 0, push_sh);
-        const unsigned is = wf_reserve(cnt_next + 1, push_ext || push_sh);
-        if (push_ext) qt_next[ie] = id * 2u;
-        if (push_sh) qt_next[ih] = id * 2u + 1u;
-        if (push_ext || push_sh) qs_next[is] = id;
+        // ---- flush the super-block's appends: two global atomics, coalesced copies
+        __syncthreads();
+        const unsigned nr = ctl[0], np = ctl[1];
+        if (threadIdx.x == 0) {
+            ctl[3] = nr ? atomicAdd(cnt_next + kCntRays, nr) : 0u;
+            ctl[4] = np ? atomicAdd(cnt_next + kCntPaths, np) : 0u;
+        }
+        __syncthreads();
+        const unsigned gr = ctl[3], gp = ctl[4];
+        for (unsigned k = threadIdx.x; k < nr; k += kBlockThreads) qt_next[gr + k] = out_rays[k];
+        for (unsigned k = threadIdx.x; k < np; k += kBlockThreads) qs_next[gp + k] = out_paths[k];
+        __syncthreads();
+        if (threadIdx.x == 0) { ctl[0] = 0u; ctl[1] = 0u; }
+        // (the __syncthreads after the next block fetch orders this reset before any append)
     }
 }
 

@@ -6,7 +6,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "headline"
 sc, pr = scenes.CONFIGS[cfg]()
 d = device.Device(); d.upload_scene(sc); d.resize(pr["width"], pr["height"]); d.count_rays(True)
 L = device.lib()
-for v in (0, 1):
+for v in (1, 2):
     d.set_variant(v); d.reset_stats()
     out = (C.c_ulonglong * 8)(); L.glrtx_debug_trav_stats(out)
     d.render(dict(pr, seed=host.frame_seed(0))); d.sync()
