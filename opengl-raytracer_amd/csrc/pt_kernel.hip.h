@@ -170,12 +170,13 @@ DEV bool box_pass(float4 lo, float4 hi, float ox, float oy, float oz, float ix, 
 // may still shrink; the entry keeps its entry distance t0 and is re-checked against the current tHit
 // when popped, which reproduces the reference's visit set exactly (its test at pop time is
 // t1 >= t0 -- independent of tHit -- and t0 <= tHit).  Leaf children are never box-tested, as in the
-// reference (:310-331).  The per-lane stack lives in LDS: entry e of lane l at
-// stack[(2e + {0,1}) * kBlockThreads + l] (bank = l mod 32: conflict-free ds_read/write_b32).
+// reference (:310-331).  The per-lane stack lives in LDS as 8-byte {ref, t0} entries, entry e of lane l
+// at byte (e * kBlockThreads + l) * 8: one conflict-free ds_read/write_b64 per pop/push.
 #ifdef GLRTX_TRAV_STATS
 // Diagnostic build only (-DGLRTX_TRAV_STATS): [0] wave loop iterations, [1] active lanes summed over
 // iterations, [2] lanes on the fork path, [3] lanes on the leaf path, [4] iterations with both paths live
 __device__ unsigned long long g_trav_stats[8];
+__device__ unsigned long long g_trav_hist[16];  // rays by ceil(log2(iterations))
 DEV void trav_stats_iter(int cur) {
     const unsigned long long m = __ballot(1), mf = __ballot(cur >= 0);
     if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
@@ -195,6 +196,9 @@ struct Trav {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz;
     Hit h;
     int cur, sp;
+#ifdef GLRTX_TRAV_STATS
+    unsigned iters;
+#endif
 };
 
 // Returns false if the ray is finished before the first step (root box missed).
@@ -204,6 +208,9 @@ DEV bool trav_init(const DevScene &sc, Trav &T, float ox, float oy, float oz, fl
     T.h.t = PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
     T.sp = 0;
     T.cur = sc.root_ref;
+#ifdef GLRTX_TRAV_STATS
+    T.iters = 0;
+#endif
     if (T.cur >= 0) {  // the root fork's own box
         float t0;
         if (!box_pass(sc.root_lo, sc.root_hi, ox, oy, oz, T.ix, T.iy, T.iz, T.h.t, t0)) return false;
@@ -217,6 +224,10 @@ template <bool CLOSEST>
 DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
 #ifdef GLRTX_TRAV_STATS
     trav_stats_iter(T.cur);
+    T.iters++;
+#define TS_DONE atomicAdd(&g_trav_hist[T.iters <= 1 ? 0 : (32 - __clz((int)T.iters - 1)) > 15 ? 15 : (32 - __clz((int)T.iters - 1))], 1ull)
+#else
+#define TS_DONE
 #endif
     const int cur = T.cur;
     if (cur >= 0) {
@@ -228,8 +239,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
         const bool pr = r != REF_ABSENT && (r < 0 || box_pass(R0, R1, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0r));
         if (pr) {
             if (pl) {
-                stack[(2 * T.sp) * kBlockThreads] = l;
-                stack[(2 * T.sp + 1) * kBlockThreads] = __float_as_int(t0l);
+                reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = make_int2(l, __float_as_int(t0l));  // one ds_write_b64
                 T.sp++;
             }
             T.cur = r;
@@ -243,14 +253,16 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
         // leaf :310-331 with intersect(Ray, Triangle) :226-257
         const int t = ~cur;
         const float4 T0 = sc.tris[3 * t], T1 = sc.tris[3 * t + 1], T2 = sc.tris[3 * t + 2];
+        // o - v0 is formed before the determinant test so that all three loads are issued together
+        // (otherwise the compiler sinks the v0 load behind the branch: a second dependent round trip)
+        const float tx = T.ox - T0.x, ty = T.oy - T0.y, tz = T.oz - T0.z;
         const float px = T.dy * T2.z - T.dz * T2.y;
         const float py = T.dz * T2.x - T.dx * T2.z;
         const float pz = T.dx * T2.y - T.dy * T2.x;
         const float det = dot3(T1.x, T1.y, T1.z, px, py, pz);
+        const float U = dot3(tx, ty, tz, px, py, pz);
         if (!(-PT_EPS < det && det < PT_EPS)) {
             const float inv = 1.0f / det;
-            const float tx = T.ox - T0.x, ty = T.oy - T0.y, tz = T.oz - T0.z;
-            const float U = dot3(tx, ty, tz, px, py, pz);
             const float u = U * inv;
             if (!(u < 0.0f || 1.0f < u)) {
                 const float qx = ty * T1.z - tz * T1.y;
@@ -273,11 +285,11 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
     }
     // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298
     for (;;) {
-        if (T.sp == 0) return true;
+        if (T.sp == 0) { TS_DONE; return true; }
         T.sp--;
-        T.cur = stack[(2 * T.sp) * kBlockThreads];
-        const float t0 = __int_as_float(stack[(2 * T.sp + 1) * kBlockThreads]);
-        if (T.h.t >= t0) return false;
+        const int2 e = reinterpret_cast<const int2 *>(stack)[T.sp * kBlockThreads];  // one ds_read_b64
+        T.cur = e.x;
+        if (T.h.t >= __int_as_float(e.y)) return false;
     }
 }
 
@@ -686,7 +698,7 @@ DEV int local_row_to_y(const KernelArgs &a, int lrow) {  // owned stripe s holds
 DEV void lds_setup(const KernelArgs &a, unsigned char *lds_raw, float4 *&lds_mats, int *&stack) {
     lds_mats = reinterpret_cast<float4 *>(lds_raw);
     const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
-    stack = reinterpret_cast<int *>(lds_raw + (size_t)mat_f4 * sizeof(float4)) + threadIdx.x;
+    stack = reinterpret_cast<int *>(lds_raw + (size_t)mat_f4 * sizeof(float4)) + 2 * threadIdx.x;  // 8-byte entries
     if (a.sc.mats_in_lds) {
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
         __syncthreads();
@@ -866,7 +878,11 @@ struct WfArgs {
     unsigned *cnt;    // per trip: [4*it + 0] rays queued, [+1] paths queued, [+2] traversal work head
     int total;        // tile-order ids: tiles8_x * tiles8_y * 64
     int tiles8_x;
+    int group, n_groups;  // this pipeline instance owns id blocks b (of kGroupBlock ids) with b % n_groups == group
+    int group_slots;      // dense queue slots of the group: its blocks * kGroupBlock
+    int refill_min;       // refill a traversal wave once this many lanes are idle
 };
+constexpr int kGroupBlock = 4096;
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
 constexpr unsigned WF_FINISHING = 1u << 29;  // the path has ended; only that shadow ray is awaited
 
@@ -907,17 +923,18 @@ DEV bool wf_start(const KernelArgs &a, Rng &rng, float fcx, float fcy, Path &P, 
 }
 
 __global__ __launch_bounds__(256) void wf_generate(const KernelArgs a, const WfArgs w) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // dense queues: one slot per tile-order id
-        w.cnt[kCntRays] = (unsigned)w.total;
-        w.cnt[kCntPaths] = (unsigned)w.total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // dense queues: one slot per id of the group's blocks
+        w.cnt[kCntRays] = (unsigned)w.group_slots;
+        w.cnt[kCntPaths] = (unsigned)w.group_slots;
     }
-    for (int id = blockIdx.x * 256 + threadIdx.x; id < w.total; id += gridDim.x * 256) {
+    for (int slot = blockIdx.x * 256 + threadIdx.x; slot < w.group_slots; slot += gridDim.x * 256) {
+        const int id = ((slot / kGroupBlock) * w.n_groups + w.group) * kGroupBlock + slot % kGroupBlock;
         int lx, lrow;
         bool go = false;
         Rng rng = {0.f, 0.f, a.seed_x, a.seed_y};
         Path P;
         unsigned sample = 0;
-        if (wf_pixel(a, w, id, lx, lrow)) {
+        if (id < w.total && wf_pixel(a, w, id, lx, lrow)) {
             const int gy = local_row_to_y(a, lrow);
             const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
             rng.x = fcx / (float)a.width; rng.y = fcy / (float)a.height;  // :567
@@ -929,15 +946,15 @@ __global__ __launch_bounds__(256) void wf_generate(const KernelArgs a, const WfA
             w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
             w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        w.qT[0][id] = go ? (unsigned)id * 2u : WF_INVALID;
-        w.qS[0][id] = go ? (unsigned)id : WF_INVALID;
+        w.qT[0][slot] = go ? (unsigned)id * 2u : WF_INVALID;
+        w.qS[0][slot] = go ? (unsigned)id : WF_INVALID;
     }
 }
 
 template <bool COUNT_RAYS>
 __global__ __launch_bounds__(kBlockThreads) void wf_traverse(const KernelArgs a, const WfArgs w, int it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    int *stack = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
+    int *stack = reinterpret_cast<int *>(lds_raw) + 2 * threadIdx.x;  // 8-byte entries, lane-interleaved
     const unsigned *q = w.qT[it & 1];
     unsigned *cnt = w.cnt + (size_t)kCntStride * it;
     const int n_rays = (int)cnt[kCntRays];
@@ -959,7 +976,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_traverse(const KernelArgs a,
     for (;;) {
         // ---- refill idle lanes with queued rays, once enough of them are idle
         unsigned long long idle = __ballot(!active);
-        if (__popcll(idle) >= kRefillMin || idle == ~0ull) {
+        if (__popcll(idle) >= w.refill_min || idle == ~0ull) {
             while (idle != 0ull && !exhausted) {
                 if (chunk_next >= chunk_end) {
                     const int lo = shard * per, hi = lo + per < n_rays ? lo + per : n_rays;

@@ -217,18 +217,19 @@ INL float pt_tri(v3 o, v3 d, v3 v0, v3 v1, v3 v2, v3 n0, v3 n1, v3 n2, int want_
 }
 
 /* ------------------------------------------- intersect(Ray, Intersection) :276-335 */
-typedef struct { v3 norm; float tHit; int mtrl; int hit; } pt_isect;
+typedef struct { v3 norm; float tHit; int mtrl; int hit; int tri; unsigned visits; } pt_isect;
 
 INL void pt_traverse(const pt_scene *sc, v3 o, v3 d, int want_normal, pt_isect *is) {
     int stack[64];
     int pos = 0;
     stack[0] = 0;
-    is->tHit = PT_INFTY; is->norm.x = is->norm.y = is->norm.z = 0.f; is->mtrl = 0; is->hit = 0;
+    is->tHit = PT_INFTY; is->norm.x = is->norm.y = is->norm.z = 0.f; is->mtrl = 0; is->hit = 0; is->tri = -1; is->visits = 0;
     const int n_bvh_texels = sc->n_nodes * 3, n_vert_texels = sc->n_vert * 5;
     float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z; /* :260, recomputed per node there */
     while (pos >= 0) {
         int slot = pos;
         int node = stack[slot];
+        is->visits++;
         pos -= 1;
         v3 bmin = fetch3(sc->bvh, n_bvh_texels, node * 3 + 0);
         v3 bmax = fetch3(sc->bvh, n_bvh_texels, node * 3 + 1);
@@ -265,11 +266,84 @@ INL void pt_traverse(const pt_scene *sc, v3 o, v3 d, int want_normal, pt_isect *
                 is->norm = n;
                 is->mtrl = (int)tr[3];
                 is->hit = 1;
+                is->tri = index;
             }
             is->tHit = FMIN(is->tHit, dist);
         }
     }
 }
+
+#ifdef PT_ORDERED_EXPERIMENT
+/* EXPERIMENT (not part of the oracle proper): a near-child-first traversal with the reference's
+ * DFS leaf rank as tie-break, run next to the reference-order traversal to count (a) disagreements
+ * in (tri, t) and (b) node visits of both orders.  Build: gcc -DPT_ORDERED_EXPERIMENT ... */
+#include <stdio.h>
+#include <stdlib.h>
+unsigned long long g_exp[16]; /* 0 rays, 1 mismatches, 2 ref visits, 3 ord visits, 4 ref max, 5 ord max */
+static int *g_rank = NULL;    /* triangle -> position in the reference's right-first DFS leaf order */
+static void exp_build_rank(const pt_scene *sc) {
+    g_rank = (int *)malloc(sizeof(int) * (size_t)(sc->n_tri + 1));
+    int *st = (int *)malloc(sizeof(int) * (size_t)(sc->n_nodes + 2));
+    int sp = 0, r = 0;
+    st[sp++] = 0;
+    while (sp) {
+        int n = st[--sp];
+        const float *c = sc->bvh + 9 * (size_t)n + 6;
+        if (c[2] < 0.0f) { if (c[0] >= 0) st[sp++] = (int)c[0]; if (c[1] >= 0) st[sp++] = (int)c[1]; }
+        else g_rank[(int)c[2]] = r++;
+    }
+    free(st);
+}
+static float exp_box(const pt_scene *sc, int node, v3 o, float ix, float iy, float iz, float tHit, int *pass) {
+    const float *b = sc->bvh + 9 * (size_t)node;
+    float fx = (b[3] - o.x) * ix, fy = (b[4] - o.y) * iy, fz = (b[5] - o.z) * iz;
+    float nx = (b[0] - o.x) * ix, ny = (b[1] - o.y) * iy, nz = (b[2] - o.z) * iz;
+    float tmaxx = FMAX(fx, nx), tmaxy = FMAX(fy, ny), tmaxz = FMAX(fz, nz);
+    float tminx = FMIN(fx, nx), tminy = FMIN(fy, ny), tminz = FMIN(fz, nz);
+    float t1 = FMIN(tmaxy, tmaxz); t1 = FMIN(tmaxx, t1);
+    float t0 = FMAX(tminy, tminz); t0 = FMAX(tminx, t0);
+    *pass = FMIN(t1, tHit) >= t0;
+    return t0;
+}
+static void exp_ordered(const pt_scene *sc, v3 o, v3 d, float *t_out, int *tri_out, unsigned *visits) {
+    struct { int node; float t0; } st[128];
+    int sp = 0, best = -1;
+    float tHit = PT_INFTY, ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const int nvt = sc->n_vert * 5;
+    int pass; float t0 = exp_box(sc, 0, o, ix, iy, iz, tHit, &pass);
+    const float *c0 = sc->bvh + 6;
+    if (c0[2] >= 0.0f) { pass = 1; t0 = -PT_INFTY; }
+    if (pass) { st[sp].node = 0; st[sp].t0 = t0; sp++; }
+    while (sp) {
+        sp--;
+        int n = st[sp].node;
+        if (!(tHit >= st[sp].t0)) continue;
+        (*visits)++;
+        const float *c = sc->bvh + 9 * (size_t)n + 6;
+        if (c[2] < 0.0f) {
+            int kid[2] = {(int)c[0], (int)c[1]}, ok[2] = {0, 0}; float kt[2] = {-PT_INFTY, -PT_INFTY};
+            for (int k = 0; k < 2; k++) {
+                if (!(c[k] >= 0.0f)) continue;
+                if (sc->bvh[9 * (size_t)kid[k] + 8] >= 0.0f) ok[k] = 1; /* leaf child: never box-tested */
+                else kt[k] = exp_box(sc, kid[k], o, ix, iy, iz, tHit, &ok[k]);
+            }
+            /* near child on top of the stack */
+            int first = (ok[0] && ok[1]) ? (kt[0] <= kt[1] ? 0 : 1) : (ok[0] ? 0 : 1);
+            int second = 1 - first;
+            if (ok[second]) { st[sp].node = kid[second]; st[sp].t0 = kt[second]; sp++; }
+            if (ok[first]) { st[sp].node = kid[first]; st[sp].t0 = kt[first]; sp++; }
+        } else {
+            int index = (int)c[2]; float tr[4]; fetch4(sc->tri, sc->n_tri, index, tr);
+            int i0 = (int)tr[0] * 5, i1 = (int)tr[1] * 5, i2 = (int)tr[2] * 5;
+            v3 v0 = fetch3(sc->vert, nvt, i0), v1 = fetch3(sc->vert, nvt, i1), v2 = fetch3(sc->vert, nvt, i2), z = {0, 0, 0}, n3;
+            float dist = pt_tri(o, d, v0, v1, v2, z, z, z, 0, &n3);
+            if (dist < tHit || (dist == tHit && best >= 0 && dist < PT_INFTY && g_rank[index] < g_rank[best])) best = index;
+            tHit = FMIN(tHit, dist);
+        }
+    }
+    *t_out = tHit; *tri_out = best;
+}
+#endif
 
 /* fresnelConductor :158-178; association order as compiled [order] */
 INL float pt_fresnel1(float c2, float s2, float cosI, float eta, float k) {
@@ -293,6 +367,26 @@ INL float pt_ggx(float hx, float hy, float hz, float ax, float ay) {
     return 1.0f / ((PT_PI * ax) * ((ay * l2) * l2));
 }
 
+
+#ifdef PT_ORDERED_EXPERIMENT
+#define EXP_CHECK(IS, O, D)                                                                         \
+    do {                                                                                            \
+        float t2_; int tri2_; unsigned v2_ = 0;                                                     \
+        exp_ordered(sc, O, D, &t2_, &tri2_, &v2_);                                                  \
+        int bad_ = !((t2_ == (IS).tHit || (t2_ != t2_ && (IS).tHit != (IS).tHit)) && tri2_ == (IS).tri); \
+        _Pragma("omp atomic") g_exp[0] += 1;                                                        \
+        if (bad_) { _Pragma("omp atomic") g_exp[1] += 1; }                                          \
+        _Pragma("omp atomic") g_exp[2] += (IS).visits;                                              \
+        _Pragma("omp atomic") g_exp[3] += v2_;                                                      \
+        if ((IS).visits > g_exp[4]) g_exp[4] = (IS).visits;                                         \
+        if (v2_ > g_exp[5]) g_exp[5] = v2_;                                                         \
+        if ((IS).visits > 128) { _Pragma("omp atomic") g_exp[6] += 1; }                             \
+        if (v2_ > 128) { _Pragma("omp atomic") g_exp[7] += 1; }                                     \
+    } while (0)
+#else
+#define EXP_CHECK(IS, O, D) ((void)0)
+#endif
+
 /* radiance() :409-559 with sampleDirect() :337-403 inlined */
 INL v3 pt_radiance(const pt_scene *sc, const pt_params *pr, pt_rng *rng, v3 o, v3 d, uint64_t *rays) {
     v3 L = {0.f, 0.f, 0.f}, beta = {1.f, 1.f, 1.f};
@@ -304,6 +398,7 @@ INL v3 pt_radiance(const pt_scene *sc, const pt_params *pr, pt_rng *rng, v3 o, v
         pt_isect is;
         pt_traverse(sc, o, d, 1, &is);
         (*rays)++;
+        EXP_CHECK(is, o, d);
         const v3 n = is.norm;
         TRACE("depth %d hit %d t %.9g mtrl %d n %.9g %.9g %.9g o %.9g %.9g %.9g d %.9g %.9g %.9g\n", depth, is.hit,
               is.tHit, is.mtrl, n.x, n.y, n.z, o.x, o.y, o.z, d.x, d.y, d.z);
@@ -453,6 +548,7 @@ INL v3 pt_radiance(const pt_scene *sc, const pt_params *pr, pt_rng *rng, v3 o, v
                 pt_isect sh;
                 pt_traverse(sc, so, dir, 0, &sh);
                 (*rays)++;
+                EXP_CHECK(sh, so, dir);
                 float dist = sqrtf(dd);
                 TRACE("  nee lid %d ua %.9g ub %.9g hit %d dist %.9g tS %.9g diff %.9g\n", lid, ua, ub, sh.hit, dist,
                       sh.tHit, fabsf(dist - sh.tHit));
@@ -614,6 +710,9 @@ static uint64_t pt_render_rows(const pt_scene *sc, const pt_params *pr, float *a
  * Returns the number of rays traced (executions of intersect(), :276). */
 uint64_t pt_oracle_render(const pt_scene *sc, const pt_params *pr, float *accum, size_t pitch_bytes,
                           int y0, int y1, int threads) {
+#ifdef PT_ORDERED_EXPERIMENT
+    exp_build_rank(sc);
+#endif
     return pt_render_rows(sc, pr, accum, pitch_bytes / sizeof(float), y0, y1, threads);
 }
 
@@ -627,6 +726,10 @@ void pt_oracle_rand_stream(float W, float H, int px, int py, float sx, float sy,
 void pt_oracle_sincos(const float *x, int n, float *s, float *c) {
     for (int i = 0; i < n; i++) { s[i] = pt_sin(x[i]); c[i] = pt_cos(x[i]); }
 }
+
+#ifdef PT_ORDERED_EXPERIMENT
+void pt_oracle_exp_stats(unsigned long long *out) { for (int i = 0; i < 16; i++) out[i] = g_exp[i]; }
+#endif
 
 int pt_oracle_max_threads(void) {
 #ifdef _OPENMP
