@@ -119,10 +119,10 @@ int glrtx_bind_accum(glrtx_ctx *ctx, void *device_ptr, size_t pitch_bytes);
 /* Optional: launch on a caller-owned hipStream_t (passed as void*); NULL restores the ctx stream. */
 int glrtx_set_stream(glrtx_ctx *ctx, void *hip_stream);
 
-/* Kernel variant (tuning knob, no reference counterpart): 2 = wavefront pipeline (separate traversal and
- * shading kernels over device-resident ray/path queues; default), 1 = persistent megakernel with path
- * regeneration, 0 = megakernel, one 16x16 tile per workgroup.  All produce bit-identical images.
- * The default can also be set with the environment variable GLRTX_VARIANT. */
+/* Kernel variant (tuning knob, no reference counterpart): 2 = workgroup-local wavefront (default: one
+ * persistent launch; each workgroup runs traverse/shade trips over its own pixel blocks), 1 = persistent
+ * megakernel with path regeneration, 0 = megakernel, one 16x16 tile per workgroup.  All three produce
+ * bit-identical images.  The default can also be set with the environment variable GLRTX_VARIANT. */
 int glrtx_set_variant(glrtx_ctx *ctx, int variant);
 
 /* Enable/disable per-launch ray counting (one atomic per wavefront); default off. */

@@ -40,14 +40,8 @@ struct glrtx_ctx {
     std::string err;
 
     DevBuf forks, tris, nrms, mats, lights, accum_own, counter, rgba8, work;
-    static constexpr int kMaxGroups = 8;
-    DevBuf wfA[6], wfH, wfHS, wfQT[kMaxGroups][2], wfQS[kMaxGroups][2], wfCnt[kMaxGroups];  // wavefront pipeline state (variant 2)
-    hipStream_t wfStream[kMaxGroups] = {};
-    hipEvent_t wfFork = nullptr, wfJoin[kMaxGroups] = {};
-    int wf_groups = 1;           // independent pipeline instances overlapped on separate streams
-    int wf_total = 0, wf_cnt_trips = 0;
-    uint64_t wf_rays = 0;        // rays counted by wavefront launches (host-side sum of queue lengths)
-    int variant = 2;          // 0 = tile kernel, 1 = persistent kernel with path regeneration, 2 = wavefront pipeline
+    DevBuf wfA[6], wfH, wfHS, wfQ;  // wavefront path state + per-workgroup queues (variant 2)
+    int variant = 2;          // 0 = tile megakernel, 1 = persistent megakernel with path regeneration, 2 = workgroup-local wavefront
     int n_cu = 256;
     int resident_wg[2] = {0, 0};  // persistent grid size per COUNT_RAYS instantiation (0 = not yet queried)
     DevScene sc{};
@@ -299,84 +293,46 @@ int ensure(glrtx_ctx *c, DevBuf &b, size_t bytes) {
     return GLRTX_OK;
 }
 
-// Variant 2: generate, then n_samples*(max_depth+1) trips of {traverse, shade}.  The image's path ids
-// are dealt in blocks to `wf_groups` independent pipeline instances, each on its own stream: a trip
-// ends with a few long rays (up to ~500 dependent node visits), and the other instances' kernels fill
-// the GPU while one instance waits for its stragglers.  Queue lengths live on the device, so every
-// kernel is launched with a fixed grid.
-int launch_wavefront(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
+// Variant 2: one persistent launch; every workgroup runs the wavefront trips of its own pixel blocks.
+int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
+    (void)p;
     const int tiles8_x = (c->width + 7) / 8, tiles8_y = (c->owned_rows + 7) / 8;
     const size_t total = (size_t)tiles8_x * tiles8_y * 64;
-    if (total * 2 + 2 * (size_t)kGroupBlock * glrtx_ctx::kMaxGroups >= (size_t)INT32_MAX)
-        return fail(c, GLRTX_EINVAL, "image too large for the wavefront variant");
-    const long long trips_ll = (long long)p->n_samples * ((long long)p->max_depth + 1);
-    if (trips_ll > 100000) return fail(c, GLRTX_EINVAL, "n_samples * (max_depth + 1) too large for the wavefront variant");
-    const int trips = (int)trips_ll;
-    const int n_blocks = (int)((total + kGroupBlock - 1) / kGroupBlock);
-    const int G = std::max(1, std::min(c->wf_groups, n_blocks));
+    if (total * 2 >= (size_t)INT32_MAX) return fail(c, GLRTX_EINVAL, "image too large for the wgwf variant");
     int rc;
     for (auto &b : c->wfA) if ((rc = ensure(c, b, total * sizeof(float4)))) return rc;
     if ((rc = ensure(c, c->wfH, total * sizeof(float4)))) return rc;
     if ((rc = ensure(c, c->wfHS, total * sizeof(float2)))) return rc;
-    const size_t cnt_bytes = (size_t)(trips + 2) * kCntStride * sizeof(unsigned);
+    WfArgs w;
+    std::memset(&w, 0, sizeof w);
+    w.A0 = (float4 *)c->wfA[0].p; w.A1 = (float4 *)c->wfA[1].p; w.A2 = (float4 *)c->wfA[2].p;
+    w.A3 = (float4 *)c->wfA[3].p; w.A4 = (float4 *)c->wfA[4].p; w.A5 = (float4 *)c->wfA[5].p;
+    w.H = (float4 *)c->wfH.p; w.HS = (float2 *)c->wfHS.p;
+    w.total = (int)total;
+    w.tiles8_x = tiles8_x;
+    w.refill_min = kRefillMin;
+    if (const char *v = std::getenv("GLRTX_REFILL_MIN")) w.refill_min = std::max(1, std::min(64, std::atoi(v)));
 
-    const int lds_trav = 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int);
-    const int lds_shade = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + (3 * kShadeBlock + 8) * (int)sizeof(unsigned);
-    if (lds_trav > 160 * 1024) return fail(c, GLRTX_EDEVICE, "traversal kernel needs %d B of LDS", lds_trav);
-    if (lds_trav > 64 * 1024) {
-        HIP_TRY(c, hipFuncSetAttribute((const void *)wf_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_trav));
-        HIP_TRY(c, hipFuncSetAttribute((const void *)wf_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_trav));
+    const int lds = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
+                    16 * (int)sizeof(unsigned);
+    if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
+    const int ci = c->count_rays ? 1 : 0;
+    if (lds > 64 * 1024) {
+        HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_wgwf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_wgwf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
-    int per_cu = 0, per_cu_shade = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_traverse<false>, kBlockThreads, lds_trav));
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, wf_shade, kBlockThreads, lds_shade));
+    int per_cu = 0;
+    if (ci) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_wgwf<true>, kBlockThreads, lds));
+    else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_wgwf<false>, kBlockThreads, lds));
     if (per_cu < 1) per_cu = 1;
-    if (per_cu_shade < 1) per_cu_shade = 1;
-    if (const char *v = std::getenv("GLRTX_TRAV_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));
-
-    if (!c->wfFork) HIP_TRY(c, hipEventCreateWithFlags(&c->wfFork, hipEventDisableTiming));
+    const int n_blocks = (int)((total + kWgPaths - 1) / kWgPaths);
+    const int grid = std::max(1, std::min(per_cu * c->n_cu, n_blocks));
+    if ((rc = ensure(c, c->wfQ, (size_t)grid * 6 * kWgPaths * sizeof(unsigned)))) return rc;  // per-workgroup queues
+    HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(c, hipEventRecord(c->wfFork, c->stream));
-    for (int g = 0; g < G; g++) {
-        if (!c->wfStream[g]) HIP_TRY(c, hipStreamCreateWithFlags(&c->wfStream[g], hipStreamNonBlocking));
-        if (!c->wfJoin[g]) HIP_TRY(c, hipEventCreateWithFlags(&c->wfJoin[g], hipEventDisableTiming));
-        hipStream_t st = c->wfStream[g];
-        const int my_blocks = (n_blocks - g + G - 1) / G;
-        const size_t slots = (size_t)my_blocks * kGroupBlock;
-        for (int k = 0; k < 2; k++) {
-            if ((rc = ensure(c, c->wfQT[g][k], 2 * slots * sizeof(unsigned)))) return rc;
-            if ((rc = ensure(c, c->wfQS[g][k], slots * sizeof(unsigned)))) return rc;
-        }
-        if ((rc = ensure(c, c->wfCnt[g], cnt_bytes))) return rc;
-
-        WfArgs w;
-        w.A0 = (float4 *)c->wfA[0].p; w.A1 = (float4 *)c->wfA[1].p; w.A2 = (float4 *)c->wfA[2].p;
-        w.A3 = (float4 *)c->wfA[3].p; w.A4 = (float4 *)c->wfA[4].p; w.A5 = (float4 *)c->wfA[5].p;
-        w.H = (float4 *)c->wfH.p; w.HS = (float2 *)c->wfHS.p;
-        for (int k = 0; k < 2; k++) { w.qT[k] = (unsigned *)c->wfQT[g][k].p; w.qS[k] = (unsigned *)c->wfQS[g][k].p; }
-        w.cnt = (unsigned *)c->wfCnt[g].p;
-        w.total = (int)total;
-        w.tiles8_x = tiles8_x;
-        w.group = g; w.n_groups = G; w.group_slots = (int)slots;
-        w.refill_min = kRefillMin;
-        if (const char *v = std::getenv("GLRTX_REFILL_MIN")) w.refill_min = std::max(1, std::min(64, std::atoi(v)));
-
-        const int grid_trav = std::max(1, std::min(per_cu * c->n_cu, (int)((2 * slots + kRayChunk * 4 - 1) / (kRayChunk * 4))));
-        const int grid_gen = std::max(1, std::min((int)((slots + 255) / 256), 8 * c->n_cu));
-        const int grid_shade = std::max(1, std::min(per_cu_shade * c->n_cu, (int)((slots + kShadeBlock - 1) / kShadeBlock)));
-
-        HIP_TRY(c, hipStreamWaitEvent(st, c->wfFork, 0));
-        HIP_TRY(c, hipMemsetAsync(c->wfCnt[g].p, 0, cnt_bytes, st));
-        hipLaunchKernelGGL(wf_generate, dim3(grid_gen), dim3(256), 0, st, a, w);
-        for (int it = 0; it < trips; it++) {
-            if (c->count_rays) hipLaunchKernelGGL(wf_traverse<true>, dim3(grid_trav), dim3(kBlockThreads), lds_trav, st, a, w, it);
-            else hipLaunchKernelGGL(wf_traverse<false>, dim3(grid_trav), dim3(kBlockThreads), lds_trav, st, a, w, it);
-            hipLaunchKernelGGL(wf_shade, dim3(grid_shade), dim3(kBlockThreads), lds_shade, st, a, w, it);
-        }
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(c->wfJoin[g], st));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->wfJoin[g], 0));
-    }
+    if (ci) hipLaunchKernelGGL(pt_render_wgwf<true>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (unsigned *)c->wfQ.p);
+    else hipLaunchKernelGGL(pt_render_wgwf<false>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (unsigned *)c->wfQ.p);
+    HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->launch_pending = true;
     c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples;
@@ -422,7 +378,6 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
     }
     c->stream = c->own_stream;
     c->n_cu = prop.multiProcessorCount;
-    if (const char *v = std::getenv("GLRTX_WF_GROUPS")) { const int x = std::atoi(v); if (x >= 1 && x <= glrtx_ctx::kMaxGroups) c->wf_groups = x; }
     if (const char *v = std::getenv("GLRTX_VARIANT")) { const int x = std::atoi(v); if (x >= 0 && x <= 2) c->variant = x; }
     *out = c;
     return GLRTX_OK;
@@ -435,14 +390,7 @@ void glrtx_destroy(glrtx_ctx *c) {
     dev_free(c->forks); dev_free(c->tris); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights);
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
     for (auto &b : c->wfA) dev_free(b);
-    dev_free(c->wfH); dev_free(c->wfHS);
-    for (int g = 0; g < glrtx_ctx::kMaxGroups; g++) {
-        dev_free(c->wfCnt[g]);
-        for (int k = 0; k < 2; k++) { dev_free(c->wfQT[g][k]); dev_free(c->wfQS[g][k]); }
-        if (c->wfStream[g]) (void)hipStreamDestroy(c->wfStream[g]);
-        if (c->wfJoin[g]) (void)hipEventDestroy(c->wfJoin[g]);
-    }
-    if (c->wfFork) (void)hipEventDestroy(c->wfFork);
+    dev_free(c->wfH); dev_free(c->wfHS); dev_free(c->wfQ);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->tm0) (void)hipEventDestroy(c->tm0);
@@ -619,7 +567,7 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     if ((size_t)a.pitch_f4 * (size_t)c->owned_rows >= (size_t)INT32_MAX)
         return fail(c, GLRTX_EINVAL, "accumulator too large for 32-bit pixel offsets");
 
-    if (c->variant == 2) return launch_wavefront(c, a, p);
+    if (c->variant == 2) return launch_wgwf(c, a, p);
     if (c->variant == 1) {
         // persistent kernel: grid = what is resident at once (occupancy x CUs), capped by the work available
         const int ci = c->count_rays ? 1 : 0;
@@ -712,7 +660,7 @@ int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
     if (!c || !out) return GLRTX_EINVAL;
     *out = c->st;
     unsigned long long r = 0;
-    if (c->counter.p && hipMemcpy(&r, c->counter.p, sizeof r, hipMemcpyDeviceToHost) == hipSuccess) out->rays = r + c->wf_rays;
+    if (c->counter.p && hipMemcpy(&r, c->counter.p, sizeof r, hipMemcpyDeviceToHost) == hipSuccess) out->rays = r;
     return GLRTX_OK;
 }
 
@@ -720,7 +668,6 @@ int glrtx_reset_stats(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
     if (int rc = glrtx_sync(c)) return rc;
     HIP_TRY(c, hipMemset(c->counter.p, 0, sizeof(unsigned long long)));
-    c->wf_rays = 0;
     c->st.rays = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_ms_total = 0.0; c->st.kernel_ms_last = 0.f;
     return GLRTX_OK;
 }

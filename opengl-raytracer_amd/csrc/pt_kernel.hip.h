@@ -850,20 +850,19 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
     flush_rays<COUNT_RAYS>(a, rays);
 }
 
-// ------------------------------------------------------------------------------------------ wavefront pipeline
-// Variant C ("wavefront"): the depth loop is cut at its two traversals.  Per frame:
-//     wf_generate                      camera rays of sample 0 for every owned pixel
-//     repeat  n_samples*(u_maxDepth+1) times:
-//         wf_traverse(it)              all rays queued for this trip: the paths' next rays AND the shadow
-//                                      rays of the previous bounce (both are closest-hit queries, :363)
-//         wf_shade(it)                 per live path: resolve the pending shadow ray (:367), then shade_hit()
-//                                      on the new hit, queue next + shadow ray; finished paths add their
-//                                      sample to the accumulator and start the pixel's next sample
-// wf_traverse is a small-register kernel whose lanes pull RAYS from the queue one at a time (a lane
-// whose ray is finished takes the next queued ray), so SIMD lanes stay full although traversal length
-// varies 10x between rays; wf_shade runs on a compacted list of live paths.  Path state lives in HBM
-// as float4 SoA, indexed by the pixel's tile-order id.  Per-path arithmetic, RNG call order and the
-// order in which samples are added to a pixel are exactly those of the megakernels: bit-identical.
+// ------------------------------------------------------------------------------------------ wavefront formulation
+// The depth loop cut at its two traversals.  A "trip" is: traverse every queued ray -- the paths'
+// next rays AND the shadow rays of the previous bounce (both are closest-hit queries, :363) -- then,
+// per live path, resolve the pending shadow ray (:367), run shade_hit() on the new hit and queue the
+// next + shadow ray; finished paths add their sample to the accumulator and start the pixel's next
+// sample.  The traverse phase pulls RAYS one at a time (a lane whose ray is finished takes the next
+// queued ray), so SIMD lanes stay full although traversal length varies 10x between rays; the shade
+// phase runs on a compacted list of live paths.  Path state lives in HBM as float4 SoA indexed by
+// the pixel's tile-order id.  Per-path arithmetic, RNG call order and the order in which samples
+// are added to a pixel are exactly those of the megakernels: results are bit-identical.
+// (A device-wide version of this pipeline -- one traverse and one shade kernel per trip over global
+// queues -- was built and measured first: 5.3 ms per headline frame, of which ~3.4 ms was nine
+// device-wide waits for each trip's longest ray.  The workgroup-local form below replaced it.)
 struct WfArgs {
     float4 *A0;  // {next ray origin (= shadow ray origin), rng.x}
     float4 *A1;  // {next ray direction, rng.y}
@@ -873,18 +872,14 @@ struct WfArgs {
     float4 *A5;  // {shadow ray direction, -}
     float4 *H;   // closest hit of the path's ray {t, tri, u, v}
     float2 *HS;  // closest hit of the shadow ray {t, tri}
-    unsigned *qT[2];  // ray queues (ping-pong): id*2 + kind (0 = path ray, 1 = shadow ray)
-    unsigned *qS[2];  // path queues (ping-pong): ids to shade after the traversal
-    unsigned *cnt;    // per trip: [4*it + 0] rays queued, [+1] paths queued, [+2] traversal work head
     int total;        // tile-order ids: tiles8_x * tiles8_y * 64
     int tiles8_x;
-    int group, n_groups;  // this pipeline instance owns id blocks b (of kGroupBlock ids) with b % n_groups == group
-    int group_slots;      // dense queue slots of the group: its blocks * kGroupBlock
-    int refill_min;       // refill a traversal wave once this many lanes are idle
+    int refill_min;   // refill a traversal wave once this many lanes are idle
 };
-constexpr int kGroupBlock = 4096;
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
 constexpr unsigned WF_FINISHING = 1u << 29;  // the path has ended; only that shadow ray is awaited
+constexpr unsigned WF_INVALID = 0xFFFFFFFFu; // queue entry to skip
+constexpr int kRefillMin = 16;               // refill a traversal wave once this many lanes are idle
 
 DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lrow) {
     const int t = id >> 6, k = id & 63;
@@ -892,20 +887,6 @@ DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lr
     lrow = (t / w.tiles8_x) * 8 + (k >> 3);
     return lx < a.width && lrow < a.owned_rows;
 }
-
-// Queue bookkeeping.  A single contended device counter sustains only ~88 atomics/us on MI355X, so
-// the queues are built to need very few of them: wf_generate writes its queue densely (slot = id,
-// out-of-image ids carry WF_INVALID), wf_shade collects the appends of 2048 paths in LDS and reserves
-// global space once per super-block, and wf_traverse pulls 256-ray chunks from 16 sharded heads.
-constexpr unsigned WF_INVALID = 0xFFFFFFFFu;  // queue entry to skip
-// Counters of one trip; every contended word sits in its own 128-byte line (atomics to one line serialise).
-constexpr int kTravShards = 16;
-constexpr int kCntLine = 32;  // unsigned words per 128-byte line
-constexpr int kCntRays = 0, kCntPaths = kCntLine, kCntShadeHead = 2 * kCntLine, kCntTravHead = 3 * kCntLine /* + shard*kCntLine */;
-constexpr int kCntStride = (3 + kTravShards) * kCntLine;  // unsigned words of counters per trip
-constexpr int kRayChunk = 256;    // rays a wavefront reserves per global atomic
-constexpr int kRefillMin = 16;    // refill a traversal wave once this many lanes are idle
-constexpr int kShadeBlock = 2048; // paths per wf_shade super-block (8 per thread)
 
 // Start the pixel's next sample(s): camera ray -> state; returns true if a ray must be traced.
 // With u_maxDepth <= 0 a sample is finished as soon as it starts (main() still draws its jitter).
@@ -922,245 +903,253 @@ DEV bool wf_start(const KernelArgs &a, Rng &rng, float fcx, float fcy, Path &P, 
     }
 }
 
-__global__ __launch_bounds__(256) void wf_generate(const KernelArgs a, const WfArgs w) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // dense queues: one slot per id of the group's blocks
-        w.cnt[kCntRays] = (unsigned)w.group_slots;
-        w.cnt[kCntPaths] = (unsigned)w.group_slots;
+// Start pixel `id` (tile-order id): seed its RNG, draw sample 0's camera ray, store the path state.
+// Returns true if a ray was queued (false: outside the image, or nothing to trace).
+DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id) {
+    int lx, lrow;
+    bool go = false;
+    Rng rng = {0.f, 0.f, a.seed_x, a.seed_y};
+    Path P;
+    unsigned sample = 0;
+    if (id < w.total && wf_pixel(a, w, id, lx, lrow)) {
+        const int gy = local_row_to_y(a, lrow);
+        const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
+        rng.x = fcx / (float)a.width; rng.y = fcy / (float)a.height;  // :567
+        go = wf_start(a, rng, fcx, fcy, P, sample, a.accum + (size_t)lrow * a.pitch_f4 + lx);
     }
-    for (int slot = blockIdx.x * 256 + threadIdx.x; slot < w.group_slots; slot += gridDim.x * 256) {
-        const int id = ((slot / kGroupBlock) * w.n_groups + w.group) * kGroupBlock + slot % kGroupBlock;
-        int lx, lrow;
-        bool go = false;
-        Rng rng = {0.f, 0.f, a.seed_x, a.seed_y};
-        Path P;
-        unsigned sample = 0;
-        if (id < w.total && wf_pixel(a, w, id, lx, lrow)) {
-            const int gy = local_row_to_y(a, lrow);
-            const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
-            rng.x = fcx / (float)a.width; rng.y = fcy / (float)a.height;  // :567
-            go = wf_start(a, rng, fcx, fcy, P, sample, a.accum + (size_t)lrow * a.pitch_f4 + lx);
+    if (go) {
+        w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
+        w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
+        w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
+        w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return go;
+}
+
+// One path of the shade stage: resolve the light sample of the previous bounce, then either close the
+// sample (and start the pixel's next one) or run shade_hit() on the new hit.  Outputs which rays to
+// queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray.
+DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, unsigned id, bool &push_ext, bool &push_sh) {
+    int lx, lrow;
+    wf_pixel(a, w, (int)id, lx, lrow);
+    const int gy = local_row_to_y(a, lrow);
+    const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
+    float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
+    const float4 s0 = w.A0[id], s1 = w.A1[id], s2 = w.A2[id], s3 = w.A3[id];
+    Rng rng = {s0.w, s1.w, a.seed_x, a.seed_y};
+    const unsigned meta = __float_as_uint(s2.w);
+    unsigned sample = (meta >> 8) & 0xFFFFFu;
+    Path P;
+    P.ox = s0.x; P.oy = s0.y; P.oz = s0.z; P.dx = s1.x; P.dy = s1.y; P.dz = s1.z;
+    P.bx = s2.x; P.by = s2.y; P.bz = s2.z;
+    P.depth = (int)(meta & 0xFFu);
+    // resolve the light sample of the previous bounce (:367, :539)
+    P.Lx = s3.x; P.Ly = s3.y; P.Lz = s3.z;
+    if (meta & WF_PENDING) {
+        const float2 hs = w.HS[id];
+        if (!nee_accepted(s3.w, hs.x, __float_as_int(hs.y) >= 0)) {
+            const float4 s4 = w.A4[id];
+            P.Lx = s4.x; P.Ly = s4.y; P.Lz = s4.z;
         }
-        if (go) {
+    }
+    bool ended = (meta & WF_FINISHING) != 0u;
+    Shade sh;
+    sh.has_shadow = false;
+    if (!ended) {
+        const float4 hh = w.H[id];
+        Hit h;
+        h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
+        shade_hit(a, lds_mats, rng, P, h, sh);
+        if (sh.ended && !sh.has_shadow) { P.Lx = sh.Lpx; P.Ly = sh.Lpy; P.Lz = sh.Lpz; }
+        ended = sh.ended && !sh.has_shadow;  // with a shadow ray in flight the sample closes next trip
+    }
+    if (ended) {
+        // radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609)
+        float4 acc = *px;
+        acc.x = acc.x + fmin_c(P.Lx, 100.0f);
+        acc.y = acc.y + fmin_c(P.Ly, 100.0f);
+        acc.z = acc.z + fmin_c(P.Lz, 100.0f);
+        acc.w = acc.w + 1.0f;
+        *px = acc;
+        sample++;
+        push_ext = wf_start(a, rng, fcx, fcy, P, sample, px);  // the pixel's next sample, if any
+        if (push_ext) {
             w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
             w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
             w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
             w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        w.qT[0][slot] = go ? (unsigned)id * 2u : WF_INVALID;
-        w.qS[0][slot] = go ? (unsigned)id : WF_INVALID;
+    } else {
+        // shade_hit ran and the path goes on and/or awaits its shadow ray
+        push_sh = sh.has_shadow;
+        push_ext = !sh.ended;
+        const unsigned m2 = (unsigned)P.depth | (sample << 8) | (push_sh ? WF_PENDING : 0u) | (sh.ended ? WF_FINISHING : 0u);
+        w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
+        w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
+        w.A2[id] = make_float4(P.bx, P.by, P.bz, __uint_as_float(m2));
+        w.A3[id] = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist);
+        if (push_sh) {
+            w.A4[id] = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f);
+            w.A5[id] = make_float4(sh.sdx, sh.sdy, sh.sdz, 0.f);
+        }
     }
 }
 
+// ------------------------------------------------------------------------------------------ workgroup-local wavefront
+// Variant D ("wgwf"): the wavefront formulation with every queue and every barrier LOCAL to a
+// workgroup.  A workgroup takes kWgPaths pixels (16 tiles of 8x8) from a global counter and runs
+// their trips itself: traverse phase (lanes pull rays from an LDS queue, refilled as they finish),
+// __syncthreads, shade phase (the workgroup's live paths, compacted), __syncthreads, ... until the
+// paths are done; then it takes the next block.  There is no device-wide barrier anywhere: a
+// workgroup waiting for its last long ray idles only itself, while the other resident workgroups are
+// at other stages -- the global pipeline of variant C loses ~300 us per trip to that wait, nine times
+// a frame.  One kernel launch per frame.  State lives in the same HBM arrays as variant C.
+#ifndef GLRTX_WG_PATHS
+#define GLRTX_WG_PATHS 1024
+#endif
+constexpr int kWgPaths = GLRTX_WG_PATHS;  // pixels per workgroup block (16 tiles of 8x8)
+#ifndef GLRTX_WGWF_WAVES
+#define GLRTX_WGWF_WAVES 4
+#endif
+
 template <bool COUNT_RAYS>
-__global__ __launch_bounds__(kBlockThreads) void wf_traverse(const KernelArgs a, const WfArgs w, int it) {
+__global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, unsigned *wg_queues) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    int *stack = reinterpret_cast<int *>(lds_raw) + 2 * threadIdx.x;  // 8-byte entries, lane-interleaved
-    const unsigned *q = w.qT[it & 1];
-    unsigned *cnt = w.cnt + (size_t)kCntStride * it;
-    const int n_rays = (int)cnt[kCntRays];
+    // LDS: materials | stack | ctl[16].  The workgroup's ray/path queues live in its private slice of a
+    // global buffer (L2-resident, read and written with unit stride).
+    float4 *lds_mats = reinterpret_cast<float4 *>(lds_raw);
+    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    unsigned char *pl = lds_raw + (size_t)mat_f4 * sizeof(float4);
+    int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
+    pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
+    unsigned *ctl = reinterpret_cast<unsigned *>(pl);            // 0: block, 1: ray head, 2..3: nRays[2], 4..5: nPaths[2]
+    unsigned *rayQ = wg_queues + (size_t)blockIdx.x * 6 * kWgPaths;  // [2][2*kWgPaths]
+    unsigned *pathQ = rayQ + 4 * kWgPaths;                            // [2][kWgPaths]
+    if (a.sc.mats_in_lds)
+        for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
+
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    // the queue is cut into kTravShards ranges, each with its own head: a wave starts on its home
-    // shard and moves to the next one when a shard runs dry
-    const int per = ((n_rays + kTravShards - 1) / kTravShards + kRayChunk - 1) / kRayChunk * kRayChunk;
-    int shard = (int)((blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)) % kTravShards);
-    int shards_left = kTravShards;
-
-    int chunk_next = 0, chunk_end = 0;  // wave-uniform
-    bool exhausted = n_rays == 0;
-    bool active = false;
-    unsigned rid = 0, rays = 0;
-    Trav T;
-    T.cur = 0; T.sp = 0;
+    const int n_blocks = (w.total + kWgPaths - 1) / kWgPaths;
+    unsigned rays = 0;
 
     for (;;) {
-        // ---- refill idle lanes with queued rays, once enough of them are idle
-        unsigned long long idle = __ballot(!active);
-        if (__popcll(idle) >= w.refill_min || idle == ~0ull) {
-            while (idle != 0ull && !exhausted) {
-                if (chunk_next >= chunk_end) {
-                    const int lo = shard * per, hi = lo + per < n_rays ? lo + per : n_rays;
-                    int base = hi;
-                    unsigned *head = cnt + kCntTravHead + shard * kCntLine;
-                    // peek before the atomic: a dry shard costs a load, not a contended read-modify-write
-                    if (lo < hi && lo + (int)__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hi) {
-                        if (lane == 0) base = lo + (int)atomicAdd(head, (unsigned)kRayChunk);
-                        base = __builtin_amdgcn_readfirstlane(base);
+        __syncthreads();  // previous block fully retired (and, first time, materials staged)
+        if (threadIdx.x == 0) {
+            ctl[0] = atomicAdd(work_counter, 1u);
+            ctl[2] = 0u; ctl[3] = 0u; ctl[4] = 0u; ctl[5] = 0u;
+        }
+        __syncthreads();
+        const int blk = (int)ctl[0];
+        if (blk >= n_blocks) break;
+
+        // ---- generate: sample 0 of the block's pixels; queues are filled densely with skip markers
+        for (int k = threadIdx.x; k < kWgPaths; k += kBlockThreads) {
+            const int id = blk * kWgPaths + k;
+            const bool go = wf_generate_one(a, w, id);
+            rayQ[k] = go ? (unsigned)id * 2u : WF_INVALID;
+            pathQ[k] = go ? (unsigned)id : WF_INVALID;
+        }
+        if (threadIdx.x == 0) { ctl[2] = kWgPaths; ctl[4] = kWgPaths; }
+        int cur = 0;
+
+        for (;;) {
+            if (threadIdx.x == 0) ctl[1] = 0u;  // ray head of this trip
+            __syncthreads();                    // queues of `cur` complete, state stores visible in the workgroup
+            const int n_rays = (int)ctl[2 + cur], n_paths = (int)ctl[4 + cur];
+            if (n_paths == 0) break;
+            const unsigned *rq = rayQ + cur * 2 * kWgPaths;
+            const unsigned *pq = pathQ + cur * kWgPaths;
+
+            // ---- traverse phase: lanes pull rays; a lane whose ray is finished takes the next one
+            {
+                int chunk_next = 0, chunk_end = 0;  // wave-uniform
+                bool exhausted = n_rays == 0;
+                bool active = false;
+                unsigned rid = 0;
+                Trav T;
+                T.cur = 0; T.sp = 0;
+                for (;;) {
+                    unsigned long long idle = __ballot(!active);
+                    if ((int)__popcll(idle) >= w.refill_min || idle == ~0ull) {
+                        while (idle != 0ull && !exhausted) {
+                            if (chunk_next >= chunk_end) {
+                                int base = 0;
+                                if (lane == 0) base = (int)atomicAdd(&ctl[1], 64u);
+                                base = __builtin_amdgcn_readfirstlane(base);
+                                if (base >= n_rays) { exhausted = true; break; }
+                                chunk_next = base;
+                                chunk_end = base + 64 < n_rays ? base + 64 : n_rays;
+                            }
+                            const int n = __popcll(idle);
+                            const int avail = chunk_end - chunk_next;
+                            const int take = n < avail ? n : avail;
+                            const int rank = __popcll(idle & lt_mask);
+                            if (!active && rank < take) {
+                                rid = rq[chunk_next + rank];
+                                if (rid != WF_INVALID) {
+                                    const unsigned id = rid >> 1;
+                                    const float4 o = w.A0[id];
+                                    const float4 d = (rid & 1u) ? w.A5[id] : w.A1[id];
+                                    rays++;
+                                    active = trav_init(a.sc, T, o.x, o.y, o.z, d.x, d.y, d.z);
+                                    if (!active) {
+                                        if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(-1));
+                                        else w.H[id] = make_float4(T.h.t, __int_as_float(-1), 0.f, 0.f);
+                                    }
+                                }
+                            }
+                            chunk_next += take;
+                            idle = __ballot(!active);
+                        }
                     }
-                    if (base >= hi) {  // this shard is dry: next one
-                        shard = (shard + 1) % kTravShards;
-                        if (--shards_left == 0) exhausted = true;
+                    if (!__any(active)) {
+                        if (exhausted) break;
                         continue;
                     }
-                    chunk_next = base;
-                    chunk_end = base + kRayChunk < hi ? base + kRayChunk : hi;
-                }
-                const int n = __popcll(idle);
-                const int avail = chunk_end - chunk_next;
-                const int take = n < avail ? n : avail;
-                const int rank = __popcll(idle & lt_mask);
-                if (!active && rank < take) {
-                    rid = q[chunk_next + rank];
-                    if (rid != WF_INVALID) {
-                        const unsigned id = rid >> 1;
-                        const float4 o = w.A0[id];
-                        const float4 d = (rid & 1u) ? w.A5[id] : w.A1[id];
-                        rays++;
-                        active = trav_init(a.sc, T, o.x, o.y, o.z, d.x, d.y, d.z);
-                        if (!active) {  // the root box was missed: result known at once
-                            if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(-1));
-                            else w.H[id] = make_float4(T.h.t, __int_as_float(-1), 0.f, 0.f);
+                    if (active) {
+                        if (trav_step<true>(a.sc, stack, T)) {
+                            const unsigned id = rid >> 1;
+                            if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(T.h.tri));
+                            else w.H[id] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
+                            active = false;
                         }
                     }
                 }
-                chunk_next += take;
-                idle = __ballot(!active);
             }
-        }
-        if (!__any(active)) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---- one traversal step per live lane
-        if (active) {
-            if (trav_step<true>(a.sc, stack, T)) {
-                const unsigned id = rid >> 1;
-                if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(T.h.tri));
-                else w.H[id] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
-                active = false;
+            __syncthreads();  // all hit records of this trip written
+
+            // ---- shade phase: the block's live paths; appends go to the other queue pair
+            {
+                unsigned *rq_next = rayQ + (cur ^ 1) * 2 * kWgPaths;
+                unsigned *pq_next = pathQ + (cur ^ 1) * kWgPaths;
+                for (int j0 = 0; j0 < n_paths; j0 += kBlockThreads) {
+                    const int i = j0 + (int)threadIdx.x;
+                    bool push_ext = false, push_sh = false;
+                    unsigned id = WF_INVALID;
+                    if (i < n_paths) id = pq[i];
+                    if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, id, push_ext, push_sh);
+                    const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
+                    unsigned br = 0, bp = 0;
+                    if (lane == 0) {
+                        if (mp) {
+                            br = atomicAdd(&ctl[2 + (cur ^ 1)], (unsigned)(__popcll(me) + __popcll(ms)));
+                            bp = atomicAdd(&ctl[4 + (cur ^ 1)], (unsigned)__popcll(mp));
+                        }
+                    }
+                    br = __builtin_amdgcn_readfirstlane(br);
+                    bp = __builtin_amdgcn_readfirstlane(bp);
+                    if (push_ext) rq_next[br + __popcll(me & lt_mask)] = id * 2u;
+                    if (push_sh) rq_next[br + __popcll(me) + __popcll(ms & lt_mask)] = id * 2u + 1u;
+                    if (push_ext || push_sh) pq_next[bp + __popcll(mp & lt_mask)] = id;
+                }
             }
+            __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
+            if (threadIdx.x == 0) { ctl[2 + cur] = 0u; ctl[4 + cur] = 0u; }
+            cur ^= 1;
         }
     }
     flush_rays<COUNT_RAYS>(a, rays);
-}
-
-__global__ __launch_bounds__(kBlockThreads) void wf_shade(const KernelArgs a, const WfArgs w, int it) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    // LDS: materials | out_rays[2*kShadeBlock] | out_paths[kShadeBlock] | {n_rays, n_paths, block, gbase_r, gbase_p}
-    float4 *lds_mats = reinterpret_cast<float4 *>(lds_raw);
-    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
-    unsigned *out_rays = reinterpret_cast<unsigned *>(lds_raw + (size_t)mat_f4 * sizeof(float4));
-    unsigned *out_paths = out_rays + 2 * kShadeBlock;
-    unsigned *ctl = out_paths + kShadeBlock;
-    if (a.sc.mats_in_lds)
-        for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
-    if (threadIdx.x == 0) { ctl[0] = 0u; ctl[1] = 0u; }
-    __syncthreads();
-
-    const unsigned *qs = w.qS[it & 1];
-    unsigned *qt_next = w.qT[(it + 1) & 1], *qs_next = w.qS[(it + 1) & 1];
-    unsigned *cnt = w.cnt + (size_t)kCntStride * it, *cnt_next = cnt + kCntStride;
-    const int n_paths = (int)cnt[kCntPaths];
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-    for (;;) {
-        // ---- next super-block of kShadeBlock queue entries (dynamic: shading cost varies)
-        if (threadIdx.x == 0) ctl[2] = atomicAdd(cnt + kCntShadeHead, 1u);
-        __syncthreads();
-        const int sb = (int)ctl[2];
-        if ((long long)sb * kShadeBlock >= n_paths) break;
-
-        for (int j = 0; j < kShadeBlock / kBlockThreads; j++) {
-            const int i = sb * kShadeBlock + j * kBlockThreads + (int)threadIdx.x;
-            bool push_ext = false, push_sh = false;
-            unsigned id = WF_INVALID;
-            if (i < n_paths) id = qs[i];
-            if (id != WF_INVALID) {
-                int lx, lrow;
-                wf_pixel(a, w, (int)id, lx, lrow);
-                const int gy = local_row_to_y(a, lrow);
-                const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
-                float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
-                const float4 s0 = w.A0[id], s1 = w.A1[id], s2 = w.A2[id], s3 = w.A3[id];
-                Rng rng = {s0.w, s1.w, a.seed_x, a.seed_y};
-                const unsigned meta = __float_as_uint(s2.w);
-                unsigned sample = (meta >> 8) & 0xFFFFFu;
-                Path P;
-                P.ox = s0.x; P.oy = s0.y; P.oz = s0.z; P.dx = s1.x; P.dy = s1.y; P.dz = s1.z;
-                P.bx = s2.x; P.by = s2.y; P.bz = s2.z;
-                P.depth = (int)(meta & 0xFFu);
-                // resolve the light sample of the previous bounce (:367, :539)
-                P.Lx = s3.x; P.Ly = s3.y; P.Lz = s3.z;
-                if (meta & WF_PENDING) {
-                    const float2 hs = w.HS[id];
-                    if (!nee_accepted(s3.w, hs.x, __float_as_int(hs.y) >= 0)) {
-                        const float4 s4 = w.A4[id];
-                        P.Lx = s4.x; P.Ly = s4.y; P.Lz = s4.z;
-                    }
-                }
-                bool ended = (meta & WF_FINISHING) != 0u;
-                Shade sh;
-                sh.has_shadow = false;
-                if (!ended) {
-                    const float4 hh = w.H[id];
-                    Hit h;
-                    h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
-                    shade_hit(a, lds_mats, rng, P, h, sh);
-                    if (sh.ended && !sh.has_shadow) { P.Lx = sh.Lpx; P.Ly = sh.Lpy; P.Lz = sh.Lpz; }
-                    ended = sh.ended && !sh.has_shadow;  // with a shadow ray in flight the sample closes next trip
-                }
-                if (ended) {
-                    // radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609)
-                    float4 acc = *px;
-                    acc.x = acc.x + fmin_c(P.Lx, 100.0f);
-                    acc.y = acc.y + fmin_c(P.Ly, 100.0f);
-                    acc.z = acc.z + fmin_c(P.Lz, 100.0f);
-                    acc.w = acc.w + 1.0f;
-                    *px = acc;
-                    sample++;
-                    push_ext = wf_start(a, rng, fcx, fcy, P, sample, px);  // the pixel's next sample, if any
-                    if (push_ext) {
-                        w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
-                        w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
-                        w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
-                        w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                } else {
-                    // shade_hit ran and the path goes on and/or awaits its shadow ray
-                    push_sh = sh.has_shadow;
-                    push_ext = !sh.ended;
-                    const unsigned m2 = (unsigned)P.depth | (sample << 8) | (push_sh ? WF_PENDING : 0u) | (sh.ended ? WF_FINISHING : 0u);
-                    w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
-                    w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
-                    w.A2[id] = make_float4(P.bx, P.by, P.bz, __uint_as_float(m2));
-                    w.A3[id] = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist);
-                    if (push_sh) {
-                        w.A4[id] = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f);
-                        w.A5[id] = make_float4(sh.sdx, sh.sdy, sh.sdz, 0.f);
-                    }
-                }
-            }
-            // ---- append to the workgroup's LDS buffers: one LDS atomic per wave and buffer
-            {
-                const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
-                unsigned br = 0, bp = 0;
-                if (lane == 0) {
-                    if (me | ms) br = atomicAdd(&ctl[0], (unsigned)(__popcll(me) + __popcll(ms)));
-                    if (mp) bp = atomicAdd(&ctl[1], (unsigned)__popcll(mp));
-                }
-                br = __builtin_amdgcn_readfirstlane(br);
-                bp = __builtin_amdgcn_readfirstlane(bp);
-                if (push_ext) out_rays[br + __popcll(me & lt_mask)] = id * 2u;
-                if (push_sh) out_rays[br + __popcll(me) + __popcll(ms & lt_mask)] = id * 2u + 1u;
-                if (push_ext || push_sh) out_paths[bp + __popcll(mp & lt_mask)] = id;
-            }
-        }
-        // ---- flush the super-block's appends: two global atomics, coalesced copies
-        __syncthreads();
-        const unsigned nr = ctl[0], np = ctl[1];
-        if (threadIdx.x == 0) {
-            ctl[3] = nr ? atomicAdd(cnt_next + kCntRays, nr) : 0u;
-            ctl[4] = np ? atomicAdd(cnt_next + kCntPaths, np) : 0u;
-        }
-        __syncthreads();
-        const unsigned gr = ctl[3], gp = ctl[4];
-        for (unsigned k = threadIdx.x; k < nr; k += kBlockThreads) qt_next[gr + k] = out_rays[k];
-        for (unsigned k = threadIdx.x; k < np; k += kBlockThreads) qs_next[gp + k] = out_paths[k];
-        __syncthreads();
-        if (threadIdx.x == 0) { ctl[0] = 0u; ctl[1] = 0u; }
-        // (the __syncthreads after the next block fetch orders this reset before any append)
-    }
 }
 
 // ------------------------------------------------------------------------------------------ resolve

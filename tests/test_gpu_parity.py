@@ -191,3 +191,24 @@ def test_empty_and_edge_scenes(gpu_device):
     scene, params = scenes.config_c1(17, 9, max_depth=0, subdiv=1)  # max_depth 0: no rays, count still advances
     acc, st = gpu_render(d, scene, params)
     assert st.rays == 0 and np.all(acc[..., 3] == 1) and np.all(acc[..., :3] == 0)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_all_kernel_variants_bit_identical(gpu_device, variant):
+    """The tile megakernel (0), the persistent megakernel with path regeneration (1) and the
+    workgroup-local wavefront (2, default) share the shading/traversal code and must agree bitwise,
+    including at sizes smaller than one workgroup block and with several samples per pass."""
+    from oracle import pt_oracle
+    d = gpu_device
+    try:
+        d.set_variant(variant)
+        for cfg, kw in (("c1", dict(width=40, height=24, max_depth=5, n_samples=3, subdiv=1)),
+                        ("c2", dict(width=320, height=180, max_depth=8, n_samples=2, subdiv=2)),
+                        ("c3", dict(width=160, height=90, max_depth=2, n=3000))):
+            scene, params = scenes.CONFIGS[cfg](**kw)
+            ref, ref_rays = pt_oracle.render(scene, params)
+            acc, st = gpu_render(d, scene, params)
+            assert st.rays == ref_rays
+            assert_bit_equal(acc, ref, f"variant {variant} {cfg}")
+    finally:
+        d.set_variant(2)
