@@ -10,6 +10,7 @@ the 1920x1080 image, u_maxDepth = 8, 1 sample/pixel, fresh u_seed per frame) acc
 resident float4 framebuffer.  With N > 1 ranks the image rows are sharded in interleaved 16-row
 stripes (one process per GPU, global pixel coordinates, no data-path collective) and every frame ends
 with the RCCL all_gather of the finished rows ("gather the framebuffer"), inside the timed region.
+One frame is ONE launch of the render kernel (pt_render_wgwf, the workgroup-local wavefront).
 Scene and accumulators are resident in HBM before timing starts.  Rays are counted exactly (one
 execution of intersect() = one ray) by an untimed pass over the same seeds with the
 counting variant of the kernel; the timed launches use the clean kernel.
@@ -163,7 +164,7 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "kernel": "pt_render_kernel<false>", "kernel_ms_avg": round(kernel_ms, 4),
+                "kernel": "pt_render_wgwf<false>", "kernel_ms_avg": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "note": "branchy scalar-FP32 traversal: VALU/latency-bound, not HBM-bound (DESIGN.md section 6)"}
 

@@ -688,6 +688,15 @@ int glrtx_debug_trav_hist(unsigned long long out[16]) {
 }
 #endif
 
+#ifdef GLRTX_PHASE_STATS
+int glrtx_debug_phase_cycles(unsigned long long out[8]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return GLRTX_EDEVICE;
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
+    return GLRTX_OK;
+}
+#endif
+
 int glrtx_timer_begin(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));

@@ -1012,6 +1012,17 @@ constexpr int kWgPaths = GLRTX_WG_PATHS;  // pixels per workgroup block (16 tile
 #define GLRTX_WGWF_WAVES 4
 #endif
 
+#ifdef GLRTX_PHASE_STATS
+// Diagnostic build only: shader-clock cycles thread 0 of every workgroup spent per phase
+// [0] generate, [1] traverse (own work), [2] wait at the barrier after traverse, [3] shade, [4] wait after shade
+__device__ unsigned long long g_phase_cycles[8];
+#define PH_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PH_ADD(i, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], (t1) - (t0)); } while (0)
+#else
+#define PH_STAMP(var)
+#define PH_ADD(i, t0, t1)
+#endif
+
 template <bool COUNT_RAYS>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, unsigned *wg_queues) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1044,6 +1055,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         if (blk >= n_blocks) break;
 
         // ---- generate: sample 0 of the block's pixels; queues are filled densely with skip markers
+        PH_STAMP(pg0);
         for (int k = threadIdx.x; k < kWgPaths; k += kBlockThreads) {
             const int id = blk * kWgPaths + k;
             const bool go = wf_generate_one(a, w, id);
@@ -1052,6 +1064,8 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         }
         if (threadIdx.x == 0) { ctl[2] = kWgPaths; ctl[4] = kWgPaths; }
         int cur = 0;
+        PH_STAMP(pg1);
+        PH_ADD(0, pg0, pg1);
 
         for (;;) {
             if (threadIdx.x == 0) ctl[1] = 0u;  // ray head of this trip
@@ -1062,13 +1076,25 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
             const unsigned *pq = pathQ + cur * kWgPaths;
 
             // ---- traverse phase: lanes pull rays; a lane whose ray is finished takes the next one
+            PH_STAMP(pt0);
             {
                 int chunk_next = 0, chunk_end = 0;  // wave-uniform
                 bool exhausted = n_rays == 0;
                 bool active = false;
+                // A finished ray's hit record is kept in registers and written when the lane is refilled
+                // (or at the end of the phase): a store issued inside the stepping loop would sit in vmcnt
+                // and make every following node fetch of the whole wave wait for it.
+                bool unsaved = false;
                 unsigned rid = 0;
                 Trav T;
                 T.cur = 0; T.sp = 0;
+                T.h.t = PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
+                auto save_hit = [&]() {
+                    const unsigned id = rid >> 1;
+                    if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(T.h.tri));
+                    else w.H[id] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
+                    unsaved = false;
+                };
                 for (;;) {
                     unsigned long long idle = __ballot(!active);
                     if ((int)__popcll(idle) >= w.refill_min || idle == ~0ull) {
@@ -1086,6 +1112,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
                             const int take = n < avail ? n : avail;
                             const int rank = __popcll(idle & lt_mask);
                             if (!active && rank < take) {
+                                if (unsaved) save_hit();
                                 rid = rq[chunk_next + rank];
                                 if (rid != WF_INVALID) {
                                     const unsigned id = rid >> 1;
@@ -1093,10 +1120,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
                                     const float4 d = (rid & 1u) ? w.A5[id] : w.A1[id];
                                     rays++;
                                     active = trav_init(a.sc, T, o.x, o.y, o.z, d.x, d.y, d.z);
-                                    if (!active) {
-                                        if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(-1));
-                                        else w.H[id] = make_float4(T.h.t, __int_as_float(-1), 0.f, 0.f);
-                                    }
+                                    unsaved = !active;  // root box missed: the (miss) record is already final
                                 }
                             }
                             chunk_next += take;
@@ -1109,15 +1133,18 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
                     }
                     if (active) {
                         if (trav_step<true>(a.sc, stack, T)) {
-                            const unsigned id = rid >> 1;
-                            if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(T.h.tri));
-                            else w.H[id] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
                             active = false;
+                            unsaved = true;
                         }
                     }
                 }
+                if (unsaved) save_hit();
             }
+            PH_STAMP(pt1);
             __syncthreads();  // all hit records of this trip written
+            PH_STAMP(pt2);
+            PH_ADD(1, pt0, pt1);
+            PH_ADD(2, pt1, pt2);
 
             // ---- shade phase: the block's live paths; appends go to the other queue pair
             {
@@ -1144,7 +1171,11 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
                     if (push_ext || push_sh) pq_next[bp + __popcll(mp & lt_mask)] = id;
                 }
             }
+            PH_STAMP(ps1);
             __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
+            PH_STAMP(ps2);
+            PH_ADD(3, pt2, ps1);
+            PH_ADD(4, ps1, ps2);
             if (threadIdx.x == 0) { ctl[2 + cur] = 0u; ctl[4 + cur] = 0u; }
             cur ^= 1;
         }

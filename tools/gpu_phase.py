@@ -1,0 +1,12 @@
+import sys, ctypes as C; sys.path.insert(0,'.'); sys.path.insert(0,'opengl-raytracer_amd/python')
+import numpy as np
+from glrt_amd import scenes, device, host
+device.lib_path = lambda: device.LIB_DIR / "libglrtx_phase.so"
+sc, pr = scenes.config_headline()
+d = device.Device(); d.upload_scene(sc); d.resize(1920, 1080)
+L = device.lib(); out = (C.c_ulonglong * 8)()
+d.render(dict(pr, seed=host.frame_seed(0))); d.sync(); L.glrtx_debug_phase_cycles(out)
+d.render(dict(pr, seed=host.frame_seed(1))); d.sync(); L.glrtx_debug_phase_cycles(out)
+o = np.array(list(out)[:5], float); print("ms", d.stats().kernel_ms_last)
+names = ["generate", "traverse", "wait after traverse", "shade", "wait after shade"]
+for n, v in zip(names, o): print(f"{n:22s} {v/o.sum()*100:5.1f} %   ({v/1e6:.1f} Mcycles summed over workgroups)")
