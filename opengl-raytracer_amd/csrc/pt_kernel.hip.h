@@ -875,6 +875,7 @@ struct WfArgs {
     int total;        // tile-order ids: tiles8_x * tiles8_y * 64
     int tiles8_x;
     int refill_min;   // refill a traversal wave once this many lanes are idle
+    int block_paths;  // pixels per workgroup block (multiple of 256, <= kWgPathsMax)
 };
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
 constexpr unsigned WF_FINISHING = 1u << 29;  // the path has ended; only that shadow ray is awaited
@@ -1004,10 +1005,8 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 // workgroup waiting for its last long ray idles only itself, while the other resident workgroups are
 // at other stages -- the global pipeline of variant C loses ~300 us per trip to that wait, nine times
 // a frame.  One kernel launch per frame.  State lives in the same HBM arrays as variant C.
-#ifndef GLRTX_WG_PATHS
-#define GLRTX_WG_PATHS 1024
-#endif
-constexpr int kWgPaths = GLRTX_WG_PATHS;  // pixels per workgroup block (16 tiles of 8x8)
+constexpr int kWgPathsMax = 1024;  // pixels per workgroup block: 1024 (16 tiles of 8x8) when the image is large enough to
+                                   // give every resident workgroup >= 2 blocks, else 512 or 256 (chosen by the host)
 #ifndef GLRTX_WGWF_WAVES
 #define GLRTX_WGWF_WAVES 4
 #endif
@@ -1034,13 +1033,14 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
     unsigned *ctl = reinterpret_cast<unsigned *>(pl);            // 0: block, 1: ray head, 2..3: nRays[2], 4..5: nPaths[2]
-    unsigned *rayQ = wg_queues + (size_t)blockIdx.x * 6 * kWgPaths;  // [2][2*kWgPaths]
-    unsigned *pathQ = rayQ + 4 * kWgPaths;                            // [2][kWgPaths]
+    unsigned *rayQ = wg_queues + (size_t)blockIdx.x * 6 * kWgPathsMax;  // [2][2*block_paths]
+    unsigned *pathQ = rayQ + 4 * w.block_paths;                          // [2][block_paths]
     if (a.sc.mats_in_lds)
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
 
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int kWgPaths = w.block_paths;
     const int n_blocks = (w.total + kWgPaths - 1) / kWgPaths;
     unsigned rays = 0;
 
