@@ -252,9 +252,11 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
     } else {
         // leaf :310-331 with intersect(Ray, Triangle) :226-257
         const int t = ~cur;
-        const float4 T0 = sc.tris[3 * t], T1 = sc.tris[3 * t + 1], T2 = sc.tris[3 * t + 2];
-        // o - v0 is formed before the determinant test so that all three loads are issued together
-        // (otherwise the compiler sinks the v0 load behind the branch: a second dependent round trip)
+        float4 T0 = sc.tris[3 * t];
+        const float4 T1 = sc.tris[3 * t + 1], T2 = sc.tris[3 * t + 2];
+        // Pin v0 here: otherwise the compiler sinks its load behind the determinant test and the
+        // triangle costs two dependent memory round trips instead of one.
+        asm volatile("" : "+v"(T0.x), "+v"(T0.y), "+v"(T0.z));
         const float tx = T.ox - T0.x, ty = T.oy - T0.y, tz = T.oz - T0.z;
         const float px = T.dy * T2.z - T.dz * T2.y;
         const float py = T.dz * T2.x - T.dx * T2.z;
@@ -287,9 +289,14 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
     for (;;) {
         if (T.sp == 0) { TS_DONE; return true; }
         T.sp--;
-        const int2 e = reinterpret_cast<const int2 *>(stack)[T.sp * kBlockThreads];  // one ds_read_b64
-        T.cur = e.x;
-        if (T.h.t >= __int_as_float(e.y)) return false;
+        // ONE ds_read_b64 for {ref, t0}: left to itself the compiler reads t0, waits, and only then reads the
+        // ref of entries that survive -- two dependent LDS round trips per pop.  (The low 32 bits of a generic
+        // pointer into LDS are the LDS byte address; the wait is inside the statement, cdna guide section 5.7.)
+        unsigned long long e;
+        const unsigned lds_addr = (unsigned)(uintptr_t)stack + (unsigned)T.sp * (kBlockThreads * 8u);
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(lds_addr) : "memory");
+        T.cur = (int)(unsigned)e;
+        if (T.h.t >= __uint_as_float((unsigned)(e >> 32))) return false;
     }
 }
 
