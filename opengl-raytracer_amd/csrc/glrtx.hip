@@ -325,6 +325,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
     if (ci) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_wgwf<true>, kBlockThreads, lds));
     else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_wgwf<false>, kBlockThreads, lds));
     if (per_cu < 1) per_cu = 1;
+    if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));  // occupancy experiments
     // block size: as large as possible while there are still >= 1.5 blocks per resident workgroup
     // (measured on the headline frame: 1024 -> 4.2 ms, 512 -> 4.6 ms at 1080p; at 1/8 of the rows 256 -> 1.5 ms, 1024 -> 2.9 ms)
     const int resident = per_cu * c->n_cu;
