@@ -1018,6 +1018,105 @@ constexpr int kWgPathsMax = 1024;  // pixels per workgroup block: 1024 (16 tiles
 #define GLRTX_WGWF_WAVES 4
 #endif
 
+// Traverse phase of one block-trip, run by a whole workgroup: lanes pull the block's queued rays
+// (64 at a time per wave through *ray_head, an LDS counter) and a lane whose ray is finished takes the
+// next one once refill_min lanes of its wave are idle.  Hit records go to w.H / w.HS.
+DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, const unsigned *rq, int n_rays,
+                           unsigned *ray_head, unsigned &rays) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int chunk_next = 0, chunk_end = 0;  // wave-uniform
+    bool exhausted = n_rays == 0;
+    bool active = false;
+    // A finished ray's hit record is kept in registers and written when the lane is refilled
+    // (or at the end of the phase): a store issued inside the stepping loop would sit in vmcnt
+    // and make every following node fetch of the whole wave wait for it.
+    bool unsaved = false;
+    unsigned rid = 0;
+    Trav T;
+    T.cur = 0; T.sp = 0;
+    T.h.t = PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
+    auto save_hit = [&]() {
+        const unsigned id = rid >> 1;
+        if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(T.h.tri));
+        else w.H[id] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
+        unsaved = false;
+    };
+    for (;;) {
+        unsigned long long idle = __ballot(!active);
+        if ((int)__popcll(idle) >= w.refill_min || idle == ~0ull) {
+            while (idle != 0ull && !exhausted) {
+                if (chunk_next >= chunk_end) {
+                    int base = 0;
+                    if (lane == 0) base = (int)atomicAdd(ray_head, 64u);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n_rays) { exhausted = true; break; }
+                    chunk_next = base;
+                    chunk_end = base + 64 < n_rays ? base + 64 : n_rays;
+                }
+                const int n = __popcll(idle);
+                const int avail = chunk_end - chunk_next;
+                const int take = n < avail ? n : avail;
+                const int rank = __popcll(idle & lt_mask);
+                if (!active && rank < take) {
+                    if (unsaved) save_hit();
+                    rid = rq[chunk_next + rank];
+                    if (rid != WF_INVALID) {
+                        const unsigned id = rid >> 1;
+                        const float4 o = w.A0[id];
+                        const float4 d = (rid & 1u) ? w.A5[id] : w.A1[id];
+                        rays++;
+                        active = trav_init(a.sc, T, o.x, o.y, o.z, d.x, d.y, d.z);
+                        unsaved = !active;  // root box missed: the (miss) record is already final
+                    }
+                }
+                chunk_next += take;
+                idle = __ballot(!active);
+            }
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+        if (active) {
+            if (trav_step<true>(a.sc, stack, T)) {
+                active = false;
+                unsaved = true;
+            }
+        }
+    }
+    if (unsaved) save_hit();
+}
+
+// Shade phase of one block-trip, run by a whole workgroup: every live path of the block (pq[0..n_paths))
+// goes through wf_shade_path(); the rays and paths of the next trip are appended to rq_next / pq_next
+// (wave-aggregated, one LDS atomic per wave and queue on *n_rays_next / *n_paths_next).
+DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const unsigned *pq, int n_paths,
+                        unsigned *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int j0 = 0; j0 < n_paths; j0 += kBlockThreads) {
+        const int i = j0 + (int)threadIdx.x;
+        bool push_ext = false, push_sh = false;
+        unsigned id = WF_INVALID;
+        if (i < n_paths) id = pq[i];
+        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, id, push_ext, push_sh);
+        const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
+        unsigned br = 0, bp = 0;
+        if (lane == 0) {
+            if (mp) {
+                br = atomicAdd(n_rays_next, (unsigned)(__popcll(me) + __popcll(ms)));
+                bp = atomicAdd(n_paths_next, (unsigned)__popcll(mp));
+            }
+        }
+        br = __builtin_amdgcn_readfirstlane(br);
+        bp = __builtin_amdgcn_readfirstlane(bp);
+        if (push_ext) rq_next[br + __popcll(me & lt_mask)] = id * 2u;
+        if (push_sh) rq_next[br + __popcll(me) + __popcll(ms & lt_mask)] = id * 2u + 1u;
+        if (push_ext || push_sh) pq_next[bp + __popcll(mp & lt_mask)] = id;
+    }
+}
+
 #ifdef GLRTX_PHASE_STATS
 // Diagnostic build only: shader-clock cycles thread 0 of every workgroup spent per phase
 // [0] generate, [1] traverse (own work), [2] wait at the barrier after traverse, [3] shade, [4] wait after shade
@@ -1045,8 +1144,6 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     if (a.sc.mats_in_lds)
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
 
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int kWgPaths = w.block_paths;
     const int n_blocks = (w.total + kWgPaths - 1) / kWgPaths;
     unsigned rays = 0;
@@ -1084,69 +1181,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 
             // ---- traverse phase: lanes pull rays; a lane whose ray is finished takes the next one
             PH_STAMP(pt0);
-            {
-                int chunk_next = 0, chunk_end = 0;  // wave-uniform
-                bool exhausted = n_rays == 0;
-                bool active = false;
-                // A finished ray's hit record is kept in registers and written when the lane is refilled
-                // (or at the end of the phase): a store issued inside the stepping loop would sit in vmcnt
-                // and make every following node fetch of the whole wave wait for it.
-                bool unsaved = false;
-                unsigned rid = 0;
-                Trav T;
-                T.cur = 0; T.sp = 0;
-                T.h.t = PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
-                auto save_hit = [&]() {
-                    const unsigned id = rid >> 1;
-                    if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(T.h.tri));
-                    else w.H[id] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
-                    unsaved = false;
-                };
-                for (;;) {
-                    unsigned long long idle = __ballot(!active);
-                    if ((int)__popcll(idle) >= w.refill_min || idle == ~0ull) {
-                        while (idle != 0ull && !exhausted) {
-                            if (chunk_next >= chunk_end) {
-                                int base = 0;
-                                if (lane == 0) base = (int)atomicAdd(&ctl[1], 64u);
-                                base = __builtin_amdgcn_readfirstlane(base);
-                                if (base >= n_rays) { exhausted = true; break; }
-                                chunk_next = base;
-                                chunk_end = base + 64 < n_rays ? base + 64 : n_rays;
-                            }
-                            const int n = __popcll(idle);
-                            const int avail = chunk_end - chunk_next;
-                            const int take = n < avail ? n : avail;
-                            const int rank = __popcll(idle & lt_mask);
-                            if (!active && rank < take) {
-                                if (unsaved) save_hit();
-                                rid = rq[chunk_next + rank];
-                                if (rid != WF_INVALID) {
-                                    const unsigned id = rid >> 1;
-                                    const float4 o = w.A0[id];
-                                    const float4 d = (rid & 1u) ? w.A5[id] : w.A1[id];
-                                    rays++;
-                                    active = trav_init(a.sc, T, o.x, o.y, o.z, d.x, d.y, d.z);
-                                    unsaved = !active;  // root box missed: the (miss) record is already final
-                                }
-                            }
-                            chunk_next += take;
-                            idle = __ballot(!active);
-                        }
-                    }
-                    if (!__any(active)) {
-                        if (exhausted) break;
-                        continue;
-                    }
-                    if (active) {
-                        if (trav_step<true>(a.sc, stack, T)) {
-                            active = false;
-                            unsaved = true;
-                        }
-                    }
-                }
-                if (unsaved) save_hit();
-            }
+            wg_traverse_phase(a, w, stack, rq, n_rays, &ctl[1], rays);
             PH_STAMP(pt1);
             __syncthreads();  // all hit records of this trip written
             PH_STAMP(pt2);
@@ -1154,30 +1189,8 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
             PH_ADD(2, pt1, pt2);
 
             // ---- shade phase: the block's live paths; appends go to the other queue pair
-            {
-                unsigned *rq_next = rayQ + (cur ^ 1) * 2 * kWgPaths;
-                unsigned *pq_next = pathQ + (cur ^ 1) * kWgPaths;
-                for (int j0 = 0; j0 < n_paths; j0 += kBlockThreads) {
-                    const int i = j0 + (int)threadIdx.x;
-                    bool push_ext = false, push_sh = false;
-                    unsigned id = WF_INVALID;
-                    if (i < n_paths) id = pq[i];
-                    if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, id, push_ext, push_sh);
-                    const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
-                    unsigned br = 0, bp = 0;
-                    if (lane == 0) {
-                        if (mp) {
-                            br = atomicAdd(&ctl[2 + (cur ^ 1)], (unsigned)(__popcll(me) + __popcll(ms)));
-                            bp = atomicAdd(&ctl[4 + (cur ^ 1)], (unsigned)__popcll(mp));
-                        }
-                    }
-                    br = __builtin_amdgcn_readfirstlane(br);
-                    bp = __builtin_amdgcn_readfirstlane(bp);
-                    if (push_ext) rq_next[br + __popcll(me & lt_mask)] = id * 2u;
-                    if (push_sh) rq_next[br + __popcll(me) + __popcll(ms & lt_mask)] = id * 2u + 1u;
-                    if (push_ext || push_sh) pq_next[bp + __popcll(mp & lt_mask)] = id;
-                }
-            }
+            wg_shade_phase(a, w, lds_mats, pq, n_paths, rayQ + (cur ^ 1) * 2 * kWgPaths, pathQ + (cur ^ 1) * kWgPaths,
+                           &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)]);
             PH_STAMP(ps1);
             __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
             PH_STAMP(ps2);
