@@ -229,62 +229,57 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
 #else
 #define TS_DONE
 #endif
+    // Both arms are written with straight-line arithmetic and ONE combined predicate instead of the
+    // reference's nested early-outs: in a divergent wave some lane takes every early-out path anyway, and
+    // each nesting level costs scalar exec-mask bookkeeping on the latency-critical instruction stream.
+    // Evaluating a test's later terms when an earlier one already failed cannot change the outcome
+    // (pure IEEE arithmetic; a NaN/inf produced behind a failed test is masked by the predicate).
     const int cur = T.cur;
+    bool need_pop = true;
     if (cur >= 0) {
         const float4 *N = sc.forks + 4 * (size_t)cur;
         const float4 L0 = N[0], L1 = N[1], R0 = N[2], R1 = N[3];
         const int l = __float_as_int(L0.w), r = __float_as_int(L1.w);
-        float t0l = -PT_INFTY, t0r;
-        const bool pl = l != REF_ABSENT && (l < 0 || box_pass(L0, L1, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0l));
-        const bool pr = r != REF_ABSENT && (r < 0 || box_pass(R0, R1, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0r));
-        if (pr) {
-            if (pl) {
-                reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = make_int2(l, __float_as_int(t0l));  // one ds_write_b64
-                T.sp++;
-            }
-            T.cur = r;
-            return false;
+        float t0l, t0r;
+        const bool bl = box_pass(L0, L1, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0l);
+        const bool br = box_pass(R0, R1, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0r);
+        // leaf children are never box-tested (:310-331); an absent child never passes
+        const bool pl = l != REF_ABSENT && (l < 0 || bl);
+        const bool pr = r != REF_ABSENT && (r < 0 || br);
+        if (pl && pr) {  // continue with the right child, the left one waits on the stack
+            reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = make_int2(l, __float_as_int(l < 0 ? -PT_INFTY : t0l));  // one ds_write_b64
+            T.sp++;
         }
-        if (pl) {
-            T.cur = l;
-            return false;
-        }
+        T.cur = pr ? r : l;
+        need_pop = !(pl || pr);
     } else {
         // leaf :310-331 with intersect(Ray, Triangle) :226-257
         const int t = ~cur;
         float4 T0 = sc.tris[3 * t];
         const float4 T1 = sc.tris[3 * t + 1], T2 = sc.tris[3 * t + 2];
-        // Pin v0 here: otherwise the compiler sinks its load behind the determinant test and the
-        // triangle costs two dependent memory round trips instead of one.
-        asm volatile("" : "+v"(T0.x), "+v"(T0.y), "+v"(T0.z));
         const float tx = T.ox - T0.x, ty = T.oy - T0.y, tz = T.oz - T0.z;
         const float px = T.dy * T2.z - T.dz * T2.y;
         const float py = T.dz * T2.x - T.dx * T2.z;
         const float pz = T.dx * T2.y - T.dy * T2.x;
         const float det = dot3(T1.x, T1.y, T1.z, px, py, pz);
         const float U = dot3(tx, ty, tz, px, py, pz);
-        if (!(-PT_EPS < det && det < PT_EPS)) {
-            const float inv = 1.0f / det;
-            const float u = U * inv;
-            if (!(u < 0.0f || 1.0f < u)) {
-                const float qx = ty * T1.z - tz * T1.y;
-                const float qy = tz * T1.x - tx * T1.z;
-                const float qz = tx * T1.y - ty * T1.x;
-                const float V = dot3(T.dx, T.dy, T.dz, qx, qy, qz);
-                const float v = V * inv;
-                if (!(v < 0.0f || 1.0f < inv * (U + V))) {  // u+v>1 is evaluated as inv*(U+V)>1
-                    const float tt = dot3(T2.x, T2.y, T2.z, qx, qy, qz) * inv;
-                    if (!(PT_EPS >= tt)) {
-                        if (tt < T.h.t) {
-                            T.h.tri = t;
-                            if (CLOSEST) { T.h.u = u; T.h.v = v; }
-                        }
-                        T.h.t = __builtin_fminf(T.h.t, tt);
-                    }
-                }
-            }
-        }
+        const float inv = 1.0f / det;
+        const float u = U * inv;
+        const float qx = ty * T1.z - tz * T1.y;
+        const float qy = tz * T1.x - tx * T1.z;
+        const float qz = tx * T1.y - ty * T1.x;
+        const float V = dot3(T.dx, T.dy, T.dz, qx, qy, qz);
+        const float v = V * inv;
+        const float tt = dot3(T2.x, T2.y, T2.z, qx, qy, qz) * inv;
+        const bool hit = !(-PT_EPS < det && det < PT_EPS) && !(u < 0.0f || 1.0f < u) &&
+                         !(v < 0.0f || 1.0f < inv * (U + V)) &&  // u+v>1 is evaluated as inv*(U+V)>1
+                         !(PT_EPS >= tt);
+        const bool closer = hit && tt < T.h.t;  // strict: among equal distances the first one visited wins (:325)
+        T.h.tri = closer ? t : T.h.tri;
+        if (CLOSEST) { T.h.u = closer ? u : T.h.u; T.h.v = closer ? v : T.h.v; }
+        T.h.t = hit ? __builtin_fminf(T.h.t, tt) : T.h.t;
     }
+    if (!need_pop) return false;
     // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298
     for (;;) {
         if (T.sp == 0) { TS_DONE; return true; }
