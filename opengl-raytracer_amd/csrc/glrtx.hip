@@ -154,7 +154,7 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
 
     // ---- triangles: {v0, material} {v1-v0} {v2-v0}; normals {n0} {n1} {n2}
     std::vector<float4> &tris = P.tris, &nrms = P.nrms;
-    tris.assign(3 * n_tri, make_float4(0.f, 0.f, 0.f, 0.f));
+    tris.assign(4 * n_tri, make_float4(0.f, 0.f, 0.f, 0.f));  // 64-byte records, same shape as a fork record
     nrms.assign(3 * n_tri, make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t t = 0; t < n_tri; t++) {
         int i[3];
@@ -163,9 +163,9 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         const float mf = tri[4 * t + 3];
         if (!(mf >= 0.0f) || (size_t)mf >= n_mat) return pfail(c, err_out, GLRTX_ESCENE, "triangle %zu: material %g out of range", t, mf);
         const float *p0 = vert + 15 * (size_t)i[0], *p1 = vert + 15 * (size_t)i[1], *p2 = vert + 15 * (size_t)i[2];
-        tris[3 * t + 0] = make_float4(p0[0], p0[1], p0[2], as_float((int)mf));
-        tris[3 * t + 1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.f);
-        tris[3 * t + 2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.f);
+        tris[4 * t + 0] = make_float4(p0[0], p0[1], p0[2], as_float((int)mf));
+        tris[4 * t + 1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.f);
+        tris[4 * t + 2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.f);
         nrms[3 * t + 0] = make_float4(p0[3], p0[4], p0[5], 0.f);
         nrms[3 * t + 1] = make_float4(p1[3], p1[4], p1[5], 0.f);
         nrms[3 * t + 2] = make_float4(p2[3], p2[4], p2[5], 0.f);

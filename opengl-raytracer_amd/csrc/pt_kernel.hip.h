@@ -21,7 +21,7 @@
 //            ref >= 0 -> fork index, ref < 0 -> ~triangle (leaf nodes are folded into their
 //            parent's ref: the reference never tests a leaf's own box, raytrace.frag:310-331),
 //            ref == REF_ABSENT -> no child.  The root's own box is in DevScene.
-//   tris   : 3 x float4 per triangle {v0.xyz, materialId} {v1-v0, -} {v2-v0, -}
+//   tris   : 4 x float4 (64 B, the shape of a fork record) per triangle {v0.xyz, materialId} {v1-v0, -} {v2-v0, -} {-}
 //   nrms   : 3 x float4 per triangle {n0} {n1} {n2}   (read once per ray, for the closest hit only)
 //   mats   : 3 x float4 per material {emission.xyz, type} {param0.xyz, alpha.x} {param1.xyz, alpha.y}
 //   lights : 6 x float4 per light triangle {v0, materialId} {v1} {v2} {n0} {n1} {n2}
@@ -236,13 +236,17 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
     // (pure IEEE arithmetic; a NaN/inf produced behind a failed test is masked by the predicate).
     const int cur = T.cur;
     bool need_pop = true;
-    if (cur >= 0) {
-        const float4 *N = sc.forks + 4 * (size_t)cur;
-        const float4 L0 = N[0], L1 = N[1], R0 = N[2], R1 = N[3];
-        const int l = __float_as_int(L0.w), r = __float_as_int(L1.w);
+    // Fork and triangle records have the same 64-byte shape and are fetched by the SAME four loads, issued
+    // before the wave splits into its fork lanes and its triangle lanes: in a mixed wave (3 of 4 iterations)
+    // the two arms then cost one memory round trip, not two.
+    const bool is_fork = cur >= 0;
+    const float4 *N = is_fork ? sc.forks + 4 * (size_t)cur : sc.tris + 4 * (size_t)(~cur);
+    const float4 A = N[0], B = N[1], C = N[2], D = N[3];
+    if (is_fork) {
+        const int l = __float_as_int(A.w), r = __float_as_int(B.w);
         float t0l, t0r;
-        const bool bl = box_pass(L0, L1, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0l);
-        const bool br = box_pass(R0, R1, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0r);
+        const bool bl = box_pass(A, B, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0l);
+        const bool br = box_pass(C, D, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0r);
         // leaf children are never box-tested (:310-331); an absent child never passes
         const bool pl = l != REF_ABSENT && (l < 0 || bl);
         const bool pr = r != REF_ABSENT && (r < 0 || br);
@@ -253,24 +257,22 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
         T.cur = pr ? r : l;
         need_pop = !(pl || pr);
     } else {
-        // leaf :310-331 with intersect(Ray, Triangle) :226-257
+        // leaf :310-331 with intersect(Ray, Triangle) :226-257; A = {v0, material}, B = v1-v0, C = v2-v0
         const int t = ~cur;
-        float4 T0 = sc.tris[3 * t];
-        const float4 T1 = sc.tris[3 * t + 1], T2 = sc.tris[3 * t + 2];
-        const float tx = T.ox - T0.x, ty = T.oy - T0.y, tz = T.oz - T0.z;
-        const float px = T.dy * T2.z - T.dz * T2.y;
-        const float py = T.dz * T2.x - T.dx * T2.z;
-        const float pz = T.dx * T2.y - T.dy * T2.x;
-        const float det = dot3(T1.x, T1.y, T1.z, px, py, pz);
+        const float tx = T.ox - A.x, ty = T.oy - A.y, tz = T.oz - A.z;
+        const float px = T.dy * C.z - T.dz * C.y;
+        const float py = T.dz * C.x - T.dx * C.z;
+        const float pz = T.dx * C.y - T.dy * C.x;
+        const float det = dot3(B.x, B.y, B.z, px, py, pz);
         const float U = dot3(tx, ty, tz, px, py, pz);
         const float inv = 1.0f / det;
         const float u = U * inv;
-        const float qx = ty * T1.z - tz * T1.y;
-        const float qy = tz * T1.x - tx * T1.z;
-        const float qz = tx * T1.y - ty * T1.x;
+        const float qx = ty * B.z - tz * B.y;
+        const float qy = tz * B.x - tx * B.z;
+        const float qz = tx * B.y - ty * B.x;
         const float V = dot3(T.dx, T.dy, T.dz, qx, qy, qz);
         const float v = V * inv;
-        const float tt = dot3(T2.x, T2.y, T2.z, qx, qy, qz) * inv;
+        const float tt = dot3(C.x, C.y, C.z, qx, qy, qz) * inv;
         const bool hit = !(-PT_EPS < det && det < PT_EPS) && !(u < 0.0f || 1.0f < u) &&
                          !(v < 0.0f || 1.0f < inv * (U + V)) &&  // u+v>1 is evaluated as inv*(U+V)>1
                          !(PT_EPS >= tt);
@@ -389,7 +391,7 @@ DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &
         if (h.tri < 0) break;  // miss: nothing is added and the loop ends (:497-499)
 
         // normal of the closest hit (:254), computed once instead of per candidate
-        const float4 T0 = sc.tris[3 * h.tri];
+        const float4 T0 = sc.tris[4 * h.tri];
         float nx, ny, nz;
         {
             const float4 N0 = sc.nrms[3 * h.tri], N1 = sc.nrms[3 * h.tri + 1], N2 = sc.nrms[3 * h.tri + 2];
