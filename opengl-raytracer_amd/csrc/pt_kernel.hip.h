@@ -1075,8 +1075,12 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
             if (exhausted) break;
             continue;
         }
+        // two traversal steps per trip through the loop: halves the refill bookkeeping (ballots, branches) on
+        // the latency-critical instruction stream; a lane that finishes on the first step idles for one step
         if (active) {
-            if (trav_step<true>(a.sc, stack, T)) {
+            bool fin = trav_step<true>(a.sc, stack, T);
+            if (!fin) fin = trav_step<true>(a.sc, stack, T);
+            if (fin) {
                 active = false;
                 unsaved = true;
             }
