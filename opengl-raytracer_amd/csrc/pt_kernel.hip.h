@@ -1009,6 +1009,9 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 // workgroup waiting for its last long ray idles only itself, while the other resident workgroups are
 // at other stages -- the global pipeline of variant C loses ~300 us per trip to that wait, nine times
 // a frame.  One kernel launch per frame.  State lives in the same HBM arrays as variant C.
+#ifndef GLRTX_STEPS_PER_TRIP
+#define GLRTX_STEPS_PER_TRIP 2
+#endif
 constexpr int kWgPathsMax = 1024;  // pixels per workgroup block: 1024 (16 tiles of 8x8) when the image is large enough to
                                    // give every resident workgroup >= 2 blocks, else 512 or 256 (chosen by the host)
 #ifndef GLRTX_WGWF_WAVES
@@ -1075,11 +1078,13 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
             if (exhausted) break;
             continue;
         }
-        // two traversal steps per trip through the loop: halves the refill bookkeeping (ballots, branches) on
+        // GLRTX_STEPS_PER_TRIP traversal steps per trip through the loop: cuts the refill bookkeeping (ballots, branches) on
         // the latency-critical instruction stream; a lane that finishes on the first step idles for one step
         if (active) {
             bool fin = trav_step<true>(a.sc, stack, T);
-            if (!fin) fin = trav_step<true>(a.sc, stack, T);
+#pragma unroll
+            for (int k = 1; k < GLRTX_STEPS_PER_TRIP; k++)
+                if (!fin) fin = trav_step<true>(a.sc, stack, T);
             if (fin) {
                 active = false;
                 unsaved = true;
