@@ -233,17 +233,19 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
                 }
                 ref_of[n] = (int)(forks.size() / 4);
                 for (int k = 0; k < 4; k++) forks.push_back(make_float4(0.f, 0.f, 0.f, as_float(REF_ABSENT)));
+                // forks are numbered in the order the traversal meets them (children.y first, raytrace.frag:299-307):
+                // the first-visited child's record directly follows its parent's
                 f.stage = 1;
-                int l;
-                if (!child(n, 0, l)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
-                if (l >= 0) { st.push_back({l, 0}); }
+                int r;
+                if (!child(n, 1, r)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
+                if (r >= 0) { st.push_back({r, 0}); }
                 continue;
             }
             if (f.stage == 1) {
                 f.stage = 2;
-                int r;
-                if (!child(n, 1, r)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
-                if (r >= 0) { st.push_back({r, 0}); }
+                int l;
+                if (!child(n, 0, l)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
+                if (l >= 0) { st.push_back({l, 0}); }
                 continue;
             }
             int l, r;
@@ -326,15 +328,13 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
     else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_wgwf<false>, kBlockThreads, lds));
     if (per_cu < 1) per_cu = 1;
     if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));  // occupancy experiments
-    // block size: as large as possible while there are still >= 1.5 blocks per resident workgroup
-    // (measured on the headline frame: 1024 -> 4.2 ms, 512 -> 4.6 ms at 1080p; at 1/8 of the rows 256 -> 1.5 ms, 1024 -> 2.9 ms)
+    // paths kept alive per workgroup: 1024, less when the image cannot give every resident workgroup that many pixels
     const int resident = per_cu * c->n_cu;
     int block_paths = kWgPathsMax;
-    while (block_paths > 256 && 2 * ((total + block_paths - 1) / block_paths) < (size_t)3 * resident) block_paths /= 2;
+    while (block_paths > 256 && total < (size_t)resident * block_paths) block_paths /= 2;
     if (const char *v = std::getenv("GLRTX_BLOCK_PATHS")) { const int x = std::atoi(v); if (x == 256 || x == 512 || x == 1024) block_paths = x; }
     w.block_paths = block_paths;
-    const int n_blocks = (int)((total + block_paths - 1) / block_paths);
-    const int grid = std::max(1, std::min(resident, n_blocks));
+    const int grid = std::max(1, std::min(resident, (int)((total + block_paths - 1) / block_paths)));
     if ((rc = ensure(c, c->wfQ, (size_t)grid * 6 * kWgPathsMax * sizeof(unsigned)))) return rc;  // per-workgroup queues
     HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -697,6 +697,12 @@ int glrtx_debug_trav_hist(unsigned long long out[16]) {
 #endif
 
 #ifdef GLRTX_PHASE_STATS
+int glrtx_debug_trip_log(unsigned out[16 * 64 * 4]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trip_log), 16 * 64 * 16) != hipSuccess) return GLRTX_EDEVICE;
+    static unsigned z[16 * 64 * 4];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trip_log), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
+    return GLRTX_OK;
+}
 int glrtx_debug_phase_cycles(unsigned long long out[8]) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return GLRTX_EDEVICE;
     unsigned long long z[8] = {0};

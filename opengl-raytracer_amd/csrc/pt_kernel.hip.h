@@ -1127,6 +1127,9 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
 // Diagnostic build only: shader-clock cycles thread 0 of every workgroup spent per phase
 // [0] generate, [1] traverse (own work), [2] wait at the barrier after traverse, [3] shade, [4] wait after shade
 __device__ unsigned long long g_phase_cycles[8];
+// per-trip log of every 64th workgroup: {n_rays, n_paths, traverse+wait cycles, shade+wait cycles}, 64 trips at most;
+// entry 0 = {trips, start cycle (low 32 bits), end cycle, blocks taken}
+__device__ uint4 g_trip_log[16][64];
 #define PH_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define PH_ADD(i, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], (t1) - (t0)); } while (0)
 #else
@@ -1144,68 +1147,91 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     unsigned char *pl = lds_raw + (size_t)mat_f4 * sizeof(float4);
     int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
-    unsigned *ctl = reinterpret_cast<unsigned *>(pl);            // 0: block, 1: ray head, 2..3: nRays[2], 4..5: nPaths[2]
+    unsigned *ctl = reinterpret_cast<unsigned *>(pl);            // 0: first new tile, 1: ray head, 2..3: nRays[2], 4..5: nPaths[2], 6: new tiles, 7: frame exhausted
     unsigned *rayQ = wg_queues + (size_t)blockIdx.x * 6 * kWgPathsMax;  // [2][2*block_paths]
     unsigned *pathQ = rayQ + 4 * w.block_paths;                          // [2][block_paths]
     if (a.sc.mats_in_lds)
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
 
     const int kWgPaths = w.block_paths;
-    const int n_blocks = (w.total + kWgPaths - 1) / kWgPaths;
+    const int n_tiles = w.total >> 6;  // 8x8-pixel tiles (64 consecutive tile-order ids each)
     unsigned rays = 0;
-
+#ifdef GLRTX_PHASE_STATS
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.x / 64 < 16)
+        g_trip_log[blockIdx.x / 64][0].y = (unsigned)(__builtin_amdgcn_s_memtime() >> 4);
+#endif
+    if (threadIdx.x == 0) { ctl[2] = 0u; ctl[3] = 0u; ctl[4] = 0u; ctl[5] = 0u; ctl[7] = 0u; }
+    int cur = 0;
+    __syncthreads();  // materials staged, ctl initialised
     for (;;) {
-        __syncthreads();  // previous block fully retired (and, first time, materials staged)
+        // ---- top-up: the workgroup keeps up to kWgPaths paths alive; free slots are refilled with new pixels, whole tiles
+        // at a time, from the frame's tile counter (one atomic per workgroup and trip).  Every trip therefore runs on a
+        // (nearly) full set of rays, and workgroups finish together when the counter runs out.
+        PH_STAMP(pg0);
         if (threadIdx.x == 0) {
-            ctl[0] = atomicAdd(work_counter, 1u);
-            ctl[2] = 0u; ctl[3] = 0u; ctl[4] = 0u; ctl[5] = 0u;
+            const int want = (kWgPaths - (int)ctl[4 + cur]) >> 6;
+            int base = 0, got = 0;
+            if (want > 0 && ctl[7] == 0u) {
+                base = (int)atomicAdd(work_counter, (unsigned)want);
+                got = base < n_tiles ? (want < n_tiles - base ? want : n_tiles - base) : 0;
+                if (base + want >= n_tiles) ctl[7] = 1u;  // the frame has no more tiles
+            }
+            ctl[0] = (unsigned)base; ctl[6] = (unsigned)got;
         }
         __syncthreads();
-        const int blk = (int)ctl[0];
-        if (blk >= n_blocks) break;
-
-        // ---- generate: sample 0 of the block's pixels; queues are filled densely with skip markers
-        PH_STAMP(pg0);
-        for (int k = threadIdx.x; k < kWgPaths; k += kBlockThreads) {
-            const int id = blk * kWgPaths + k;
-            const bool go = wf_generate_one(a, w, id);
-            rayQ[k] = go ? (unsigned)id * 2u : WF_INVALID;
-            pathQ[k] = go ? (unsigned)id : WF_INVALID;
+        {
+            const int got = (int)ctl[6] * 64, id0 = (int)ctl[0] * 64;
+            const int nr = (int)ctl[2 + cur], np = (int)ctl[4 + cur];
+            unsigned *rq_w = rayQ + cur * 2 * kWgPaths + nr;
+            unsigned *pq_w = pathQ + cur * kWgPaths + np;
+            for (int k = threadIdx.x; k < got; k += kBlockThreads) {
+                const int id = id0 + k;
+                const bool go = wf_generate_one(a, w, id);  // pixels outside the image leave skip markers
+                rq_w[k] = go ? (unsigned)id * 2u : WF_INVALID;
+                pq_w[k] = go ? (unsigned)id : WF_INVALID;
+            }
+            __syncthreads();  // everyone has read the counts
+            if (threadIdx.x == 0) { ctl[2 + cur] = (unsigned)(nr + got); ctl[4 + cur] = (unsigned)(np + got); ctl[1] = 0u; }
         }
-        if (threadIdx.x == 0) { ctl[2] = kWgPaths; ctl[4] = kWgPaths; }
-        int cur = 0;
+        __syncthreads();  // queues of `cur` complete, state stores visible in the workgroup
         PH_STAMP(pg1);
         PH_ADD(0, pg0, pg1);
+        const int n_rays = (int)ctl[2 + cur], n_paths = (int)ctl[4 + cur];
+        if (n_paths == 0) break;  // nothing alive and nothing left to take
+        const unsigned *rq = rayQ + cur * 2 * kWgPaths;
+        const unsigned *pq = pathQ + cur * kWgPaths;
 
-        for (;;) {
-            if (threadIdx.x == 0) ctl[1] = 0u;  // ray head of this trip
-            __syncthreads();                    // queues of `cur` complete, state stores visible in the workgroup
-            const int n_rays = (int)ctl[2 + cur], n_paths = (int)ctl[4 + cur];
-            if (n_paths == 0) break;
-            const unsigned *rq = rayQ + cur * 2 * kWgPaths;
-            const unsigned *pq = pathQ + cur * kWgPaths;
+        // ---- traverse phase: lanes pull rays; a lane whose ray is finished takes the next one
+        PH_STAMP(pt0);
+        wg_traverse_phase(a, w, stack, rq, n_rays, &ctl[1], rays);
+        PH_STAMP(pt1);
+        __syncthreads();  // all hit records of this trip written
+        PH_STAMP(pt2);
+        PH_ADD(1, pt0, pt1);
+        PH_ADD(2, pt1, pt2);
 
-            // ---- traverse phase: lanes pull rays; a lane whose ray is finished takes the next one
-            PH_STAMP(pt0);
-            wg_traverse_phase(a, w, stack, rq, n_rays, &ctl[1], rays);
-            PH_STAMP(pt1);
-            __syncthreads();  // all hit records of this trip written
-            PH_STAMP(pt2);
-            PH_ADD(1, pt0, pt1);
-            PH_ADD(2, pt1, pt2);
-
-            // ---- shade phase: the block's live paths; appends go to the other queue pair
-            wg_shade_phase(a, w, lds_mats, pq, n_paths, rayQ + (cur ^ 1) * 2 * kWgPaths, pathQ + (cur ^ 1) * kWgPaths,
-                           &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)]);
-            PH_STAMP(ps1);
-            __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
-            PH_STAMP(ps2);
-            PH_ADD(3, pt2, ps1);
-            PH_ADD(4, ps1, ps2);
-            if (threadIdx.x == 0) { ctl[2 + cur] = 0u; ctl[4 + cur] = 0u; }
-            cur ^= 1;
+        // ---- shade phase: the live paths; appends go to the other queue pair
+        wg_shade_phase(a, w, lds_mats, pq, n_paths, rayQ + (cur ^ 1) * 2 * kWgPaths, pathQ + (cur ^ 1) * kWgPaths,
+                       &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)]);
+        PH_STAMP(ps1);
+        __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
+        PH_STAMP(ps2);
+        PH_ADD(3, pt2, ps1);
+        PH_ADD(4, ps1, ps2);
+#ifdef GLRTX_PHASE_STATS
+        if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.x / 64 < 16) {
+            uint4 *lg = g_trip_log[blockIdx.x / 64];
+            const unsigned n = lg[0].x + 1u;
+            if (n < 64u) { lg[n] = make_uint4((unsigned)n_rays, (unsigned)n_paths, (unsigned)(pt2 - pt0), (unsigned)(ps2 - pt2)); lg[0].x = n; }
         }
+#endif
+        if (threadIdx.x == 0) { ctl[2 + cur] = 0u; ctl[4 + cur] = 0u; }
+        cur ^= 1;
     }
+#ifdef GLRTX_PHASE_STATS
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.x / 64 < 16)
+        g_trip_log[blockIdx.x / 64][0].z = (unsigned)(__builtin_amdgcn_s_memtime() >> 4);
+#endif
     flush_rays<COUNT_RAYS>(a, rays);
 }
 

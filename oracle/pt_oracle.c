@@ -345,6 +345,71 @@ static void exp_ordered(const pt_scene *sc, v3 o, v3 d, float *t_out, int *tri_o
 }
 #endif
 
+#ifdef PT_ORDERED_EXPERIMENT
+/* EXPERIMENT 2: step counts of the device traversal (children's boxes in the parent, reference order, t0 recheck at pop)
+ * under two record layouts.  g_exp[8] fork steps, [9] leaf steps (current layout: one 64-B record per step);
+ * [10] fetches with 128-B "slot" records (a fork + its first-visited child inline), [11] inline visits saved. */
+static unsigned char *g_kind = NULL; /* 1 = processed inline from the parent's slot */
+static void exp_build_kind(const pt_scene *sc) {
+    g_kind = (unsigned char *)calloc((size_t)sc->n_nodes + 1, 1);
+    int *st = (int *)malloc(sizeof(int) * (size_t)(sc->n_nodes + 2));
+    int sp = 0;
+    st[sp++] = 0;
+    while (sp) {
+        int n = st[--sp];
+        const float *c = sc->bvh + 9 * (size_t)n + 6;
+        if (c[2] >= 0.0f) continue;
+        int x = (int)c[0], y = (int)c[1];
+        if (c[1] >= 0.0f) { g_kind[y] = g_kind[n] ? 0 : 1; st[sp++] = y; }
+        if (c[0] >= 0.0f) { g_kind[x] = 0; st[sp++] = x; }
+    }
+    free(st);
+}
+static void exp_slot_sim(const pt_scene *sc, v3 o, v3 d) {
+    struct { int node; float t0; } st[128];
+    int sp = 0;
+    float tHit = PT_INFTY, ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const int nvt = sc->n_vert * 5;
+    unsigned long long nf = 0, nl = 0, fetch = 0, inl = 0;
+    int pass; float t0 = exp_box(sc, 0, o, ix, iy, iz, tHit, &pass);
+    if (sc->bvh[8] >= 0.0f) { pass = 1; t0 = -PT_INFTY; }
+    if (pass) { st[sp].node = 0; st[sp].t0 = t0; sp++; }
+    while (sp) {
+        sp--;
+        int n = st[sp].node;
+        if (!(tHit >= st[sp].t0)) continue;
+        for (;;) {
+            const float *c = sc->bvh + 9 * (size_t)n + 6;
+            if (g_kind[n]) inl++; else fetch++;
+            if (c[2] < 0.0f) {
+                nf++;
+                int kid[2] = {(int)c[0], (int)c[1]}, ok[2] = {0, 0}; float kt[2] = {-PT_INFTY, -PT_INFTY};
+                for (int k = 0; k < 2; k++) {
+                    if (!(c[k] >= 0.0f)) continue;
+                    if (sc->bvh[9 * (size_t)kid[k] + 8] >= 0.0f) ok[k] = 1;
+                    else kt[k] = exp_box(sc, kid[k], o, ix, iy, iz, tHit, &ok[k]);
+                }
+                if (ok[0]) { st[sp].node = kid[0]; st[sp].t0 = kt[0]; sp++; }
+                if (ok[1]) { n = kid[1]; continue; }  /* first-visited child: no stack round trip */
+                break;
+            } else {
+                nl++;
+                int index = (int)c[2]; float tr[4]; fetch4(sc->tri, sc->n_tri, index, tr);
+                int i0 = (int)tr[0] * 5, i1 = (int)tr[1] * 5, i2 = (int)tr[2] * 5;
+                v3 v0 = fetch3(sc->vert, nvt, i0), v1 = fetch3(sc->vert, nvt, i1), v2 = fetch3(sc->vert, nvt, i2), z = {0, 0, 0}, n3;
+                float dist = pt_tri(o, d, v0, v1, v2, z, z, z, 0, &n3);
+                tHit = FMIN(tHit, dist);
+                break;
+            }
+        }
+    }
+    _Pragma("omp atomic") g_exp[8] += nf;
+    _Pragma("omp atomic") g_exp[9] += nl;
+    _Pragma("omp atomic") g_exp[10] += fetch;
+    _Pragma("omp atomic") g_exp[11] += inl;
+}
+#endif
+
 /* fresnelConductor :158-178; association order as compiled [order] */
 INL float pt_fresnel1(float c2, float s2, float cosI, float eta, float k) {
     float eta2 = eta * eta, k2 = k * k;
@@ -373,6 +438,7 @@ INL float pt_ggx(float hx, float hy, float hz, float ax, float ay) {
     do {                                                                                            \
         float t2_; int tri2_; unsigned v2_ = 0;                                                     \
         exp_ordered(sc, O, D, &t2_, &tri2_, &v2_);                                                  \
+        exp_slot_sim(sc, O, D);                                                                     \
         int bad_ = !((t2_ == (IS).tHit || (t2_ != t2_ && (IS).tHit != (IS).tHit)) && tri2_ == (IS).tri); \
         _Pragma("omp atomic") g_exp[0] += 1;                                                        \
         if (bad_) { _Pragma("omp atomic") g_exp[1] += 1; }                                          \
@@ -712,6 +778,7 @@ uint64_t pt_oracle_render(const pt_scene *sc, const pt_params *pr, float *accum,
                           int y0, int y1, int threads) {
 #ifdef PT_ORDERED_EXPERIMENT
     exp_build_rank(sc);
+    exp_build_kind(sc);
 #endif
     return pt_render_rows(sc, pr, accum, pitch_bytes / sizeof(float), y0, y1, threads);
 }
