@@ -335,6 +335,8 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
     if (const char *v = std::getenv("GLRTX_BLOCK_PATHS")) { const int x = std::atoi(v); if (x == 256 || x == 512 || x == 1024) block_paths = x; }
     w.block_paths = block_paths;
     const int grid = std::max(1, std::min(resident, (int)((total + block_paths - 1) / block_paths)));
+    w.gss_div = 4 * grid;
+    if (const char *v = std::getenv("GLRTX_GSS_DIV")) w.gss_div = std::max(0, std::atoi(v));
     if ((rc = ensure(c, c->wfQ, (size_t)grid * 6 * kWgPathsMax * sizeof(unsigned)))) return rc;  // per-workgroup queues
     HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));

@@ -241,6 +241,9 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
     // the two arms then cost one memory round trip, not two.
     const bool is_fork = cur >= 0;
     const float4 *N = is_fork ? sc.forks + 4 * (size_t)cur : sc.tris + 4 * (size_t)(~cur);
+    // (Left to the compiler these become dwordx3 loads plus, on the fork arm, one more dwordx3 and two dword loads of the
+    // refs: 56 bytes per fork lane, 36 per triangle lane.  Forcing four dwordx4 loads issued together was measured 9 %
+    // SLOWER -- the cost of a step grows with the bytes returned per lane, about 0.017 ms of frame time per byte.)
     const float4 A = N[0], B = N[1], C = N[2], D = N[3];
     if (is_fork) {
         const int l = __float_as_int(A.w), r = __float_as_int(B.w);
@@ -880,6 +883,7 @@ struct WfArgs {
     int tiles8_x;
     int refill_min;   // refill a traversal wave once this many lanes are idle
     int block_paths;  // pixels per workgroup block (multiple of 256, <= kWgPathsMax)
+    int gss_div;      // top-up requests are capped at ceil(tiles left / gss_div); 0 = uncapped
 };
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
 constexpr unsigned WF_FINISHING = 1u << 29;  // the path has ended; only that shadow ray is awaited
@@ -1169,8 +1173,15 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // (nearly) full set of rays, and workgroups finish together when the counter runs out.
         PH_STAMP(pg0);
         if (threadIdx.x == 0) {
-            const int want = (kWgPaths - (int)ctl[4 + cur]) >> 6;
+            int want = (kWgPaths - (int)ctl[4 + cur]) >> 6;
             int base = 0, got = 0;
+            if (want > 0 && ctl[7] == 0u && w.gss_div > 0) {
+                // guided self-scheduling: towards the end of the frame take smaller helpings, so that the last tiles are
+                // spread over all workgroups and they finish together (the peek is racy; it only sizes the request)
+                const int left = n_tiles - (int)__hip_atomic_load(work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int share = left > 0 ? (left + w.gss_div - 1) / w.gss_div : 1;
+                want = want < share ? want : share;
+            }
             if (want > 0 && ctl[7] == 0u) {
                 base = (int)atomicAdd(work_counter, (unsigned)want);
                 got = base < n_tiles ? (want < n_tiles - base ? want : n_tiles - base) : 0;
