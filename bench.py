@@ -7,10 +7,15 @@
 
 One "step" = one frame: one pass of the path-tracing hot path (raytrace.frag::main on every pixel of
 the 1920x1080 image, u_maxDepth = 8, 1 sample/pixel, fresh u_seed per frame) accumulated into the
-resident float4 framebuffer.  With N > 1 ranks the image rows are sharded in interleaved 16-row
-stripes (one process per GPU, global pixel coordinates, no data-path collective) and every frame ends
-with the RCCL all_gather of the finished rows ("gather the framebuffer"), inside the timed region.
-One frame is ONE launch of the render kernel (pt_render_wgwf, the workgroup-local wavefront).
+resident float4 framebuffer.  Frames are issued --frames-in-flight B at a time (default 8) through
+glrtx_render_frames: ONE launch of the render kernel (pt_render_wgwf, the workgroup-local wavefront)
+covers B consecutive frames and adds their samples to the accumulator in frame order, so the result
+is bit-identical to B separate launches (tests/test_gpu_parity.py) while the GPU stays full across
+frame boundaries.  K steps are therefore ceil(K / B) launches; B = 1 gives one launch per frame, and
+the JSON line also carries that figure ("one_launch_per_frame"), measured after the timed region.
+With N > 1 ranks the image rows are sharded in interleaved 16-row stripes (one process per GPU,
+global pixel coordinates, no data-path collective) and every launch ends with the RCCL all_gather of
+the finished rows ("gather the framebuffer"), inside the timed region.
 Scene and accumulators are resident in HBM before timing starts.  Rays are counted exactly (one
 execution of intersect() = one ray) by an untimed pass over the same seeds with the
 counting variant of the kernel; the timed launches use the clean kernel.
@@ -62,7 +67,9 @@ def main():
     ap.add_argument("--config", default="headline", help="headline | c2 | c3 | c4 | c5 (parity-test configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline sample")
-    ap.add_argument("--no-gather", action="store_true", help="skip the per-frame framebuffer gather (N > 1)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the framebuffer gather (N > 1)")
+    ap.add_argument("--no-single", action="store_true", help="skip the extra one-launch-per-frame measurement (profiling runs)")
+    ap.add_argument("--frames-in-flight", type=int, default=8, help="frames per launch of the render kernel (1 = one launch per frame)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -102,11 +109,21 @@ def main():
     def seed(f):
         return host.frame_seed(f)
 
-    def frame(f, gather=True):
-        dev.render(dict(params, seed=seed(f)))
-        if world > 1 and gather and not args.no_gather:
-            return dist.gather_rows(accum, H, STRIPE)
-        return accum
+    B = max(1, args.frames_in_flight)
+
+    def run(f0, f1, gather=True, per_launch=None):
+        """Frames [f0, f1): per_launch frames per launch of the render kernel, the framebuffer gathered after every launch."""
+        per_launch = per_launch or B
+        img = accum
+        for g in range(f0, f1, per_launch):
+            n = min(per_launch, f1 - g)
+            if n == 1:
+                dev.render(dict(params, seed=seed(g)))
+            else:
+                dev.render_frames(params, [seed(g + i) for i in range(n)])
+            if world > 1 and gather and not args.no_gather:
+                img = dist.gather_rows(accum, H, STRIPE)
+        return img
 
     def barrier():
         torch.cuda.synchronize()
@@ -117,8 +134,7 @@ def main():
     # ---- exact ray count for the timed frames (untimed, counting kernel variant)
     dev.count_rays(True)
     dev.reset_stats()
-    for f in range(args.warmup, args.warmup + args.steps):
-        frame(f, gather=False)
+    run(args.warmup, args.warmup + args.steps, gather=False)
     dev.sync()
     rays_local = int(dev.stats().rays)
     dev.count_rays(False)
@@ -126,15 +142,13 @@ def main():
     dev.reset_stats()
 
     # ---- warm-up, then K timed frames
-    for f in range(args.warmup):
-        frame(f)
+    run(0, args.warmup)
     dev.sync()
     dev.reset_stats()
     barrier()
     t0 = time.perf_counter()
     dev.timer_begin()
-    for f in range(args.warmup, args.warmup + args.steps):
-        img = frame(f)
+    img = run(args.warmup, args.warmup + args.steps)
     ev_ms = dev.timer_end()
     barrier()
     t1 = time.perf_counter()
@@ -142,9 +156,23 @@ def main():
     st = dev.stats()
     del img
 
+    # ---- the same frames once more, one launch per frame (reported next to the headline figure)
+    single = None
+    if B > 1 and not args.no_single:
+        n1 = min(args.steps, 20)
+        run(0, 2, per_launch=1)
+        barrier()
+        t2 = time.perf_counter()
+        run(args.warmup, args.warmup + n1, per_launch=1)
+        barrier()
+        single = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device="cuda")
+        if world > 1:
+            td.all_reduce(single, op=td.ReduceOp.MAX)
+        single = float(single.item()) / n1
+
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     rays = torch.tensor([rays_local], dtype=torch.int64, device="cuda")
-    kern_ms = torch.tensor([st.kernel_ms_total / max(st.launches, 1)], dtype=torch.float64, device="cuda")
+    kern_ms = torch.tensor([st.kernel_ms_total / max(st.kernel_launches, 1)], dtype=torch.float64, device="cuda")
     if world > 1:
         td.all_reduce(elapsed, op=td.ReduceOp.MAX)
         td.all_reduce(rays, op=td.ReduceOp.SUM)
@@ -153,7 +181,9 @@ def main():
 
     # ---- roofline of the render kernel (per launch, per GPU): algorithmic bytes / measured launch duration
     scene_b = scenes.scene_bytes(scene)
-    algo_bytes = len(ys) * W * 32 + scene_b  # 16 B read + 16 B write per owned pixel + one read of the compact scene
+    frames_per_launch = st.launches / max(st.kernel_launches, 1)
+    # per frame 16 B read + 16 B write per owned pixel, times the frames one launch covers, + one read of the compact scene
+    algo_bytes = int(len(ys) * W * 32 * frames_per_launch) + scene_b
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
     pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
@@ -165,7 +195,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "kernel": "pt_render_wgwf<false>", "kernel_ms_avg": round(kernel_ms, 4),
-                "algorithmic_bytes_per_launch": algo_bytes,
+                "algorithmic_bytes_per_launch": algo_bytes, "frames_per_launch": round(frames_per_launch, 3),
                 "note": "branchy scalar-FP32 traversal: VALU/latency-bound, not HBM-bound (DESIGN.md section 6)"}
 
     cpu_baseline = None
@@ -201,7 +231,10 @@ def main():
             "config": {"workload": f"{args.config}: {n_tri} triangles (BVH {scene['bvh_kind']}), {W}x{H}, "
                                    f"u_maxDepth={params['max_depth']}, {params['n_samples']} spp/frame",
                        "partition": f"{world} x interleaved {STRIPE}-row stripes" + ("" if world == 1 else
-                                    (", no gather" if args.no_gather else ", RCCL all_gather of the framebuffer every frame")),
+                                    (", no gather" if args.no_gather else ", RCCL all_gather of the framebuffer after every launch")),
+                       "frames_in_flight": B,
+                       "one_launch_per_frame": None if single is None else
+                           {"ms_per_step": round(single * 1e3, 4), "value": round(total_rays / args.steps / single / 1e6, 3)},
                        "rays_per_frame": round(total_rays / args.steps, 1),
                        "mpaths_per_s": round(W * H * params["n_samples"] * args.steps / elapsed_s / 1e6, 3),
                        "event_ms_per_step": round(ev_ms / args.steps, 4)},

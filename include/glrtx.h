@@ -51,7 +51,7 @@ extern "C" {
 #define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
 #define GLRTX_ENOMEM (-5)
 
-#define GLRTX_ABI_VERSION 1
+#define GLRTX_ABI_VERSION 2
 
 typedef struct glrtx_ctx glrtx_ctx;
 
@@ -71,9 +71,12 @@ typedef struct glrtx_stats {
     uint64_t rays;          /* executions of intersect(Ray, out Intersection) since last clear/reset_stats;
                                only counted by launches made while ray counting is enabled */
     uint64_t paths;         /* pixel samples traced (owned pixels * n_samples per launch) */
-    uint64_t launches;      /* glrtx_render calls */
-    double kernel_ms_total; /* sum of per-launch device time (HIP events on the ctx stream) */
-    float kernel_ms_last;
+    uint64_t launches;      /* frames rendered: glrtx_render calls + frames of glrtx_render_frames calls */
+    uint64_t kernel_launches; /* launches of the render kernel (one per glrtx_render / glrtx_render_frames call) */
+    double kernel_ms_total; /* sum over launches of the RENDER kernel's device time (HIP events on the ctx stream) */
+    double accumulate_ms_total; /* sum of the plane-accumulation passes that follow glrtx_render_frames launches */
+    float kernel_ms_last;   /* render kernel of the last launch */
+    int32_t frames_last;    /* frames covered by the last launch */
     int32_t width, height;  /* full image */
     int32_t owned_rows;     /* rows of this ctx's partition */
     int32_t stack_entries;  /* traversal stack entries the uploaded BVH needs */
@@ -130,6 +133,12 @@ int glrtx_count_rays(glrtx_ctx *ctx, int enable);
 
 /* Asynchronous: accumulates n_samples new samples per owned pixel (read-modify-write). */
 int glrtx_render(glrtx_ctx *ctx, const glrtx_params *params);
+/* Frames in flight.  Same result, bit for bit, as n_frames consecutive glrtx_render calls whose params differ only
+ * in `seed` (seeds_xy = n_frames pairs; params->seed is ignored) -- the reference's accumulation loop with a static
+ * camera, window.cpp:226-252 -- but issued as ONE launch, so that a small image (or one rank's share of it) still fills
+ * the GPU and the tail of one frame overlaps the next.  Every sample is kept in its own plane and the planes are added
+ * to the accumulator in frame order.  stats.launches counts n_frames.  Asynchronous; seeds_xy is copied. */
+int glrtx_render_frames(glrtx_ctx *ctx, const glrtx_params *params, const float *seeds_xy, int n_frames);
 int glrtx_sync(glrtx_ctx *ctx);
 
 /* Copy the owned rows (owned_rows x width float4) to host memory; implies a sync. */

@@ -35,18 +35,21 @@ struct glrtx_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;      // per-launch
+    hipEvent_t ev0 = nullptr, evm = nullptr, ev1 = nullptr;  // per launch: start, render kernel done, all done
     hipEvent_t tm0 = nullptr, tm1 = nullptr;      // glrtx_timer_*
     std::string err;
 
     DevBuf forks, tris, nrms, mats, lights, accum_own, counter, rgba8, work;
     DevBuf wfA[6], wfH, wfHS, wfQ;  // wavefront path state + per-workgroup queues (variant 2)
+    DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
     int variant = 2;          // 0 = tile megakernel, 1 = persistent megakernel with path regeneration, 2 = workgroup-local wavefront
     int n_cu = 256;
     int resident_wg[2] = {0, 0};  // persistent grid size per COUNT_RAYS instantiation (0 = not yet queried)
     DevScene sc{};
     bool have_scene = false;
     int n_tri = 0, n_fork = 0, n_mat = 0, n_light = 0;
+    const float *frames_seeds = nullptr;  // set only inside glrtx_render_frames
+    int frames_n = 1;
 
     int width = 0, height = 0;
     int rank = 0, world = 1, stripe = 16;
@@ -106,10 +109,13 @@ inline float as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
 int fold_launch_time(glrtx_ctx *c) {
     if (!c->launch_pending) return GLRTX_OK;
     HIP_TRY(c, hipEventSynchronize(c->ev1));
-    float ms = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    float ms = 0.f, ms2 = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->evm));   // render kernel
+    HIP_TRY(c, hipEventElapsedTime(&ms2, c->evm, c->ev1));  // plane accumulation (frames in flight), else ~0
     c->st.kernel_ms_last = ms;
     c->st.kernel_ms_total += ms;
+    c->st.accumulate_ms_total += ms2;
+    c->st.kernel_launches++;
     c->launch_pending = false;
     return GLRTX_OK;
 }
@@ -295,16 +301,26 @@ int ensure(glrtx_ctx *c, DevBuf &b, size_t bytes) {
     return GLRTX_OK;
 }
 
-// Variant 2: one persistent launch; every workgroup runs the wavefront trips of its own pixel blocks.
-int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
-    (void)p;
+// Variant 2: one persistent launch; every workgroup runs the wavefront trips of the pixels it takes from the frame's tile counter.
+// n_frames > 1 ("frames in flight"): the launch covers n_frames consecutive frames that differ only in u_seed (seeds_xy);
+// the per-sample planes are added to the accumulator in frame order afterwards, so the result is bit-identical to
+// n_frames separate launches.
+int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const float *seeds_xy, int n_frames) {
     const int tiles8_x = (c->width + 7) / 8, tiles8_y = (c->owned_rows + 7) / 8;
     const size_t total = (size_t)tiles8_x * tiles8_y * 64;
     if (total * 2 >= (size_t)INT32_MAX) return fail(c, GLRTX_EINVAL, "image too large for the wgwf variant");
+    int shift = 31;
+    if (n_frames > 1) {
+        shift = 6;
+        while (((size_t)1 << shift) < total) shift++;
+        if (((size_t)n_frames << shift) * 2 >= (size_t)INT32_MAX)
+            return fail(c, GLRTX_EINVAL, "glrtx_render_frames: %d frames of %zu pixels exceed the 32-bit path id space", n_frames, total);
+    }
+    const size_t ids = n_frames > 1 ? ((size_t)n_frames << shift) : total;
     int rc;
-    for (auto &b : c->wfA) if ((rc = ensure(c, b, total * sizeof(float4)))) return rc;
-    if ((rc = ensure(c, c->wfH, total * sizeof(float4)))) return rc;
-    if ((rc = ensure(c, c->wfHS, total * sizeof(float2)))) return rc;
+    for (auto &b : c->wfA) if ((rc = ensure(c, b, ids * sizeof(float4)))) return rc;
+    if ((rc = ensure(c, c->wfH, ids * sizeof(float4)))) return rc;
+    if ((rc = ensure(c, c->wfHS, ids * sizeof(float2)))) return rc;
     WfArgs w;
     std::memset(&w, 0, sizeof w);
     w.A0 = (float4 *)c->wfA[0].p; w.A1 = (float4 *)c->wfA[1].p; w.A2 = (float4 *)c->wfA[2].p;
@@ -314,6 +330,19 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
     w.tiles8_x = tiles8_x;
     w.refill_min = kRefillMin;
     if (const char *v = std::getenv("GLRTX_REFILL_MIN")) w.refill_min = std::max(1, std::min(64, std::atoi(v)));
+    w.n_frames = n_frames;
+    w.frame_shift = shift;
+    w.pid_mask = shift >= 31 ? INT32_MAX : (1 << shift) - 1;
+    w.tiles_per_frame = (int)(total >> 6);
+    const size_t plane_f4 = (size_t)a.pitch_f4 * (size_t)c->owned_rows;
+    const int n_planes = n_frames * p->n_samples;
+    if (n_frames > 1) {
+        if ((rc = ensure(c, c->wfSeeds, (size_t)n_frames * sizeof(float2)))) return rc;
+        if ((rc = ensure(c, c->wfPlanes, (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4)))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->wfSeeds.p, seeds_xy, (size_t)n_frames * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+        w.seeds = (const float2 *)c->wfSeeds.p;
+        w.planes = (float4 *)c->wfPlanes.p;
+    }
 
     const int lds = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
                     16 * (int)sizeof(unsigned);
@@ -328,13 +357,14 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
     else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_wgwf<false>, kBlockThreads, lds));
     if (per_cu < 1) per_cu = 1;
     if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));  // occupancy experiments
-    // paths kept alive per workgroup: 1024, less when the image cannot give every resident workgroup that many pixels
+    // paths kept alive per workgroup: 1024, less when the launch cannot give every resident workgroup that many pixels
     const int resident = per_cu * c->n_cu;
+    const size_t work = total * (size_t)n_frames;
     int block_paths = kWgPathsMax;
-    while (block_paths > 256 && total < (size_t)resident * block_paths) block_paths /= 2;
+    while (block_paths > 256 && work < (size_t)resident * block_paths) block_paths /= 2;
     if (const char *v = std::getenv("GLRTX_BLOCK_PATHS")) { const int x = std::atoi(v); if (x == 256 || x == 512 || x == 1024) block_paths = x; }
     w.block_paths = block_paths;
-    const int grid = std::max(1, std::min(resident, (int)((total + block_paths - 1) / block_paths)));
+    const int grid = std::max(1, (int)std::min<size_t>((size_t)resident, (work + block_paths - 1) / block_paths));
     w.gss_div = 4 * grid;
     if (const char *v = std::getenv("GLRTX_GSS_DIV")) w.gss_div = std::max(0, std::atoi(v));
     if ((rc = ensure(c, c->wfQ, (size_t)grid * 6 * kWgPathsMax * sizeof(unsigned)))) return rc;  // per-workgroup queues
@@ -343,9 +373,17 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p) {
     if (ci) hipLaunchKernelGGL(pt_render_wgwf<true>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (unsigned *)c->wfQ.p);
     else hipLaunchKernelGGL(pt_render_wgwf<false>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (unsigned *)c->wfQ.p);
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->evm, c->stream));
+    if (n_frames > 1 && n_planes > 0) {
+        const dim3 g((c->width + 63) / 64, (c->owned_rows + 3) / 4);
+        hipLaunchKernelGGL(accumulate_planes_kernel, g, dim3(256), 0, c->stream, a.accum, a.pitch_f4, c->width, c->owned_rows,
+                           (const float4 *)c->wfPlanes.p, n_planes);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->launch_pending = true;
-    c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples;
+    c->st.frames_last = n_frames;
+    c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples * (uint64_t)n_frames;
     return GLRTX_OK;
 }
 
@@ -377,7 +415,7 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
     if (!c) return fail(nullptr, GLRTX_ENOMEM, "out of host memory");
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->evm)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipEventCreate(&c->tm0)) != hipSuccess || (e = hipEventCreate(&c->tm1)) != hipSuccess ||
         (e = hipMalloc(&c->counter.p, sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(c->counter.p, 0, sizeof(unsigned long long))) != hipSuccess ||
@@ -400,8 +438,9 @@ void glrtx_destroy(glrtx_ctx *c) {
     dev_free(c->forks); dev_free(c->tris); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights);
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
     for (auto &b : c->wfA) dev_free(b);
-    dev_free(c->wfH); dev_free(c->wfHS); dev_free(c->wfQ);
+    dev_free(c->wfH); dev_free(c->wfHS); dev_free(c->wfQ); dev_free(c->wfSeeds); dev_free(c->wfPlanes);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->evm) (void)hipEventDestroy(c->evm);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->tm0) (void)hipEventDestroy(c->tm0);
     if (c->tm1) (void)hipEventDestroy(c->tm1);
@@ -542,6 +581,27 @@ int glrtx_count_rays(glrtx_ctx *c, int enable) {
     return GLRTX_OK;
 }
 
+int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_xy, int n_frames) {
+    if (!c || !p) return GLRTX_EINVAL;
+    if (n_frames < 0 || (n_frames > 0 && !seeds_xy)) return fail(c, GLRTX_EINVAL, "glrtx_render_frames: bad seeds/n_frames");
+    if (n_frames == 0) return GLRTX_OK;
+    if (n_frames == 1 || c->variant != 2) {  // the megakernel variants have no frames-in-flight form: one launch per frame
+        for (int f = 0; f < n_frames; f++) {
+            glrtx_params q = *p;
+            q.seed[0] = seeds_xy[2 * f]; q.seed[1] = seeds_xy[2 * f + 1];
+            if (int rc = glrtx_render(c, &q)) return rc;
+        }
+        return GLRTX_OK;
+    }
+    c->frames_seeds = seeds_xy;
+    c->frames_n = n_frames;
+    const int rc = glrtx_render(c, p);
+    c->frames_seeds = nullptr;
+    c->frames_n = 1;
+    if (rc == GLRTX_OK) c->st.launches += (uint64_t)(n_frames - 1);
+    return rc;
+}
+
 int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     if (!c || !p) return GLRTX_EINVAL;
     if (!c->have_scene) return fail(c, GLRTX_EINVAL, "glrtx_render: no scene uploaded");
@@ -577,7 +637,7 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     if ((size_t)a.pitch_f4 * (size_t)c->owned_rows >= (size_t)INT32_MAX)
         return fail(c, GLRTX_EINVAL, "accumulator too large for 32-bit pixel offsets");
 
-    if (c->variant == 2) return launch_wgwf(c, a, p);
+    if (c->variant == 2) return launch_wgwf(c, a, p, c->frames_seeds, c->frames_n);
     if (c->variant == 1) {
         // persistent kernel: grid = what is resident at once (occupancy x CUs), capped by the work available
         const int ci = c->count_rays ? 1 : 0;
@@ -612,8 +672,10 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     }
     }
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->evm, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->launch_pending = true;
+    c->st.frames_last = 1;
     c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples;
     return GLRTX_OK;
 }
@@ -678,7 +740,7 @@ int glrtx_reset_stats(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
     if (int rc = glrtx_sync(c)) return rc;
     HIP_TRY(c, hipMemset(c->counter.p, 0, sizeof(unsigned long long)));
-    c->st.rays = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_ms_total = 0.0; c->st.kernel_ms_last = 0.f;
+    c->st.rays = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f;
     return GLRTX_OK;
 }
 

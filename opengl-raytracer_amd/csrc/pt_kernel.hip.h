@@ -884,6 +884,17 @@ struct WfArgs {
     int refill_min;   // refill a traversal wave once this many lanes are idle
     int block_paths;  // pixels per workgroup block (multiple of 256, <= kWgPathsMax)
     int gss_div;      // top-up requests are capped at ceil(tiles left / gss_div); 0 = uncapped
+    // Frames in flight (glrtx_render_frames): n_frames consecutive frames that differ only in u_seed run in ONE launch.
+    // Path ids are (frame << frame_shift) | tile-order pixel id; every finished sample is stored in its own plane
+    // (frame * n_samples + sample) and accumulate_planes_kernel adds the planes to the accumulator in frame order, so
+    // the sums are formed in exactly the order consecutive launches would form them.  n_frames == 1: samples are
+    // added to the accumulator directly and seeds/planes are unused.
+    const float2 *seeds;  // u_seed of every frame
+    float4 *planes;       // [n_frames * n_samples][owned_rows][pitch_f4] of {min(L, 100), -}
+    int n_frames;
+    int frame_shift;      // log2 of the id stride between frames (31 for a single frame)
+    int pid_mask;         // (1 << frame_shift) - 1
+    int tiles_per_frame;  // total >> 6
 };
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
 constexpr unsigned WF_FINISHING = 1u << 29;  // the path has ended; only that shadow ray is awaited
@@ -891,40 +902,62 @@ constexpr unsigned WF_INVALID = 0xFFFFFFFFu; // queue entry to skip
 constexpr int kRefillMin = 16;               // refill a traversal wave once this many lanes are idle
 
 DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lrow) {
-    const int t = id >> 6, k = id & 63;
+    const int pid = id & w.pid_mask;
+    const int t = pid >> 6, k = pid & 63;
     lx = (t % w.tiles8_x) * 8 + (k & 7);
     lrow = (t / w.tiles8_x) * 8 + (k >> 3);
     return lx < a.width && lrow < a.owned_rows;
 }
 
+// u_seed of the frame a path belongs to
+DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, int id) {
+    return w.n_frames > 1 ? w.seeds[id >> w.frame_shift] : make_float2(a.seed_x, a.seed_y);
+}
+
+// A finished sample: radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609).
+// Single frame: read-modify-write of the accumulator.  Frames in flight: the value goes to the sample's plane.
+DEV void wf_add_sample(const KernelArgs &a, const WfArgs &w, int id, int lx, int lrow, unsigned sample, float Lx, float Ly, float Lz) {
+    if (w.n_frames > 1) {
+        const size_t slot = (size_t)(id >> w.frame_shift) * (size_t)a.n_samples + sample;
+        w.planes[(slot * (size_t)a.owned_rows + (size_t)lrow) * (size_t)a.pitch_f4 + lx] =
+            make_float4(fmin_c(Lx, 100.0f), fmin_c(Ly, 100.0f), fmin_c(Lz, 100.0f), 1.0f);
+    } else {
+        float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
+        float4 acc = *px;
+        acc.x = acc.x + fmin_c(Lx, 100.0f);
+        acc.y = acc.y + fmin_c(Ly, 100.0f);
+        acc.z = acc.z + fmin_c(Lz, 100.0f);
+        acc.w = acc.w + 1.0f;
+        *px = acc;
+    }
+}
+
 // Start the pixel's next sample(s): camera ray -> state; returns true if a ray must be traced.
 // With u_maxDepth <= 0 a sample is finished as soon as it starts (main() still draws its jitter).
-DEV bool wf_start(const KernelArgs &a, Rng &rng, float fcx, float fcy, Path &P, unsigned &sample, float4 *px) {
+DEV bool wf_start(const KernelArgs &a, const WfArgs &w, int id, int lx, int lrow, Rng &rng, float fcx, float fcy, Path &P, unsigned &sample) {
     for (;;) {
         if ((int)sample >= a.n_samples) return false;
         camera_ray(a, rng, fcx, fcy, P);
         if (a.max_depth > 0) return true;
-        float4 acc = *px;
-        acc.x = acc.x + 0.0f; acc.y = acc.y + 0.0f; acc.z = acc.z + 0.0f;  // min(L, 100) of L = 0
-        acc.w = acc.w + 1.0f;
-        *px = acc;
+        wf_add_sample(a, w, id, lx, lrow, sample, 0.0f, 0.0f, 0.0f);  // min(L, 100) of L = 0
         sample++;
     }
 }
 
-// Start pixel `id` (tile-order id): seed its RNG, draw sample 0's camera ray, store the path state.
+// Start path `id` (frame | tile-order pixel id): seed its RNG, draw sample 0's camera ray, store the path state.
 // Returns true if a ray was queued (false: outside the image, or nothing to trace).
 DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id) {
     int lx, lrow;
     bool go = false;
-    Rng rng = {0.f, 0.f, a.seed_x, a.seed_y};
+    const float2 sd = wf_seed(a, w, id);
+    Rng rng = {0.f, 0.f, sd.x, sd.y};
     Path P;
     unsigned sample = 0;
-    if (id < w.total && wf_pixel(a, w, id, lx, lrow)) {
+    if ((id & w.pid_mask) < w.total && wf_pixel(a, w, id, lx, lrow)) {
         const int gy = local_row_to_y(a, lrow);
         const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
         rng.x = fcx / (float)a.width; rng.y = fcy / (float)a.height;  // :567
-        go = wf_start(a, rng, fcx, fcy, P, sample, a.accum + (size_t)lrow * a.pitch_f4 + lx);
+        go = wf_start(a, w, id, lx, lrow, rng, fcx, fcy, P, sample);
     }
     if (go) {
         w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
@@ -943,9 +976,9 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     wf_pixel(a, w, (int)id, lx, lrow);
     const int gy = local_row_to_y(a, lrow);
     const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
-    float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
     const float4 s0 = w.A0[id], s1 = w.A1[id], s2 = w.A2[id], s3 = w.A3[id];
-    Rng rng = {s0.w, s1.w, a.seed_x, a.seed_y};
+    const float2 sd = wf_seed(a, w, (int)id);
+    Rng rng = {s0.w, s1.w, sd.x, sd.y};
     const unsigned meta = __float_as_uint(s2.w);
     unsigned sample = (meta >> 8) & 0xFFFFFu;
     Path P;
@@ -973,15 +1006,9 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         ended = sh.ended && !sh.has_shadow;  // with a shadow ray in flight the sample closes next trip
     }
     if (ended) {
-        // radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609)
-        float4 acc = *px;
-        acc.x = acc.x + fmin_c(P.Lx, 100.0f);
-        acc.y = acc.y + fmin_c(P.Ly, 100.0f);
-        acc.z = acc.z + fmin_c(P.Lz, 100.0f);
-        acc.w = acc.w + 1.0f;
-        *px = acc;
+        wf_add_sample(a, w, (int)id, lx, lrow, sample, P.Lx, P.Ly, P.Lz);
         sample++;
-        push_ext = wf_start(a, rng, fcx, fcy, P, sample, px);  // the pixel's next sample, if any
+        push_ext = wf_start(a, w, (int)id, lx, lrow, rng, fcx, fcy, P, sample);  // the pixel's next sample, if any
         if (push_ext) {
             w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
             w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
@@ -1158,7 +1185,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
 
     const int kWgPaths = w.block_paths;
-    const int n_tiles = w.total >> 6;  // 8x8-pixel tiles (64 consecutive tile-order ids each)
+    const int n_tiles = w.tiles_per_frame * w.n_frames;  // 8x8-pixel tiles (64 consecutive tile-order ids each), frame-major
     unsigned rays = 0;
 #ifdef GLRTX_PHASE_STATS
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.x / 64 < 16)
@@ -1191,12 +1218,13 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         }
         __syncthreads();
         {
-            const int got = (int)ctl[6] * 64, id0 = (int)ctl[0] * 64;
+            const int got = (int)ctl[6] * 64, tile0 = (int)ctl[0];
             const int nr = (int)ctl[2 + cur], np = (int)ctl[4 + cur];
             unsigned *rq_w = rayQ + cur * 2 * kWgPaths + nr;
             unsigned *pq_w = pathQ + cur * kWgPaths + np;
             for (int k = threadIdx.x; k < got; k += kBlockThreads) {
-                const int id = id0 + k;
+                const int g = tile0 + (k >> 6), f = g / w.tiles_per_frame;
+                const int id = (f << w.frame_shift) | ((g - f * w.tiles_per_frame) * 64 + (k & 63));
                 const bool go = wf_generate_one(a, w, id);  // pixels outside the image leave skip markers
                 rq_w[k] = go ? (unsigned)id * 2u : WF_INVALID;
                 pq_w[k] = go ? (unsigned)id : WF_INVALID;
@@ -1244,6 +1272,25 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         g_trip_log[blockIdx.x / 64][0].z = (unsigned)(__builtin_amdgcn_s_memtime() >> 4);
 #endif
     flush_rays<COUNT_RAYS>(a, rays);
+}
+
+// ------------------------------------------------------------------------------------------ frames in flight
+// Adds the sample planes of one glrtx_render_frames launch to the accumulator, plane by plane in frame (and sample)
+// order: per pixel the same chain of float additions that consecutive single-frame launches perform.
+// Bandwidth-bound: 16 B per plane and pixel in, one 16-B read-modify-write of the accumulator.
+__global__ __launch_bounds__(256) void accumulate_planes_kernel(float4 *accum, int pitch_f4, int width, int rows, const float4 *planes,
+                                                                int n_planes) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= rows) return;
+    const size_t at = (size_t)y * pitch_f4 + x, plane = (size_t)rows * pitch_f4;
+    float4 acc = accum[at];
+    for (int k = 0; k < n_planes; k++) {
+        const float4 v = planes[(size_t)k * plane + at];
+        acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z;
+        acc.w = acc.w + 1.0f;
+    }
+    accum[at] = acc;
 }
 
 // ------------------------------------------------------------------------------------------ resolve

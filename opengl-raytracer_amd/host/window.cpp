@@ -23,6 +23,7 @@ namespace glrt {
 Window::Window() {
     if (const char *e = std::getenv("GLRT_FRAMES")) frameLimit_ = std::atoi(e);
     if (const char *e = std::getenv("GLRT_MAX_DEPTH")) maxDepth_ = std::atoi(e);
+    if (const char *e = std::getenv("GLRT_FRAMES_IN_FLIGHT")) setFramesInFlight(std::atoi(e));
 }
 
 Window::~Window() {
@@ -48,11 +49,16 @@ void Window::mainloop(const std::shared_ptr<Scene> &scene_, double fps) {
         scene->nodes.empty() ? nullptr : &scene->nodes[0].bboxMin[0], scene->nodes.size()));
     resize(scene->width, scene->height);
     initialize();
-    for (int i = 0; i < frameLimit_; i++) {
+    // The reference presents (and saves) every frame; when only the final image is wanted the frames of a static
+    // camera go to the device several at a time -- same pixels, bit for bit, fewer and fuller launches.
+    const int step = (saveEveryFrame_ && !output_.empty()) ? 1 : framesInFlight_;
+    for (int i = 0; i < frameLimit_; i += step) {
+        const int n = frameLimit_ - i < step ? frameLimit_ - i : step;
         const auto t0 = std::chrono::steady_clock::now();
-        render();
+        if (n == 1) render();
+        else renderFrames(n);
         GLRTX_CHECK(glrtx_sync(ctx_));
-        lastMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        lastMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n;
         if (saveEveryFrame_ && !output_.empty()) saveCurrentFrame(output_, true);  // window.cpp:164
     }
     if (!saveEveryFrame_ && !output_.empty() && frameLimit_ > 0) saveCurrentFrame(output_, true);
@@ -60,19 +66,32 @@ void Window::mainloop(const std::shared_ptr<Scene> &scene_, double fps) {
 
 void Window::initialize() { GLRTX_CHECK(glrtx_count_rays(ctx_, 1)); }
 
-void Window::render() {
-    // window.cpp:230-243: the per-frame uniforms
-    glrtx_params p;
+void Window::frameParams(glrtx_params &p) const {
+    // window.cpp:230-243: the per-frame uniforms (u_seed is filled in by the caller)
     float cam[16];
     glrt_mat4_mul(scene->viewM, scene->modelM, cam);
     if (glrt_mat4_inverse(cam, p.c2w) != GLRT_HOST_OK || glrt_mat4_inverse(scene->projM, p.s2c) != GLRT_HOST_OK)
         GLRT_FatalError("camera matrix is singular");
     p.aperture = scene->apertureRadius;
     p.focal = scene->focalLength;
-    glrt_frame_seed(frame_++, p.seed);
+    p.seed[0] = p.seed[1] = 0.0f;
     p.n_samples = samplesPerFrame_;
     p.max_depth = maxDepth_;
+}
+
+void Window::render() {
+    glrtx_params p;
+    frameParams(p);
+    glrt_frame_seed(frame_++, p.seed);
     GLRTX_CHECK(glrtx_render(ctx_, &p));  // window.cpp:290, the draw that runs the path tracer
+}
+
+void Window::renderFrames(int n) {
+    glrtx_params p;
+    frameParams(p);
+    std::vector<float> seeds(2 * (size_t)n);
+    for (int f = 0; f < n; f++) glrt_frame_seed(frame_++, &seeds[2 * (size_t)f]);
+    GLRTX_CHECK(glrtx_render_frames(ctx_, &p, seeds.data(), n));
 }
 
 void Window::resizeDefault(int w, int h) {

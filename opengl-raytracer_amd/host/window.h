@@ -12,6 +12,7 @@
 #include "scene.h"
 
 struct glrtx_ctx;
+struct glrtx_params;
 
 namespace glrt {
 
@@ -33,17 +34,22 @@ public:
     void setOutput(const std::string &file, bool everyFrame = false) { output_ = file; saveEveryFrame_ = everyFrame; }
     void setDevice(int hipDevice) { device_ = hipDevice; }
     void setFirstFrame(unsigned f) { frame_ = f; }
+    // Frames issued per launch of the render kernel (glrtx_render_frames; bit-identical to one launch per frame).
+    // Used when no image is written between frames and render() is not overridden per frame; GLRT_FRAMES_IN_FLIGHT.
+    void setFramesInFlight(int n) { framesInFlight_ = n < 1 ? 1 : n; }
     double lastFrameMs() const { return lastMs_; }
     unsigned long long raysTraced() const;
 
 protected:
     virtual void initialize();
     virtual void render();
+    virtual void renderFrames(int n);  // n consecutive frames with a static camera, one launch
     virtual void resize(int width, int height) { resizeDefault(width, height); }
     virtual void mouse(const MouseEvent &) {}
     virtual void keyboard(int, int, int, int) {}
 
 private:
+    void frameParams(struct ::glrtx_params &p) const;
     void resizeDefault(int width, int height);
     void resetBuffer();
     void saveCurrentFrame(const std::string &filename, bool overwrite = true) const;
@@ -51,7 +57,7 @@ private:
     glrtx_ctx *ctx_ = nullptr;
     int device_ = -1;
     int width_ = 0, height_ = 0;
-    int frameLimit_ = 16, maxDepth_ = 16, samplesPerFrame_ = 1;
+    int frameLimit_ = 16, maxDepth_ = 16, samplesPerFrame_ = 1, framesInFlight_ = 8;
     unsigned frame_ = 0;
     bool saveEveryFrame_ = false;
     std::string output_ = "output.png";

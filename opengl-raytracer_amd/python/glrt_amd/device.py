@@ -22,16 +22,16 @@ class Params(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("launches", C.c_uint64),
-                ("kernel_ms_total", C.c_double), ("kernel_ms_last", C.c_float), ("width", C.c_int32),
-                ("height", C.c_int32), ("owned_rows", C.c_int32), ("stack_entries", C.c_int32),
-                ("lds_bytes", C.c_int32), ("n_tri", C.c_int32), ("n_fork", C.c_int32), ("n_mat", C.c_int32),
-                ("n_light", C.c_int32)]
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("launches", C.c_uint64), ("kernel_launches", C.c_uint64),
+                ("kernel_ms_total", C.c_double), ("accumulate_ms_total", C.c_double), ("kernel_ms_last", C.c_float),
+                ("frames_last", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("owned_rows", C.c_int32),
+                ("stack_entries", C.c_int32), ("lds_bytes", C.c_int32), ("n_tri", C.c_int32), ("n_fork", C.c_int32),
+                ("n_mat", C.c_int32), ("n_light", C.c_int32)]
 
 
 EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_error", "glrtx_upload_scene",
            "glrtx_resize", "glrtx_clear", "glrtx_set_partition", "glrtx_local_row_to_y", "glrtx_bind_accum",
-           "glrtx_set_stream", "glrtx_set_variant", "glrtx_count_rays", "glrtx_render", "glrtx_sync", "glrtx_read_accum",
+           "glrtx_set_stream", "glrtx_set_variant", "glrtx_count_rays", "glrtx_render", "glrtx_render_frames", "glrtx_sync", "glrtx_read_accum",
            "glrtx_accum_device_ptr", "glrtx_resolve_rgba8", "glrtx_get_stats", "glrtx_reset_stats",
            "glrtx_timer_begin", "glrtx_timer_end"]
 
@@ -68,6 +68,7 @@ def lib():
         L.glrtx_set_variant.argtypes = [vp, C.c_int]
         L.glrtx_count_rays.argtypes = [vp, C.c_int]
         L.glrtx_render.argtypes = [vp, C.POINTER(Params)]
+        L.glrtx_render_frames.argtypes = [vp, C.POINTER(Params), fp, C.c_int]
         L.glrtx_sync.argtypes = [vp]
         L.glrtx_read_accum.argtypes = [vp, vp, C.c_size_t]
         L.glrtx_accum_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -160,6 +161,12 @@ class Device:
     def render(self, params):
         p = params if isinstance(params, Params) else make_params(params)
         self._ck(self.L.glrtx_render(self.h, C.byref(p)))
+
+    def render_frames(self, params, seeds):
+        """Frames in flight: len(seeds) consecutive frames that differ only in u_seed, as one launch."""
+        p = params if isinstance(params, Params) else make_params(dict(params, seed=(0.0, 0.0)) if "seed" not in params else params)
+        sd = _f32(np.asarray(seeds, np.float32).reshape(-1, 2))
+        self._ck(self.L.glrtx_render_frames(self.h, C.byref(p), _fp(sd), sd.shape[0]))
 
     def sync(self):
         self._ck(self.L.glrtx_sync(self.h))

@@ -25,14 +25,16 @@ def _c1_builder(subdiv=1):
     return b
 
 
-def test_glrt_main_renders_json_scene_like_the_binding(tmp_path, gpu_device):
+@pytest.mark.parametrize("in_flight", [1, 2, 8])
+def test_glrt_main_renders_json_scene_like_the_binding(tmp_path, gpu_device, in_flight):
     from PIL import Image
     w, h, depth, frames = 96, 64, 4, 3
     b = _c1_builder()
     js = scenes.export_json_obj(b, tmp_path, w, h, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0)
     out = tmp_path / "out.png"
     r = subprocess.run([str(PKG / "lib" / "glrt_main"), "-i", str(js), "-s", "4", "--max-depth", str(depth), "--frames",
-                        str(frames), "--out", str(out)], capture_output=True, text=True, timeout=120)
+                        str(frames), "--frames-in-flight", str(in_flight), "--out", str(out)], capture_output=True, text=True,
+                       timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "#triangle: 244" in r.stdout and "Save:" in r.stdout
     img = np.asarray(Image.open(out))

@@ -212,3 +212,68 @@ def test_all_kernel_variants_bit_identical(gpu_device, variant):
             assert_bit_equal(acc, ref, f"variant {variant} {cfg}")
     finally:
         d.set_variant(2)
+
+
+def _seeds(n, start=0):
+    return [host.frame_seed(start + f) for f in range(n)]
+
+
+@pytest.mark.parametrize("cfg,kw,n_frames", [
+    ("c1", dict(width=50, height=38, max_depth=5, n_samples=1, subdiv=1), 3),    # NPOT, smaller than one workgroup block
+    ("c1", dict(width=96, height=64, max_depth=4, n_samples=3, subdiv=1), 4),    # several samples per frame: planes = frames x samples
+    ("c2", dict(width=320, height=180, max_depth=8, n_samples=1, subdiv=2), 5),
+    ("c2", dict(width=64, height=64, max_depth=0, n_samples=2, subdiv=1), 3),    # u_maxDepth 0: samples finish as they start
+])
+def test_frames_in_flight_equal_consecutive_frames_and_oracle(gpu_device, cfg, kw, n_frames):
+    """glrtx_render_frames(n) == n consecutive glrtx_render calls == the oracle run frame after frame, bitwise,
+    including the ray count."""
+    from oracle import pt_oracle
+    d = gpu_device
+    scene, params = scenes.CONFIGS[cfg](**kw)
+    seeds = _seeds(n_frames)
+    seq, st_seq = gpu_render(d, scene, params, frames=seeds)
+    d.clear(); d.reset_stats(); d.count_rays(True)
+    d.render_frames(params, seeds); d.sync()
+    bat, st = d.read_accum(), d.stats()
+    assert_bit_equal(bat, seq, f"{cfg} frames in flight vs consecutive launches")
+    assert st.rays == st_seq.rays and st.launches == n_frames
+    ref, ref_rays = None, 0
+    for sd in seeds:
+        ref, n = pt_oracle.render(scene, dict(params, seed=sd), accum=ref)
+        ref_rays += n
+    assert st.rays == ref_rays
+    assert_bit_equal(bat, ref, f"{cfg} frames in flight vs oracle")
+
+
+def test_frames_in_flight_full_size_partitions_and_accumulate_on_top(gpu_device):
+    """Headline size: 8 frames in one launch on top of an already accumulated frame, whole image and as a 3-rank
+    partition; both must equal 9 consecutive launches."""
+    d = gpu_device
+    scene, params = scenes.config_headline()
+    seeds = _seeds(9)
+    seq, _ = gpu_render(d, scene, params, frames=seeds, count_rays=False)
+    d.clear(); d.render(dict(params, seed=seeds[0])); d.render_frames(params, seeds[1:]); d.sync()
+    assert_bit_equal(d.read_accum(), seq, "1 + 8 frames in flight")
+    assert np.all(seq[..., 3] == 9.0)
+    try:
+        stitched = np.zeros_like(seq)
+        for rank in range(3):
+            d.set_partition(rank, 3, 16); d.resize(params["width"], params["height"])
+            d.render_frames(params, seeds); d.sync()
+            stitched[d.local_rows_y()] = d.read_accum()
+        assert_bit_equal(stitched, seq, "frames in flight, 3-rank partition")
+    finally:
+        d.set_partition(0, 1, 16)
+
+
+def test_frames_in_flight_other_variants_fall_back_to_consecutive_launches(gpu_device):
+    d = gpu_device
+    scene, params = scenes.config_c1(width=64, height=48, max_depth=3, subdiv=1)
+    seeds = _seeds(3)
+    want, _ = gpu_render(d, scene, params, frames=seeds)
+    try:
+        for v in (0, 1):
+            d.set_variant(v); d.clear(); d.render_frames(params, seeds); d.sync()
+            assert_bit_equal(d.read_accum(), want, f"variant {v} render_frames")
+    finally:
+        d.set_variant(2)
