@@ -7,7 +7,7 @@
 
 One "step" = one frame: one pass of the path-tracing hot path (raytrace.frag::main on every pixel of
 the 1920x1080 image, u_maxDepth = 8, 1 sample/pixel, fresh u_seed per frame) accumulated into the
-resident float4 framebuffer.  Frames are issued --frames-in-flight B at a time (default 8) through
+resident float4 framebuffer.  Frames are issued --frames-in-flight B at a time (default 16) through
 glrtx_render_frames: ONE launch of the render kernel (pt_render_wgwf, the workgroup-local wavefront)
 covers B consecutive frames and adds their samples to the accumulator in frame order, so the result
 is bit-identical to B separate launches (tests/test_gpu_parity.py) while the GPU stays full across
@@ -62,14 +62,14 @@ def effective_cpus(omp_max: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="headline", help="headline | c2 | c3 | c4 | c5 (parity-test configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-gather", action="store_true", help="skip the framebuffer gather (N > 1)")
     ap.add_argument("--no-single", action="store_true", help="skip the extra one-launch-per-frame measurement (profiling runs)")
-    ap.add_argument("--frames-in-flight", type=int, default=8, help="frames per launch of the render kernel (1 = one launch per frame)")
+    ap.add_argument("--frames-in-flight", type=int, default=16, help="frames per launch of the render kernel (1 = one launch per frame)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -362,7 +362,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     const size_t work = total * (size_t)n_frames;
     int block_paths = kWgPathsMax;
     while (block_paths > 256 && work < (size_t)resident * block_paths) block_paths /= 2;
-    if (const char *v = std::getenv("GLRTX_BLOCK_PATHS")) { const int x = std::atoi(v); if (x == 256 || x == 512 || x == 1024) block_paths = x; }
+    if (const char *v = std::getenv("GLRTX_BLOCK_PATHS")) { const int x = std::atoi(v); if (x >= 256 && x <= kWgPathsMax && (x & (x - 1)) == 0) block_paths = x; }
     w.block_paths = block_paths;
     const int grid = std::max(1, (int)std::min<size_t>((size_t)resident, (work + block_paths - 1) / block_paths));
     w.gss_div = 4 * grid;

@@ -1043,7 +1043,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 #ifndef GLRTX_STEPS_PER_TRIP
 #define GLRTX_STEPS_PER_TRIP 2
 #endif
-constexpr int kWgPathsMax = 1024;  // pixels per workgroup block: 1024 (16 tiles of 8x8) when the image is large enough to
+constexpr int kWgPathsMax = 4096;  // pixels per workgroup block: 1024 (16 tiles of 8x8) when the image is large enough to
                                    // give every resident workgroup >= 2 blocks, else 512 or 256 (chosen by the host)
 #ifndef GLRTX_WGWF_WAVES
 #define GLRTX_WGWF_WAVES 4

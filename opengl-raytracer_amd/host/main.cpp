@@ -19,7 +19,7 @@ static void usage(const char *exe) {
                 "      --max-depth D       u_maxDepth (default 16, the reference shader's default)\n"
                 "      --spp N             samples per pixel per frame, u_nSamples (default 1 as window.cpp:239)\n"
                 "      --frames F          frames to accumulate before exiting (default 16)\n"
-                "      --frames-in-flight B frames per launch of the render kernel (default 8; same pixels as 1)\n"
+                "      --frames-in-flight B frames per launch of the render kernel (default 16; same pixels as 1)\n"
                 "      --out file.png      tonemapped output (default output.png, written after the last frame)\n"
                 "      --device G          HIP device ordinal (default: current)\n", exe);
 }

@@ -57,7 +57,7 @@ private:
     glrtx_ctx *ctx_ = nullptr;
     int device_ = -1;
     int width_ = 0, height_ = 0;
-    int frameLimit_ = 16, maxDepth_ = 16, samplesPerFrame_ = 1, framesInFlight_ = 8;
+    int frameLimit_ = 16, maxDepth_ = 16, samplesPerFrame_ = 1, framesInFlight_ = 16;
     unsigned frame_ = 0;
     bool saveEveryFrame_ = false;
     std::string output_ = "output.png";
