@@ -6,6 +6,7 @@
  *
  * Reference interfaces replaced:
  *   glrt_bvh_build_sah      BVH::construct / constructRec   src/core/bvh.cpp:59-160
+ *   glrt_bvh_build_lbvh     same role, linear BVH for large scenes (BASELINE config 5)
  *   glrt_bvh_build_chain    (no counterpart: expresses BASELINE config "brute force, no BVH"
  *                            in the same node format)
  *   glrt_look_at            glm::lookAt                     src/core/scene.cpp:93
@@ -47,6 +48,10 @@ size_t glrt_bvh_node_count(size_t n_tri);
 int glrt_bvh_build_sah(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
                        int *max_depth_out);
 int glrt_bvh_build_chain(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out);
+/* Linear BVH (30-bit Morton order + Karras hierarchy).  Same output, bit for bit, as the GPU builder
+ * glrtx_build_lbvh (include/glrtx.h); internal node i at index i, leaves after them in Morton order. */
+int glrt_bvh_build_lbvh(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
+                        int *max_depth_out);
 
 void glrt_look_at(const float eye[3], const float center[3], const float up[3], float out[16]);
 void glrt_perspective(float fovy_deg, float aspect, float z_near, float z_far, float out[16]);

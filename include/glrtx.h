@@ -9,6 +9,7 @@
  *   glrtx_upload_scene               the five TextureBuffer(size, fmt, usage) + setData(ptr) uploads
  *                                    src/core/scene.cpp:254-269, src/core/texture_buffer.h:8-12
  *                                    (byte layouts unchanged: scene.h:16-35, trimesh.h:15-25, bvh.h:84-100)
+ *   glrtx_build_lbvh                 BVH::construct, src/core/bvh.cpp:59-160 (device-side linear BVH instead)
  *   glrtx_resize                     Window::resize -> resetBuffer (accumulators re-created, cleared)
  *                                    src/core/window.cpp:324-335, :366-381
  *   glrtx_clear                      glClear of the accumulation targets on reset (same lines)
@@ -106,6 +107,13 @@ int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t
                       int *stack_entries_out);
 
 /* Full image size; (re)allocates and clears this ctx's accumulator rows. */
+/* Linear BVH built on the device (30-bit Morton order, Karras hierarchy, bottom-up fit), returned in the wire format
+ * glrtx_upload_scene takes: nodes_out = (2*n_tri-1)*9 floats, root = node 0.  Takes the place of the reference's CPU
+ * builder BVH::construct (src/core/bvh.cpp:59-160) for large scenes; identical, bit for bit, to glrt_bvh_build_lbvh
+ * (glrt_host.h).  build_ms_out (may be NULL): device time of the build without the host<->device copies. */
+int glrtx_build_lbvh(glrtx_ctx *ctx, const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
+                     int *max_depth_out, float *build_ms_out);
+
 int glrtx_resize(glrtx_ctx *ctx, int width, int height);
 int glrtx_clear(glrtx_ctx *ctx);
 

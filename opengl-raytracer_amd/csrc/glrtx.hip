@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "pt_kernel.hip.h"
+#include "lbvh.hip.h"
 
 using namespace glrtx;
 
@@ -42,6 +43,8 @@ struct glrtx_ctx {
     DevBuf forks, tris, nrms, mats, lights, accum_own, counter, rgba8, work;
     DevBuf wfA[6], wfH, wfHS, wfQ;  // wavefront path state + per-workgroup queues (variant 2)
     DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
+    DevBuf bvhVert, bvhTri, bvhNodes;  // glrtx_build_lbvh staging
+    lbvh::Workspace bvhWs;
     int variant = 2;          // 0 = tile megakernel, 1 = persistent megakernel with path regeneration, 2 = workgroup-local wavefront
     int n_cu = 256;
     int resident_wg[2] = {0, 0};  // persistent grid size per COUNT_RAYS instantiation (0 = not yet queried)
@@ -439,6 +442,8 @@ void glrtx_destroy(glrtx_ctx *c) {
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
     for (auto &b : c->wfA) dev_free(b);
     dev_free(c->wfH); dev_free(c->wfHS); dev_free(c->wfQ); dev_free(c->wfSeeds); dev_free(c->wfPlanes);
+    dev_free(c->bvhVert); dev_free(c->bvhTri); dev_free(c->bvhNodes);
+    if (c->bvhWs.p) { (void)hipFree(c->bvhWs.p); c->bvhWs.p = nullptr; c->bvhWs.bytes = 0; }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->evm) (void)hipEventDestroy(c->evm);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -495,6 +500,33 @@ int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t
     if (n_fork_out) *n_fork_out = (int)(P.forks.size() / 4);
     if (stack_entries_out) *stack_entries_out = P.stack_need;
     return GLRTX_OK;
+}
+
+int glrtx_build_lbvh(glrtx_ctx *c, const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out, int *max_depth_out,
+                     float *build_ms_out) {
+    if (!c) return GLRTX_EINVAL;
+    if (!vert || !tri || !nodes_out || n_tri == 0 || n_vert == 0) return fail(c, GLRTX_EINVAL, "glrtx_build_lbvh: empty input");
+    if (2 * n_tri - 1 > ((size_t)1 << 24) || n_vert > (size_t)INT32_MAX / 16)
+        return fail(c, GLRTX_EINVAL, "glrtx_build_lbvh: %zu triangles: node indices must fit a float (2^24)", n_tri);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n_nodes = 2 * n_tri - 1;
+    int rc;
+    if ((rc = dev_upload(c, c->bvhVert, vert, n_vert * 15 * sizeof(float)))) return rc;
+    if ((rc = dev_upload(c, c->bvhTri, tri, n_tri * 4 * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->bvhNodes, n_nodes * 9 * sizeof(float)))) return rc;
+    int depth = 0, bad = 0;
+    HIP_TRY(c, hipEventRecord(c->tm0, c->stream));
+    HIP_TRY(c, lbvh::build(c->stream, (const float *)c->bvhVert.p, (unsigned)n_vert, (const float *)c->bvhTri.p, (unsigned)n_tri,
+                           (float *)c->bvhNodes.p, c->bvhWs, &depth, &bad));
+    HIP_TRY(c, hipEventRecord(c->tm1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->tm1));
+    if (bad) return fail(c, GLRTX_ESCENE, "glrtx_build_lbvh: a triangle references a vertex out of range");
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->tm0, c->tm1));
+    HIP_TRY(c, hipMemcpy(nodes_out, c->bvhNodes.p, n_nodes * 9 * sizeof(float), hipMemcpyDeviceToHost));
+    if (max_depth_out) *max_depth_out = depth;
+    if (build_ms_out) *build_ms_out = ms;
+    return depth < 63 ? GLRTX_OK : fail(c, GLRTX_EDEPTH, "glrtx_build_lbvh: tree depth %d exceeds the 64-entry traversal stack", depth);
 }
 
 int glrtx_set_partition(glrtx_ctx *c, int rank, int world, int stripe_rows) {

@@ -190,6 +190,121 @@ int glrt_bvh_build_sah(const float *vert, size_t n_vert, const float *tri, size_
     return b.max_depth < 63 ? GLRT_HOST_OK : GLRT_HOST_EDEPTH;
 }
 
+// ---------------------------------------------------------------------------------------------- LBVH
+// Linear BVH (Karras 2012): 30-bit Morton codes of the triangle-box centres, made unique by appending the triangle
+// index, sorted; the hierarchy follows from the common-prefix lengths of neighbouring keys.  This is the CPU statement
+// of the algorithm; the GPU builder (csrc/lbvh.hip, glrtx_build_lbvh) produces the same nodes bit for bit -- every
+// step is either integer arithmetic or an exactly rounded float operation, and box unions are exact.
+// Output layout: internal node i at index i (root = 0), the leaf of sorted position k at index (n - 1) + k.
+namespace lbvh {
+
+inline uint32_t expand10(uint32_t v) {  // 10 bits -> every third bit
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+inline uint32_t quantize(float c, float lo, float ext) {
+    if (!(ext > 0.0f)) return 0u;
+    const float q = (c - lo) / ext * 1024.0f;
+    int i = (int)q;
+    if (i < 0) i = 0;
+    if (i > 1023) i = 1023;
+    return (uint32_t)i;
+}
+
+inline int delta(const std::vector<uint64_t> &k, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __builtin_clzll(k[(size_t)i] ^ k[(size_t)j]);  // keys are unique: the xor is never 0
+}
+
+}  // namespace lbvh
+
+int glrt_bvh_build_lbvh(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
+                        int *max_depth_out) {
+    if (!vert || !tri || !nodes_out || n_tri == 0) return GLRT_HOST_EINVAL;
+    if (2 * n_tri - 1 > ((size_t)1 << 24)) return GLRT_HOST_EINVAL;  // node indices travel as floats
+    std::vector<Prim> prims;
+    if (!load_prims(vert, n_vert, tri, n_tri, prims)) return GLRT_HOST_EINDEX;
+    const int n = (int)n_tri;
+    auto put = [&](size_t idx, const Box &b, float cx, float cy, float cz) {
+        float *o = nodes_out + 9 * idx;
+        o[0] = b.lo[0]; o[1] = b.lo[1]; o[2] = b.lo[2];
+        o[3] = b.hi[0]; o[4] = b.hi[1]; o[5] = b.hi[2];
+        o[6] = cx; o[7] = cy; o[8] = cz;
+    };
+    if (n == 1) {
+        put(0, prims[0].box, -1.f, -1.f, 0.f);
+        if (max_depth_out) *max_depth_out = 0;
+        return GLRT_HOST_OK;
+    }
+    Box cb;
+    cb.reset();
+    for (auto &p : prims) cb.grow(p.c);
+    std::vector<uint64_t> keys((size_t)n);
+    for (int t = 0; t < n; t++) {
+        const Prim &p = prims[(size_t)t];
+        const uint32_t m = (lbvh::expand10(lbvh::quantize(p.c[0], cb.lo[0], cb.hi[0] - cb.lo[0])) << 2) |
+                           (lbvh::expand10(lbvh::quantize(p.c[1], cb.lo[1], cb.hi[1] - cb.lo[1])) << 1) |
+                           lbvh::expand10(lbvh::quantize(p.c[2], cb.lo[2], cb.hi[2] - cb.lo[2]));
+        keys[(size_t)t] = ((uint64_t)m << 32) | (uint32_t)t;
+    }
+    std::sort(keys.begin(), keys.end());
+
+    std::vector<int> left((size_t)n - 1), right((size_t)n - 1);  // >= 0 internal, < 0 ~leaf position
+    for (int i = 0; i < n - 1; i++) {
+        const int d = lbvh::delta(keys, n, i, i + 1) - lbvh::delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+        const int dmin = lbvh::delta(keys, n, i, i - d);
+        int lmax = 2;
+        while (lbvh::delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2)
+            if (lbvh::delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+        const int j = i + l * d;
+        const int dnode = lbvh::delta(keys, n, i, j);
+        int s = 0, t = l;
+        do {
+            t = (t + 1) >> 1;
+            if (lbvh::delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        } while (t > 1);
+        const int g = i + s * d + (d < 0 ? -1 : 0);
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        left[(size_t)i] = (lo == g) ? ~g : g;
+        right[(size_t)i] = (hi == g + 1) ? ~(g + 1) : g + 1;
+    }
+    // boxes bottom-up (post-order walk from the root), depth on the way down
+    std::vector<Box> ibox((size_t)n - 1);
+    std::vector<int> order, depth((size_t)n - 1, 0);
+    order.reserve((size_t)n - 1);
+    std::vector<int> st{0};
+    int max_depth = 0;
+    while (!st.empty()) {
+        const int i = st.back();
+        st.pop_back();
+        order.push_back(i);
+        for (int c : {left[(size_t)i], right[(size_t)i]}) {
+            if (c >= 0) { depth[(size_t)c] = depth[(size_t)i] + 1; st.push_back(c); }
+            max_depth = std::max(max_depth, depth[(size_t)i] + 1);
+        }
+    }
+    auto leaf_box = [&](int pos) -> const Box & { return prims[(size_t)(uint32_t)keys[(size_t)pos]].box; };
+    for (size_t k = order.size(); k-- > 0;) {
+        const int i = order[k];
+        Box b;
+        b.reset();
+        for (int c : {left[(size_t)i], right[(size_t)i]}) b.grow(c >= 0 ? ibox[(size_t)c] : leaf_box(~c));
+        ibox[(size_t)i] = b;
+    }
+    auto node_index = [&](int c) { return c >= 0 ? (float)c : (float)((n - 1) + ~c); };
+    for (int i = 0; i < n - 1; i++) put((size_t)i, ibox[(size_t)i], node_index(left[(size_t)i]), node_index(right[(size_t)i]), -1.f);
+    for (int k = 0; k < n; k++) put((size_t)(n - 1 + k), leaf_box(k), -1.f, -1.f, (float)(uint32_t)keys[(size_t)k]);
+    if (max_depth_out) *max_depth_out = max_depth;
+    return max_depth < 63 ? GLRT_HOST_OK : GLRT_HOST_EDEPTH;
+}
+
 // Chain ("brute force") tree: fork i has the global bounds and children
 // (next fork, leaf i); the last fork holds the last two leaves.  The reference
 // traversal order (push x, push y, pop y first; raytrace.frag:299-307) then

@@ -29,7 +29,7 @@ class Stats(C.Structure):
                 ("n_mat", C.c_int32), ("n_light", C.c_int32)]
 
 
-EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_error", "glrtx_upload_scene",
+EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_error", "glrtx_upload_scene", "glrtx_build_lbvh",
            "glrtx_resize", "glrtx_clear", "glrtx_set_partition", "glrtx_local_row_to_y", "glrtx_bind_accum",
            "glrtx_set_stream", "glrtx_set_variant", "glrtx_count_rays", "glrtx_render", "glrtx_render_frames", "glrtx_sync", "glrtx_read_accum",
            "glrtx_accum_device_ptr", "glrtx_resolve_rgba8", "glrtx_get_stats", "glrtx_reset_stats",
@@ -59,6 +59,7 @@ def lib():
         L.glrtx_last_error.restype = C.c_char_p
         L.glrtx_upload_scene.argtypes = [vp, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, fp,
                                          C.c_size_t]
+        L.glrtx_build_lbvh.argtypes = [vp, fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
         L.glrtx_resize.argtypes = [vp, C.c_int, C.c_int]
         L.glrtx_clear.argtypes = [vp]
         L.glrtx_set_partition.argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -136,6 +137,14 @@ class Device:
         v, t, m, l, b = (_f32(scene[k]) for k in ("vert", "tri", "mat", "light", "bvh"))
         self._ck(self.L.glrtx_upload_scene(self.h, _fp(v), v.size // 15, _fp(t), t.size // 4, _fp(m), m.size // 18,
                                            _fp(l), l.size // 4, _fp(b), b.size // 9))
+
+    def build_lbvh(self, vert, tri):
+        """Linear BVH built on the GPU.  Returns (nodes (n_nodes*3, 3) float32 in the wire format, max_depth, device ms)."""
+        v, t = _f32(vert).reshape(-1, 15), _f32(tri).reshape(-1, 4)
+        nodes = np.zeros(((2 * t.shape[0] - 1) * 3, 3), np.float32)
+        depth, ms = C.c_int(0), C.c_float(0)
+        self._ck(self.L.glrtx_build_lbvh(self.h, _fp(v), v.shape[0], _fp(t), t.shape[0], _fp(nodes), C.byref(depth), C.byref(ms)))
+        return nodes, int(depth.value), float(ms.value)
 
     def set_partition(self, rank, world, stripe_rows=16):
         self._ck(self.L.glrtx_set_partition(self.h, rank, world, stripe_rows))

@@ -27,6 +27,7 @@ def lib():
         L.glrt_bvh_node_count.restype = C.c_size_t
         L.glrt_bvh_node_count.argtypes = [C.c_size_t]
         L.glrt_bvh_build_sah.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
+        L.glrt_bvh_build_lbvh.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_build_chain.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp]
         L.glrt_look_at.argtypes = [fp, fp, fp, fp]
         L.glrt_perspective.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, fp]
@@ -55,6 +56,8 @@ def build_bvh(vert: np.ndarray, tri: np.ndarray, kind: str = "sah"):
     depth = C.c_int(0)
     if kind == "sah":
         rc = L.glrt_bvh_build_sah(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
+    elif kind == "lbvh":
+        rc = L.glrt_bvh_build_lbvh(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
     elif kind == "chain":
         rc = L.glrt_bvh_build_chain(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes))
         depth.value = 2

@@ -277,3 +277,45 @@ def test_frames_in_flight_other_variants_fall_back_to_consecutive_launches(gpu_d
             assert_bit_equal(d.read_accum(), want, f"variant {v} render_frames")
     finally:
         d.set_variant(2)
+
+
+@pytest.mark.parametrize("cfg,kw", [("c3", dict(n=1)), ("c3", dict(n=2)), ("c3", dict(n=777)), ("c3", dict(n=10_000)),
+                                    ("c2", dict(subdiv=2)), ("c5", dict(n=100_000))])
+def test_gpu_lbvh_equals_cpu_lbvh_bitwise(gpu_device, cfg, kw):
+    """glrtx_build_lbvh (Morton sort + Karras hierarchy + bottom-up fit on the device) returns exactly the nodes of the
+    CPU statement glrt_bvh_build_lbvh, and the same depth."""
+    scene, _ = scenes.CONFIGS[cfg](width=16, height=16, bvh="lbvh", **kw)
+    nodes, depth, ms = gpu_device.build_lbvh(scene["vert"], scene["tri"])
+    want = np.asarray(scene["bvh"], np.float32).reshape(-1, 3)
+    assert nodes.shape == want.shape and depth == scene["bvh_depth"]
+    assert_bit_equal(nodes, want, f"{cfg} LBVH nodes")
+    assert ms > 0.0
+
+
+def test_gpu_lbvh_many_equal_centres_and_bad_index(gpu_device):
+    sc, _ = scenes.config_c3(8, 8, n=3, bvh="sah")
+    v = np.tile(sc["vert"].reshape(-1, 5, 3)[:3], (500, 1, 1)).reshape(-1, 3)          # 500 identical triangles
+    t = np.array([[3 * i, 3 * i + 1, 3 * i + 2, 0] for i in range(500)], np.float32)
+    nodes, depth, _ = gpu_device.build_lbvh(v, t)
+    want, want_depth = host.build_bvh(v, t, "lbvh")
+    assert_bit_equal(nodes, want, "equal Morton codes"); assert depth == want_depth <= 10
+    t[7, 1] = 1e6
+    with pytest.raises(device.GlrtxError) as e:
+        gpu_device.build_lbvh(v, t)
+    assert e.value.code == device.GLRTX_ESCENE
+
+
+def test_render_with_gpu_built_lbvh_matches_oracle(gpu_device):
+    """BASELINE config 5 (100k triangles, linear BVH) at reduced resolution: tree from the GPU builder, image vs the oracle
+    with the same tree -- and vs the oracle with the SAH tree (random triangles: no exact ties)."""
+    from oracle import pt_oracle
+    d = gpu_device
+    scene, params = scenes.config_c5(width=160, height=90, max_depth=4, bvh="sah")
+    nodes, depth, _ = d.build_lbvh(scene["vert"], scene["tri"])
+    lb = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind="lbvh")
+    acc, st = gpu_render(d, lb, params)
+    ref, ref_rays = pt_oracle.render(lb, params)
+    assert st.rays == ref_rays
+    assert_bit_equal(acc, ref, "c5 with GPU-built LBVH")
+    ref_sah, _ = pt_oracle.render(scene, params)
+    assert_bit_equal(acc, ref_sah, "LBVH image vs SAH image")

@@ -18,7 +18,7 @@ def _tri_boxes(scene):
     return p.min(1), p.max(1)
 
 
-@pytest.mark.parametrize("kind", ["sah", "chain"])
+@pytest.mark.parametrize("kind", ["sah", "chain", "lbvh"])
 def test_bvh_is_a_valid_tree_over_all_triangles(kind):
     sc, _ = scenes.config_c3(32, 32, n=700, bvh=kind)
     nodes = _nodes(sc)
@@ -33,7 +33,7 @@ def test_bvh_is_a_valid_tree_over_all_triangles(kind):
         assert not seen_node[n]
         seen_node[n] = True
         bmin, bmax, ch = nodes[n, 0:3], nodes[n, 3:6], nodes[n, 6:9]
-        if parent_box is not None and kind == "sah":
+        if parent_box is not None and kind != "chain":
             assert np.all(bmin >= parent_box[0]) and np.all(bmax <= parent_box[1])
         if ch[2] < 0:
             for c in ch[:2]:
@@ -60,6 +60,31 @@ def test_chain_bvh_visits_triangles_in_order_with_reference_traversal():
         else:
             order.append(int(ch[2]))
     assert order == list(range(50)) and depth == 2
+
+
+def test_lbvh_layout_and_image_equals_sah_image():
+    """LBVH: internal node i at index i, leaves after them in Morton order (unique keys => strictly increasing);
+    the oracle renders the same image with either tree (random triangles: no exact ties)."""
+    from oracle import pt_oracle
+    sc_l, pr = scenes.config_c3(48, 32, n=900, bvh="lbvh", max_depth=3)
+    sc_s, _ = scenes.config_c3(48, 32, n=900, bvh="sah", max_depth=3)
+    nodes = _nodes(sc_l)
+    n = sc_l["tri"].shape[0]
+    assert np.all(nodes[:n - 1, 8] == -1.0) and np.all(nodes[n - 1:, 8] >= 0.0)
+    assert sorted(nodes[n - 1:, 8].astype(int).tolist()) == list(range(n))
+    assert 10 <= sc_l["bvh_depth"] < 63
+    img_l, rays_l = pt_oracle.render(sc_l, pr)
+    img_s, rays_s = pt_oracle.render(sc_s, pr)
+    assert rays_l == rays_s
+    assert np.array_equal(img_l.view(np.uint32), img_s.view(np.uint32))
+    # degenerate inputs: one triangle, two triangles, many identical triangles (equal Morton codes)
+    for k in (1, 2, 3):
+        sc1, _ = scenes.config_c3(8, 8, n=k, bvh="lbvh")
+        assert _nodes(sc1).shape[0] == 2 * k - 1
+    v = np.tile(sc_l["vert"].reshape(-1, 5, 3)[:3], (40, 1, 1)).reshape(-1, 3)
+    t = np.array([[3 * i, 3 * i + 1, 3 * i + 2, 0] for i in range(40)], np.float32)
+    nodes40, depth40 = host.build_bvh(v, t, "lbvh")
+    assert depth40 <= 8  # index tie-break splits equal codes evenly
 
 
 def test_sah_depth_bounded():
