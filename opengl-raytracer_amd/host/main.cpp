@@ -13,13 +13,14 @@
 using namespace glrt;
 
 static void usage(const char *exe) {
-    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--out file.png] [--device G]\n"
+    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--bvh sah|lbvh|lbvh-cpu] [--out file.png] [--device G]\n"
                 "  -i, --input             scene description (JSON; schema: SURVEY.md Appendix C)            [required]\n"
                 "  -s, --sample-per-cycle  accepted for compatibility; like the reference (main.cpp:13) it is not read\n"
                 "      --max-depth D       u_maxDepth (default 16, the reference shader's default)\n"
                 "      --spp N             samples per pixel per frame, u_nSamples (default 1 as window.cpp:239)\n"
                 "      --frames F          frames to accumulate before exiting (default 16)\n"
                 "      --frames-in-flight B frames per launch of the render kernel (default 16; same pixels as 1)\n"
+                "      --bvh KIND          sah (CPU, default) | lbvh (linear BVH built on the GPU) | lbvh-cpu\n"
                 "      --out file.png      tonemapped output (default output.png, written after the last frame)\n"
                 "      --device G          HIP device ordinal (default: current)\n", exe);
 }
@@ -27,6 +28,7 @@ static void usage(const char *exe) {
 int main(int argc, char **argv) {
     std::string input, out = "output.png";
     int depth = 16, spp = 1, frames = 16, device = -1, in_flight = 0;
+    std::string bvh;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&](const char *name) -> const char * {
@@ -40,6 +42,7 @@ int main(int argc, char **argv) {
         else if (a == "--frames") frames = std::atoi(next("--frames"));
         else if (a == "--frames-in-flight") in_flight = std::atoi(next("--frames-in-flight"));
         else if (a == "--out") out = next("--out");
+        else if (a == "--bvh") bvh = next("--bvh");
         else if (a == "--device") device = std::atoi(next("--device"));
         else { usage(argv[0]); return 1; }
     }
@@ -54,6 +57,7 @@ int main(int argc, char **argv) {
     window->setOutput(out);
 
     auto scene = std::make_shared<Scene>();
+    if (!bvh.empty()) scene->setBvhBuilder(bvh);
     scene->parse(input);
 
     window->mainloop(scene);

@@ -6,10 +6,12 @@
 
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 
 #include "glrt_host.h"
+#include "glrtx.h"
 #include "json.h"
 
 namespace glrt {
@@ -145,10 +147,28 @@ void Scene::finalize() {
         }
     }
     if (nodes.empty() && !triangles.empty()) {
+        // BVH::construct (scene.cpp:251-253 -> bvh.cpp:59-160).  Builders: "sah" (CPU, default), "lbvh" (linear BVH
+        // built on the GPU through glrtx_build_lbvh: for large scenes), "lbvh-cpu" (the same tree from the host library).
+        // Any of them renders the same image (only exact ties depend on tree shape).
+        std::string kind = bvhBuilder_;
+        if (const char *e = std::getenv("GLRT_BVH")) kind = e;
         nodes.resize(glrt_bvh_node_count(triangles.size()));
-        const int rc = glrt_bvh_build_sah(&vertices[0].pos[0], vertices.size(), &triangles[0].indices[0], triangles.size(),
-                                          &nodes[0].bboxMin[0], &bvhDepth_);
-        if (rc != GLRT_HOST_OK) GLRT_FatalError("BVH construction failed (%d)", rc);
+        const float *v = &vertices[0].pos[0], *t = &triangles[0].indices[0];
+        if (kind == "sah" || kind == "lbvh-cpu") {
+            const int rc = kind == "sah" ? glrt_bvh_build_sah(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_)
+                                         : glrt_bvh_build_lbvh(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_);
+            if (rc != GLRT_HOST_OK) GLRT_FatalError("BVH construction (%s) failed (%d)", kind.c_str(), rc);
+        } else if (kind == "lbvh") {
+            glrtx_ctx *ctx = nullptr;
+            if (glrtx_create(&ctx, -1) != GLRTX_OK) GLRT_FatalError("GPU BVH builder: %s", glrtx_last_error(nullptr));
+            float ms = 0.0f;
+            if (glrtx_build_lbvh(ctx, v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_, &ms) != GLRTX_OK)
+                GLRT_FatalError("glrtx_build_lbvh: %s", glrtx_last_error(ctx));
+            GLRT_Info("LBVH over %zu triangles built on the GPU in %.3f ms (depth %d)", triangles.size(), ms, bvhDepth_);
+            glrtx_destroy(ctx);
+        } else {
+            GLRT_FatalError("unknown BVH builder '%s' (sah | lbvh | lbvh-cpu)", kind.c_str());
+        }
     }
 }
 

@@ -39,6 +39,8 @@ public:
     size_t numLights() const { return lights.size(); }
     size_t numNodes() const { return nodes.size(); }
     int bvhDepth() const { return bvhDepth_; }
+    // "sah" (default) | "lbvh" (built on the GPU) | "lbvh-cpu"; call before parse().  GLRT_BVH overrides.
+    void setBvhBuilder(const std::string &kind) { bvhBuilder_ = kind; }
 
 private:
     void finalize();  // lights list + BVH (scene.cpp:246-256)
@@ -53,6 +55,7 @@ private:
     std::vector<Material> materials;
     std::vector<BVHNode> nodes;
     int bvhDepth_ = 0;
+    std::string bvhBuilder_ = "sah";
 
     friend class Window;
 };

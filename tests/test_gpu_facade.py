@@ -59,6 +59,25 @@ def test_glrt_main_renders_json_scene_like_the_binding(tmp_path, gpu_device, in_
     assert np.array_equal(img, ref)
 
 
+def test_glrt_main_with_gpu_built_lbvh_gives_the_same_image(tmp_path, gpu_device):
+    """--bvh lbvh builds the tree on the device inside Scene::parse; tree shape does not change the image
+    (exact ties aside: the image is compared with a tolerance of a few differing pixels)."""
+    from PIL import Image
+    b = _c1_builder()
+    js = scenes.export_json_obj(b, tmp_path, 96, 64, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0)
+    imgs = {}
+    for kind in ("sah", "lbvh", "lbvh-cpu"):
+        out = tmp_path / f"{kind}.png"
+        r = subprocess.run([str(PKG / "lib" / "glrt_main"), "-i", str(js), "--max-depth", "3", "--frames", "2", "--bvh", kind,
+                            "--out", str(out)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        if kind == "lbvh":
+            assert "built on the GPU" in r.stdout
+        imgs[kind] = np.asarray(Image.open(out)).astype(np.int32)
+    assert np.array_equal(imgs["lbvh"], imgs["lbvh-cpu"])
+    assert (np.abs(imgs["lbvh"] - imgs["sah"]).max(-1) > 0).mean() < 0.01
+
+
 def test_glrt_main_requires_input():
     r = subprocess.run([str(PKG / "lib" / "glrt_main")], capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stdout
