@@ -625,13 +625,38 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
         }
         return GLRTX_OK;
     }
-    c->frames_seeds = seeds_xy;
-    c->frames_n = n_frames;
-    const int rc = glrtx_render(c, p);
-    c->frames_seeds = nullptr;
-    c->frames_n = 1;
-    if (rc == GLRTX_OK) c->st.launches += (uint64_t)(n_frames - 1);
-    return rc;
+    // Frames per launch are bounded by device memory: path state (120 B per id, id stride = next power of two of the
+    // owned pixels) plus one float4 plane per sample.  A longer request is issued as several launches, in order.
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+    const size_t px = (size_t)((c->width + 7) / 8) * (size_t)((c->owned_rows + 7) / 8) * 64;
+    size_t stride = 64;
+    while (stride < px) stride <<= 1;
+    const size_t held = c->wfPlanes.bytes + c->wfH.bytes + c->wfHS.bytes + 6 * c->wfA[0].bytes;  // already ours, reusable
+    const size_t per_frame = stride * 120 + (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
+    size_t budget = std::min<size_t>((size_t)48 << 30, (free_b + held) / 2);
+    if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;  // tests
+    const size_t id_cap = (((size_t)1 << 30) - 1) / stride;  // path ids are 31-bit, ray ids twice that
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, id_cap), budget / std::max<size_t>(per_frame, 1)));
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int n = std::min(chunk, n_frames - f0);
+        int rc;
+        if (n == 1) {
+            glrtx_params q = *p;
+            q.seed[0] = seeds_xy[2 * f0]; q.seed[1] = seeds_xy[2 * f0 + 1];
+            rc = glrtx_render(c, &q);
+        } else {
+            c->frames_seeds = seeds_xy + 2 * (size_t)f0;
+            c->frames_n = n;
+            rc = glrtx_render(c, p);
+            c->frames_seeds = nullptr;
+            c->frames_n = 1;
+            if (rc == GLRTX_OK) c->st.launches += (uint64_t)(n - 1);
+        }
+        if (rc != GLRTX_OK) return rc;
+    }
+    return GLRTX_OK;
 }
 
 int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {

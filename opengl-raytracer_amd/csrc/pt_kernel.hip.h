@@ -882,7 +882,7 @@ struct WfArgs {
     int total;        // tile-order ids: tiles8_x * tiles8_y * 64
     int tiles8_x;
     int refill_min;   // refill a traversal wave once this many lanes are idle
-    int block_paths;  // pixels per workgroup block (multiple of 256, <= kWgPathsMax)
+    int block_paths;  // paths a workgroup keeps alive (power of two, 256 .. kWgPathsMax)
     int gss_div;      // top-up requests are capped at ceil(tiles left / gss_div); 0 = uncapped
     // Frames in flight (glrtx_render_frames): n_frames consecutive frames that differ only in u_seed run in ONE launch.
     // Path ids are (frame << frame_shift) | tile-order pixel id; every finished sample is stored in its own plane
@@ -1032,24 +1032,24 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 }
 
 // ------------------------------------------------------------------------------------------ workgroup-local wavefront
-// Variant D ("wgwf"): the wavefront formulation with every queue and every barrier LOCAL to a
-// workgroup.  A workgroup takes kWgPaths pixels (16 tiles of 8x8) from a global counter and runs
-// their trips itself: traverse phase (lanes pull rays from an LDS queue, refilled as they finish),
-// __syncthreads, shade phase (the workgroup's live paths, compacted), __syncthreads, ... until the
-// paths are done; then it takes the next block.  There is no device-wide barrier anywhere: a
-// workgroup waiting for its last long ray idles only itself, while the other resident workgroups are
-// at other stages -- the global pipeline of variant C loses ~300 us per trip to that wait, nine times
-// a frame.  One kernel launch per frame.  State lives in the same HBM arrays as variant C.
+// Variant 2 ("wgwf"): the wavefront formulation with every queue and every barrier LOCAL to a workgroup.
+// A workgroup keeps up to block_paths paths alive; each trip it (1) tops its free slots up with new pixels, whole
+// 8x8 tiles from the launch's tile counter, (2) traverse phase: lanes pull the queued rays, refilled as they finish,
+// __syncthreads, (3) shade phase: the live paths, compacted, __syncthreads -- until nothing is alive and the counter
+// is exhausted.  There is no device-wide barrier anywhere: a workgroup waiting for its last long ray idles only
+// itself, while the other resident workgroups are at other stages (a device-wide pipeline with one traverse and one
+// shade kernel per trip lost ~300 us per trip to that wait, nine times a frame).  One launch covers one frame, or
+// several frames in flight (WfArgs).  Path state lives in HBM as float4 SoA.
 #ifndef GLRTX_STEPS_PER_TRIP
 #define GLRTX_STEPS_PER_TRIP 2
 #endif
-constexpr int kWgPathsMax = 4096;  // pixels per workgroup block: 1024 (16 tiles of 8x8) when the image is large enough to
-                                   // give every resident workgroup >= 2 blocks, else 512 or 256 (chosen by the host)
+constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes its queues); the host picks block_paths <= this so
+                                   // that the launch has that many pixels for every resident workgroup
 #ifndef GLRTX_WGWF_WAVES
 #define GLRTX_WGWF_WAVES 4
 #endif
 
-// Traverse phase of one block-trip, run by a whole workgroup: lanes pull the block's queued rays
+// Traverse phase of one trip, run by a whole workgroup: lanes pull the workgroup's queued rays
 // (64 at a time per wave through *ray_head, an LDS counter) and a lane whose ray is finished takes the
 // next one once refill_min lanes of its wave are idle.  Hit records go to w.H / w.HS.
 DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, const unsigned *rq, int n_rays,
@@ -1125,7 +1125,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
     if (unsaved) save_hit();
 }
 
-// Shade phase of one block-trip, run by a whole workgroup: every live path of the block (pq[0..n_paths))
+// Shade phase of one trip, run by a whole workgroup: every live path (pq[0..n_paths))
 // goes through wf_shade_path(); the rays and paths of the next trip are appended to rq_next / pq_next
 // (wave-aggregated, one LDS atomic per wave and queue on *n_rays_next / *n_paths_next).
 DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const unsigned *pq, int n_paths,

@@ -319,3 +319,19 @@ def test_render_with_gpu_built_lbvh_matches_oracle(gpu_device):
     assert_bit_equal(acc, ref, "c5 with GPU-built LBVH")
     ref_sah, _ = pt_oracle.render(scene, params)
     assert_bit_equal(acc, ref_sah, "LBVH image vs SAH image")
+
+
+def test_frames_in_flight_are_chunked_by_the_memory_budget(gpu_device, monkeypatch):
+    """A request that does not fit the device-memory budget is issued as several launches, with the same result."""
+    d = gpu_device
+    scene, params = scenes.config_c2(width=256, height=144, max_depth=4, subdiv=1)
+    seeds = _seeds(7)
+    want, _ = gpu_render(d, scene, params, frames=seeds)
+    per_frame_mb = (1 << 16) * 120 / 2**20 + 256 * 144 * 16 / 2**20   # id stride 2^16 (36,864 pixels) + one plane
+    for budget_mb, launches in ((1, 7), (int(3.5 * per_frame_mb), 3), (1 << 14, 1)):
+        monkeypatch.setenv("GLRTX_FRAMES_BUDGET_MB", str(budget_mb))
+        d.clear(); d.reset_stats()
+        d.render_frames(params, seeds); d.sync()
+        st = d.stats()
+        assert st.launches == 7 and st.kernel_launches == launches, (budget_mb, st.kernel_launches)
+        assert_bit_equal(d.read_accum(), want, f"budget {budget_mb} MB")
