@@ -189,7 +189,8 @@ def main():
     pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
     if pmc.exists() and args.config == "headline" and world == 1:
         try:
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            prof = json.loads(pmc.read_text())  # measured per launch of prof["frames_per_launch"] frames; scaled to this run's launches
+            traffic = prof["hbm_bytes_per_launch"] / prof.get("frames_per_launch", 1) * frames_per_launch
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -5,8 +5,9 @@ device.lib_path = lambda: device.LIB_DIR / "libglrtx_phase.so"
 sc, pr = scenes.config_headline()
 d = device.Device(); d.upload_scene(sc); d.resize(1920, 1080)
 L = device.lib(); out = (C.c_ulonglong * 8)()
-d.render(dict(pr, seed=host.frame_seed(0))); d.sync(); L.glrtx_debug_phase_cycles(out)
-d.render(dict(pr, seed=host.frame_seed(1))); d.sync(); L.glrtx_debug_phase_cycles(out)
-o = np.array(list(out)[:5], float); print("ms", d.stats().kernel_ms_last)
-names = ["generate", "traverse", "wait after traverse", "shade", "wait after shade"]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+d.render_frames(pr, [host.frame_seed(f) for f in range(B)]); d.sync(); L.glrtx_debug_phase_cycles(out)
+d.render_frames(pr, [host.frame_seed(B + f) for f in range(B)]); d.sync(); L.glrtx_debug_phase_cycles(out)
+o = np.array(list(out)[:5], float); print("frames per launch", B, "ms per frame", d.stats().kernel_ms_last / B)
+names = ["top-up/generate", "traverse", "wait after traverse", "shade", "wait after shade"]
 for n, v in zip(names, o): print(f"{n:22s} {v/o.sum()*100:5.1f} %   ({v/1e6:.1f} Mcycles summed over workgroups)")

@@ -49,6 +49,7 @@ if main:
             "kernel": main[0], "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
             "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
             "hbm_bytes_per_launch": fetch + write,
+            "frames_per_launch": 16,  # tools/profile.sh: every launch of the profiled command covers 16 frames
             "hbm_bytes_per_launch_upper_bound_fetch_x2": 2 * fetch + write,
             "note": "FETCH_SIZE/WRITE_SIZE are KiB; scattered 16-B gathers, no gfx950 x2 streaming correction applied"}, indent=1))
 print(json.dumps(out, indent=1)[:3000])
