@@ -7,7 +7,7 @@
 
 One "step" = one frame: one pass of the path-tracing hot path (raytrace.frag::main on every pixel of
 the 1920x1080 image, u_maxDepth = 8, 1 sample/pixel, fresh u_seed per frame) accumulated into the
-resident float4 framebuffer.  Frames are issued --frames-in-flight B at a time (default 16) through
+resident float4 framebuffer.  Frames are issued --frames-in-flight B at a time (default 16 per rank) through
 glrtx_render_frames: ONE launch of the render kernel (pt_render_wgwf, the workgroup-local wavefront)
 covers B consecutive frames and adds their samples to the accumulator in frame order, so the result
 is bit-identical to B separate launches (tests/test_gpu_parity.py) while the GPU stays full across
@@ -69,7 +69,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-gather", action="store_true", help="skip the framebuffer gather (N > 1)")
     ap.add_argument("--no-single", action="store_true", help="skip the extra one-launch-per-frame measurement (profiling runs)")
-    ap.add_argument("--frames-in-flight", type=int, default=16, help="frames per launch of the render kernel (1 = one launch per frame)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames per launch of the render kernel (1 = one launch per frame; default 16 x N ranks: "
+                         "16 full frames' worth of paths in flight on every GPU, whatever share of the rows it owns)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -109,7 +111,7 @@ def main():
     def seed(f):
         return host.frame_seed(f)
 
-    B = max(1, args.frames_in_flight)
+    B = args.frames_in_flight if args.frames_in_flight > 0 else min(16 * world, 256)
 
     def run(f0, f1, gather=True, per_launch=None):
         """Frames [f0, f1): per_launch frames per launch of the render kernel, the framebuffer gathered after every launch."""
