@@ -1049,6 +1049,20 @@ constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes 
 #define GLRTX_WGWF_WAVES 4
 #endif
 
+#ifdef GLRTX_PHASE_STATS
+// Diagnostic build only: shader-clock cycles thread 0 of every workgroup spent per phase
+// [0] generate, [1] traverse (own work), [2] wait at the barrier after traverse, [3] shade, [4] wait after shade
+__device__ unsigned long long g_phase_cycles[8];
+// per-trip log of every 64th workgroup: {n_rays, n_paths, traverse+wait cycles, shade+wait cycles}, 64 trips at most;
+// entry 0 = {trips, start cycle (low 32 bits), end cycle, blocks taken}
+__device__ uint4 g_trip_log[16][64];
+#define PH_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PH_ADD(i, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], (t1) - (t0)); } while (0)
+#else
+#define PH_STAMP(var)
+#define PH_ADD(i, t0, t1)
+#endif
+
 // Traverse phase of one trip, run by a whole workgroup: lanes pull the workgroup's queued rays
 // (64 at a time per wave through *ray_head, an LDS counter) and a lane whose ray is finished takes the
 // next one once refill_min lanes of its wave are idle.  Hit records go to w.H / w.HS.
@@ -1076,6 +1090,9 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
     for (;;) {
         unsigned long long idle = __ballot(!active);
         if ((int)__popcll(idle) >= w.refill_min || idle == ~0ull) {
+#ifdef GLRTX_PHASE_STATS
+            const unsigned long long rf0 = __builtin_amdgcn_s_memtime();
+#endif
             while (idle != 0ull && !exhausted) {
                 if (chunk_next >= chunk_end) {
                     int base = 0;
@@ -1104,6 +1121,9 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
                 chunk_next += take;
                 idle = __ballot(!active);
             }
+#ifdef GLRTX_PHASE_STATS
+            if (threadIdx.x == 0) { atomicAdd(&g_phase_cycles[5], __builtin_amdgcn_s_memtime() - rf0); atomicAdd(&g_phase_cycles[6], 1ull); }
+#endif
         }
         if (!__any(active)) {
             if (exhausted) break;
@@ -1154,19 +1174,6 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
     }
 }
 
-#ifdef GLRTX_PHASE_STATS
-// Diagnostic build only: shader-clock cycles thread 0 of every workgroup spent per phase
-// [0] generate, [1] traverse (own work), [2] wait at the barrier after traverse, [3] shade, [4] wait after shade
-__device__ unsigned long long g_phase_cycles[8];
-// per-trip log of every 64th workgroup: {n_rays, n_paths, traverse+wait cycles, shade+wait cycles}, 64 trips at most;
-// entry 0 = {trips, start cycle (low 32 bits), end cycle, blocks taken}
-__device__ uint4 g_trip_log[16][64];
-#define PH_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define PH_ADD(i, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], (t1) - (t0)); } while (0)
-#else
-#define PH_STAMP(var)
-#define PH_ADD(i, t0, t1)
-#endif
 
 template <bool COUNT_RAYS>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, unsigned *wg_queues) {

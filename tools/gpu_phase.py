@@ -11,3 +11,5 @@ d.render_frames(pr, [host.frame_seed(B + f) for f in range(B)]); d.sync(); L.glr
 o = np.array(list(out)[:5], float); print("frames per launch", B, "ms per frame", d.stats().kernel_ms_last / B)
 names = ["top-up/generate", "traverse", "wait after traverse", "shade", "wait after shade"]
 for n, v in zip(names, o): print(f"{n:22s} {v/o.sum()*100:5.1f} %   ({v/1e6:.1f} Mcycles summed over workgroups)")
+o2 = list(out)
+print(f"refill sections (wave 0 of every workgroup): {o2[5]/max(o[1],1)*100:.1f} % of the traverse phase, {o2[6]} events, {o2[5]/max(o2[6],1):.0f} cycles each")
