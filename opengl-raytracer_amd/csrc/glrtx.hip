@@ -41,7 +41,7 @@ struct glrtx_ctx {
     std::string err;
 
     DevBuf forks, tris, nrms, mats, lights, accum_own, counter, rgba8, work;
-    DevBuf wfA[6], wfH, wfHS, wfQ;  // wavefront path state + per-workgroup queues (variant 2)
+    DevBuf wfA[5], wfH, wfHS, wfQ;  // wavefront path state + per-workgroup queues (variant 2)
     DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
     DevBuf bvhVert, bvhTri, bvhNodes;  // glrtx_build_lbvh staging
     lbvh::Workspace bvhWs;
@@ -327,7 +327,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     WfArgs w;
     std::memset(&w, 0, sizeof w);
     w.A0 = (float4 *)c->wfA[0].p; w.A1 = (float4 *)c->wfA[1].p; w.A2 = (float4 *)c->wfA[2].p;
-    w.A3 = (float4 *)c->wfA[3].p; w.A4 = (float4 *)c->wfA[4].p; w.A5 = (float4 *)c->wfA[5].p;
+    w.A3 = (float4 *)c->wfA[3].p; w.A4 = (float4 *)c->wfA[4].p;
     w.H = (float4 *)c->wfH.p; w.HS = (float2 *)c->wfHS.p;
     w.total = (int)total;
     w.tiles8_x = tiles8_x;
@@ -370,11 +370,11 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     const int grid = std::max(1, (int)std::min<size_t>((size_t)resident, (work + block_paths - 1) / block_paths));
     w.gss_div = 4 * grid;
     if (const char *v = std::getenv("GLRTX_GSS_DIV")) w.gss_div = std::max(0, std::atoi(v));
-    if ((rc = ensure(c, c->wfQ, (size_t)grid * 6 * kWgPathsMax * sizeof(unsigned)))) return rc;  // per-workgroup queues
+    if ((rc = ensure(c, c->wfQ, (size_t)grid * kWgQueueF4 * sizeof(float4)))) return rc;  // per-workgroup queues
     HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (ci) hipLaunchKernelGGL(pt_render_wgwf<true>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (unsigned *)c->wfQ.p);
-    else hipLaunchKernelGGL(pt_render_wgwf<false>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (unsigned *)c->wfQ.p);
+    if (ci) hipLaunchKernelGGL(pt_render_wgwf<true>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (float4 *)c->wfQ.p);
+    else hipLaunchKernelGGL(pt_render_wgwf<false>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (float4 *)c->wfQ.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->evm, c->stream));
     if (n_frames > 1 && n_planes > 0) {
@@ -625,7 +625,7 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
         }
         return GLRTX_OK;
     }
-    // Frames per launch are bounded by device memory: path state (120 B per id, id stride = next power of two of the
+    // Frames per launch are bounded by device memory: path state (104 B per id, id stride = next power of two of the
     // owned pixels) plus one float4 plane per sample.  A longer request is issued as several launches, in order.
     HIP_TRY(c, hipSetDevice(c->device));
     size_t free_b = 0, total_b = 0;
@@ -633,8 +633,8 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
     const size_t px = (size_t)((c->width + 7) / 8) * (size_t)((c->owned_rows + 7) / 8) * 64;
     size_t stride = 64;
     while (stride < px) stride <<= 1;
-    const size_t held = c->wfPlanes.bytes + c->wfH.bytes + c->wfHS.bytes + 6 * c->wfA[0].bytes;  // already ours, reusable
-    const size_t per_frame = stride * 120 + (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
+    const size_t held = c->wfPlanes.bytes + c->wfH.bytes + c->wfHS.bytes + 5 * c->wfA[0].bytes;  // already ours, reusable
+    const size_t per_frame = stride * 104 + (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
     size_t budget = std::min<size_t>((size_t)48 << 30, (free_b + held) / 2);
     if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;  // tests
     const size_t id_cap = (((size_t)1 << 30) - 1) / stride;  // path ids are 31-bit, ray ids twice that

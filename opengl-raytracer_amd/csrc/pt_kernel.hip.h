@@ -876,7 +876,8 @@ struct WfArgs {
     float4 *A2;  // {beta, meta}           meta = depth | sample << 8 | flags
     float4 *A3;  // {L if the pending light sample is accepted (or L), dist}
     float4 *A4;  // {L if it is rejected, -}
-    float4 *A5;  // {shadow ray direction, -}
+    // (ray origins/directions for the traversal travel in the workgroup's ray queue: 32-byte records
+    //  {origin, ray id} {direction, -} in queue order, read with unit stride)
     float4 *H;   // closest hit of the path's ray {t, tri, u, v}
     float2 *HS;  // closest hit of the shadow ray {t, tri}
     int total;        // tile-order ids: tiles8_x * tiles8_y * 64
@@ -946,7 +947,7 @@ DEV bool wf_start(const KernelArgs &a, const WfArgs &w, int id, int lx, int lrow
 
 // Start path `id` (frame | tile-order pixel id): seed its RNG, draw sample 0's camera ray, store the path state.
 // Returns true if a ray was queued (false: outside the image, or nothing to trace).
-DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id) {
+DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id, float4 &ray_o, float4 &ray_d) {
     int lx, lrow;
     bool go = false;
     const float2 sd = wf_seed(a, w, id);
@@ -964,6 +965,8 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id) {
         w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
         w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
         w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ray_o = make_float4(P.ox, P.oy, P.oz, __uint_as_float((unsigned)id * 2u));
+        ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
     }
     return go;
 }
@@ -971,7 +974,8 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id) {
 // One path of the shade stage: resolve the light sample of the previous bounce, then either close the
 // sample (and start the pixel's next one) or run shade_hit() on the new hit.  Outputs which rays to
 // queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray.
-DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, unsigned id, bool &push_ext, bool &push_sh) {
+DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, unsigned id, bool &push_ext, bool &push_sh,
+                       float4 &ray_o, float4 &ray_d, float4 &ray_sd) {
     int lx, lrow;
     wf_pixel(a, w, (int)id, lx, lrow);
     const int gy = local_row_to_y(a, lrow);
@@ -1014,6 +1018,8 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
             w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
             w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
             w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ray_o = make_float4(P.ox, P.oy, P.oz, 0.f);
+            ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
         }
     } else {
         // shade_hit ran and the path goes on and/or awaits its shadow ray
@@ -1024,10 +1030,10 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
         w.A2[id] = make_float4(P.bx, P.by, P.bz, __uint_as_float(m2));
         w.A3[id] = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist);
-        if (push_sh) {
-            w.A4[id] = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f);
-            w.A5[id] = make_float4(sh.sdx, sh.sdy, sh.sdz, 0.f);
-        }
+        if (push_sh) w.A4[id] = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f);
+        ray_o = make_float4(P.ox, P.oy, P.oz, 0.f);  // the next ray and the shadow ray leave from the same point
+        ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
+        ray_sd = make_float4(sh.sdx, sh.sdy, sh.sdz, 0.f);
     }
 }
 
@@ -1045,6 +1051,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 #endif
 constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes its queues); the host picks block_paths <= this so
                                    // that the launch has that many pixels for every resident workgroup
+constexpr size_t kWgQueueF4 = 8 * (size_t)kWgPathsMax + (size_t)kWgPathsMax / 2;  // float4 units per workgroup: ray records + path ids
 #ifndef GLRTX_WGWF_WAVES
 #define GLRTX_WGWF_WAVES 4
 #endif
@@ -1063,15 +1070,37 @@ __device__ uint4 g_trip_log[16][64];
 #define PH_ADD(i, t0, t1)
 #endif
 
-// Traverse phase of one trip, run by a whole workgroup: lanes pull the workgroup's queued rays
-// (64 at a time per wave through *ray_head, an LDS counter) and a lane whose ray is finished takes the
-// next one once refill_min lanes of its wave are idle.  Hit records go to w.H / w.HS.
-DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, const unsigned *rq, int n_rays,
+// Traverse phase of one trip, run by a whole workgroup: lanes pull the workgroup's queued rays and a lane whose ray
+// is finished takes the next one once refill_min lanes of its wave are idle.  Hit records go to w.H / w.HS.
+// The queue holds the rays themselves (32-byte records {origin, ray id} {direction, -}); every wave keeps TWO chunks
+// of 64 records in registers -- lane l holds record l of each -- fetched with unit stride long before they are
+// needed (64 at a time through *ray_head, an LDS counter).  A refill therefore touches no memory: the idle lane with
+// rank r takes the record held by lane (consumed + r) through a cross-lane read.  (Fetching a ray when a lane fell
+// idle -- queue index, then path state, two dependent round trips -- cost 14 % of the phase.)
+DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned &rays) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    int chunk_next = 0, chunk_end = 0;  // wave-uniform
-    bool exhausted = n_rays == 0;
+    const float4 none = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID));
+    float4 cur_o = none, cur_d = none, next_o = none, next_d = none;  // this lane's record of the current / next chunk
+    int cur_pos = 0, cur_cnt = 0, next_cnt = 0;                        // wave-uniform
+    auto fetch = [&](float4 &o, float4 &d) -> int {                    // returns the number of records in the chunk (0: queue exhausted)
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(ray_head, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        int cnt = n_rays - base;
+        cnt = cnt < 0 ? 0 : (cnt > 64 ? 64 : cnt);
+        if (lane < cnt) {
+            o = rq[2 * (size_t)(base + lane)];
+            d = rq[2 * (size_t)(base + lane) + 1];
+        }
+        return cnt;
+    };
+    // short queues (the last trips of a launch) are handed out one chunk at a time so that all four waves get some
+    const bool ahead = n_rays >= 16 * 64;
+    cur_cnt = fetch(cur_o, cur_d);
+    next_cnt = (ahead && cur_cnt == 64) ? fetch(next_o, next_d) : 0;
+    bool exhausted = cur_cnt == 0;
     bool active = false;
     // A finished ray's hit record is kept in registers and written when the lane is refilled
     // (or at the end of the phase): a store issued inside the stepping loop would sit in vmcnt
@@ -1094,31 +1123,35 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
             const unsigned long long rf0 = __builtin_amdgcn_s_memtime();
 #endif
             while (idle != 0ull && !exhausted) {
-                if (chunk_next >= chunk_end) {
-                    int base = 0;
-                    if (lane == 0) base = (int)atomicAdd(ray_head, 64u);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= n_rays) { exhausted = true; break; }
-                    chunk_next = base;
-                    chunk_end = base + 64 < n_rays ? base + 64 : n_rays;
+                if (cur_pos >= cur_cnt) {  // current chunk used up: the prefetched one takes its place, the next is requested
+                    if (ahead) {
+                        cur_o = next_o; cur_d = next_d;
+                        cur_cnt = next_cnt;
+                        next_cnt = cur_cnt == 64 ? fetch(next_o, next_d) : 0;
+                    } else {
+                        cur_cnt = cur_cnt == 64 ? fetch(cur_o, cur_d) : 0;
+                    }
+                    cur_pos = 0;
+                    if (cur_cnt == 0) { exhausted = true; break; }
                 }
                 const int n = __popcll(idle);
-                const int avail = chunk_end - chunk_next;
+                const int avail = cur_cnt - cur_pos;
                 const int take = n < avail ? n : avail;
                 const int rank = __popcll(idle & lt_mask);
+                const int src = (cur_pos + rank) & 63;
+                const float ox = __shfl(cur_o.x, src), oy = __shfl(cur_o.y, src), oz = __shfl(cur_o.z, src);
+                const unsigned new_rid = (unsigned)__shfl((int)__float_as_uint(cur_o.w), src);
+                const float dx = __shfl(cur_d.x, src), dy = __shfl(cur_d.y, src), dz = __shfl(cur_d.z, src);
                 if (!active && rank < take) {
                     if (unsaved) save_hit();
-                    rid = rq[chunk_next + rank];
+                    rid = new_rid;
                     if (rid != WF_INVALID) {
-                        const unsigned id = rid >> 1;
-                        const float4 o = w.A0[id];
-                        const float4 d = (rid & 1u) ? w.A5[id] : w.A1[id];
                         rays++;
-                        active = trav_init(a.sc, T, o.x, o.y, o.z, d.x, d.y, d.z);
+                        active = trav_init(a.sc, T, ox, oy, oz, dx, dy, dz);
                         unsaved = !active;  // root box missed: the (miss) record is already final
                     }
                 }
-                chunk_next += take;
+                cur_pos += take;
                 idle = __ballot(!active);
             }
 #ifdef GLRTX_PHASE_STATS
@@ -1149,15 +1182,16 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
 // goes through wf_shade_path(); the rays and paths of the next trip are appended to rq_next / pq_next
 // (wave-aggregated, one LDS atomic per wave and queue on *n_rays_next / *n_paths_next).
 DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const unsigned *pq, int n_paths,
-                        unsigned *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next) {
+                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int j0 = 0; j0 < n_paths; j0 += kBlockThreads) {
         const int i = j0 + (int)threadIdx.x;
         bool push_ext = false, push_sh = false;
         unsigned id = WF_INVALID;
+        float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro, rsd = ro;
         if (i < n_paths) id = pq[i];
-        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, id, push_ext, push_sh);
+        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, id, push_ext, push_sh, ro, rd, rsd);
         const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
         unsigned br = 0, bp = 0;
         if (lane == 0) {
@@ -1168,15 +1202,22 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         }
         br = __builtin_amdgcn_readfirstlane(br);
         bp = __builtin_amdgcn_readfirstlane(bp);
-        if (push_ext) rq_next[br + __popcll(me & lt_mask)] = id * 2u;
-        if (push_sh) rq_next[br + __popcll(me) + __popcll(ms & lt_mask)] = id * 2u + 1u;
+        if (push_ext) {
+            float4 *r = rq_next + 2 * (size_t)(br + __popcll(me & lt_mask));
+            r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u));
+            r[1] = rd;
+        }
+        if (push_sh) {
+            float4 *r = rq_next + 2 * (size_t)(br + __popcll(me) + __popcll(ms & lt_mask));
+            r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u + 1u));
+            r[1] = rsd;
+        }
         if (push_ext || push_sh) pq_next[bp + __popcll(mp & lt_mask)] = id;
     }
 }
 
-
 template <bool COUNT_RAYS>
-__global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, unsigned *wg_queues) {
+__global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // LDS: materials | stack | ctl[16].  The workgroup's ray/path queues live in its private slice of a
     // global buffer (L2-resident, read and written with unit stride).
@@ -1186,8 +1227,9 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
     unsigned *ctl = reinterpret_cast<unsigned *>(pl);            // 0: first new tile, 1: ray head, 2..3: nRays[2], 4..5: nPaths[2], 6: new tiles, 7: frame exhausted
-    unsigned *rayQ = wg_queues + (size_t)blockIdx.x * 6 * kWgPathsMax;  // [2][2*block_paths]
-    unsigned *pathQ = rayQ + 4 * w.block_paths;                          // [2][block_paths]
+    // per-workgroup slice of the queue buffer: ray records float4[2][2 * block_paths][2], then path ids unsigned[2][block_paths]
+    float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
+    unsigned *pathQ = reinterpret_cast<unsigned *>(rayQ + 8 * (size_t)w.block_paths);
     if (a.sc.mats_in_lds)
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
 
@@ -1227,13 +1269,15 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         {
             const int got = (int)ctl[6] * 64, tile0 = (int)ctl[0];
             const int nr = (int)ctl[2 + cur], np = (int)ctl[4 + cur];
-            unsigned *rq_w = rayQ + cur * 2 * kWgPaths + nr;
+            float4 *rq_w = rayQ + 2 * ((size_t)cur * 2 * kWgPaths + nr);
             unsigned *pq_w = pathQ + cur * kWgPaths + np;
             for (int k = threadIdx.x; k < got; k += kBlockThreads) {
                 const int g = tile0 + (k >> 6), f = g / w.tiles_per_frame;
                 const int id = (f << w.frame_shift) | ((g - f * w.tiles_per_frame) * 64 + (k & 63));
-                const bool go = wf_generate_one(a, w, id);  // pixels outside the image leave skip markers
-                rq_w[k] = go ? (unsigned)id * 2u : WF_INVALID;
+                float4 ro = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID)), rd = ro;
+                const bool go = wf_generate_one(a, w, id, ro, rd);  // pixels outside the image leave skip markers
+                rq_w[2 * k] = ro;
+                rq_w[2 * k + 1] = rd;
                 pq_w[k] = go ? (unsigned)id : WF_INVALID;
             }
             __syncthreads();  // everyone has read the counts
@@ -1244,7 +1288,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         PH_ADD(0, pg0, pg1);
         const int n_rays = (int)ctl[2 + cur], n_paths = (int)ctl[4 + cur];
         if (n_paths == 0) break;  // nothing alive and nothing left to take
-        const unsigned *rq = rayQ + cur * 2 * kWgPaths;
+        const float4 *rq = rayQ + 2 * ((size_t)cur * 2 * kWgPaths);
         const unsigned *pq = pathQ + cur * kWgPaths;
 
         // ---- traverse phase: lanes pull rays; a lane whose ray is finished takes the next one
@@ -1257,7 +1301,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         PH_ADD(2, pt1, pt2);
 
         // ---- shade phase: the live paths; appends go to the other queue pair
-        wg_shade_phase(a, w, lds_mats, pq, n_paths, rayQ + (cur ^ 1) * 2 * kWgPaths, pathQ + (cur ^ 1) * kWgPaths,
+        wg_shade_phase(a, w, lds_mats, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
                        &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)]);
         PH_STAMP(ps1);
         __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending

@@ -9,14 +9,14 @@ def t(B, reps=4):
     for it in range(reps):
         d.render_frames(pr, [host.frame_seed(it * B + f) for f in range(B)]); d.sync(); ts.append(d.stats().kernel_ms_last / B)
     return float(np.median(ts[1:]))
+knob = sys.argv[1] if len(sys.argv) > 1 else "GLRTX_REFILL_MIN"
+vals = sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2", "4", "8", "12", "16", "24", "32"]
 for world in (1, 8):
     d.set_partition(0, world, 16); d.resize(1920, 1080)
-    for B in (8, 16, 32):
-        base = t(B)
-        out = [f"base {base:.3f}"]
-        for k, vals in (("GLRTX_BLOCK_PATHS", ("1024", "2048")), ("GLRTX_GSS_DIV", ("0",))):
-            for v in vals:
-                os.environ[k] = v
-                out.append(f"{k[6:]}={v} {t(B):.3f}")
-            del os.environ[k]
-        print(f"world {world} B {B}:", "  ".join(out), flush=True)
+    for B in (1, 16):
+        out = [f"default {t(B):.3f}"]
+        for v in vals:
+            os.environ[knob] = v
+            out.append(f"{v}: {t(B):.3f}")
+        del os.environ[knob]
+        print(f"world {world} B {B} {knob}:", "  ".join(out), flush=True)
