@@ -197,7 +197,7 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "kernel": "pt_render_wgwf<false>", "kernel_ms_avg": round(kernel_ms, 4),
+                "kernel": "pt_render_wgwf<false, false>", "kernel_ms_avg": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes, "frames_per_launch": round(frames_per_launch, 3),
                 "note": "branchy scalar-FP32 traversal: VALU/latency-bound, not HBM-bound (DESIGN.md section 6)"}
 

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -40,7 +41,7 @@ struct glrtx_ctx {
     hipEvent_t tm0 = nullptr, tm1 = nullptr;      // glrtx_timer_*
     std::string err;
 
-    DevBuf forks, tris, nrms, mats, lights, accum_own, counter, rgba8, work;
+    DevBuf forks, tris, nrms, mats, lights, vine, accum_own, counter, rgba8, work;
     DevBuf wfA[5], wfH, wfHS, wfQ;  // wavefront path state + per-workgroup queues (variant 2)
     DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
     DevBuf bvhVert, bvhTri, bvhNodes;  // glrtx_build_lbvh staging
@@ -142,7 +143,8 @@ int pfail(glrtx_ctx *c, std::string *err_out, int code, const char *fmt, ...) {
 // Validation + repacking of the wire-format scene; pure host code (no HIP calls), so it can be
 // exercised without a GPU through glrtx_check_scene.
 struct Packed {
-    std::vector<float4> forks, tris, nrms, mats, lights;
+    std::vector<float4> forks, tris, nrms, mats, lights, vine;
+    int vine_uniform = 0;
     float4 root_lo = make_float4(0.f, 0.f, 0.f, 0.f), root_hi = make_float4(0.f, 0.f, 0.f, 0.f);
     int root_ref = REF_ABSENT;
     int stack_need = 0;
@@ -277,6 +279,37 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         }
         root_ref = ref_of[0];
         stack_need = need[0];
+
+        // ---- vine: every fork has a leaf as children.y and the chain continues through children.x (what
+        // glrt_bvh_build_chain emits for "brute force, no BVH").  Stored additionally as the list the traversal visits:
+        // record i = {box of fork i, its children.y triangle}; the last record = the last fork's children.x leaf.
+        if (root_ref >= 0 && n_tri >= 2) {
+            std::vector<float4> v;
+            v.reserve(4 * n_tri);
+            bool is_vine = true, uniform = true;
+            int n = 0;
+            auto rec = [&](const float *lo, const float *hi, int t) {
+                const float4 *T = &tris[4 * (size_t)t];  // {v0, mat} {e1} {e2}
+                v.push_back(make_float4(lo[0], lo[1], lo[2], T[0].x));
+                v.push_back(make_float4(hi[0], hi[1], hi[2], T[0].y));
+                v.push_back(make_float4(T[0].z, T[1].x, T[1].y, T[1].z));
+                v.push_back(make_float4(T[2].x, T[2].y, T[2].z, as_float(t)));
+            };
+            const float inf = std::numeric_limits<float>::infinity();
+            const float all_lo[3] = {-inf, -inf, -inf}, all_hi[3] = {inf, inf, inf};
+            while (true) {
+                int l, r;
+                child(n, 0, l);
+                child(n, 1, r);
+                if (l < 0 || r < 0 || is_fork(r)) { is_vine = false; break; }
+                const float *b = bvh + 9 * (size_t)n;
+                if (std::memcmp(b, bvh, 6 * sizeof(float)) != 0) uniform = false;
+                rec(b, b + 3, ~ref_of[r]);
+                if (!is_fork(l)) { rec(all_lo, all_hi, ~ref_of[l]); break; }
+                n = l;
+            }
+            if (is_vine && v.size() == 4 * n_tri) { P.vine.swap(v); P.vine_uniform = uniform ? 1 : 0; }
+        }
     }
     if (root_ref == REF_ABSENT) {  // empty scene: one childless fork, every ray misses
         forks.assign(4, make_float4(0.f, 0.f, 0.f, as_float(REF_ABSENT)));
@@ -350,14 +383,14 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     const int lds = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
                     16 * (int)sizeof(unsigned);
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
-    const int ci = c->count_rays ? 1 : 0;
-    if (lds > 64 * 1024) {
-        HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_wgwf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_wgwf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    }
+    // four instantiations: ray counting on/off x generic tree traversal / list scan of a vine (brute-force) tree
+    using Kernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *);
+    const bool vine = c->sc.n_vine > 0;
+    const Kernel kernel = c->count_rays ? (vine ? (Kernel)pt_render_wgwf<true, true> : (Kernel)pt_render_wgwf<true, false>)
+                                        : (vine ? (Kernel)pt_render_wgwf<false, true> : (Kernel)pt_render_wgwf<false, false>);
+    if (lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     int per_cu = 0;
-    if (ci) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_wgwf<true>, kBlockThreads, lds));
-    else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_wgwf<false>, kBlockThreads, lds));
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockThreads, lds));
     if (per_cu < 1) per_cu = 1;
     if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));  // occupancy experiments
     // paths kept alive per workgroup: 1024, less when the launch cannot give every resident workgroup that many pixels
@@ -373,8 +406,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     if ((rc = ensure(c, c->wfQ, (size_t)grid * kWgQueueF4 * sizeof(float4)))) return rc;  // per-workgroup queues
     HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (ci) hipLaunchKernelGGL(pt_render_wgwf<true>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (float4 *)c->wfQ.p);
-    else hipLaunchKernelGGL(pt_render_wgwf<false>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (float4 *)c->wfQ.p);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (float4 *)c->wfQ.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->evm, c->stream));
     if (n_frames > 1 && n_planes > 0) {
@@ -438,7 +470,7 @@ void glrtx_destroy(glrtx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    dev_free(c->forks); dev_free(c->tris); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights);
+    dev_free(c->forks); dev_free(c->tris); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights); dev_free(c->vine);
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
     for (auto &b : c->wfA) dev_free(b);
     dev_free(c->wfH); dev_free(c->wfHS); dev_free(c->wfQ); dev_free(c->wfSeeds); dev_free(c->wfPlanes);
@@ -469,6 +501,7 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     if ((rc = dev_upload(c, c->nrms, nrms.data(), nrms.size() * sizeof(float4)))) return rc;
     if ((rc = dev_upload(c, c->mats, mats.data(), mats.size() * sizeof(float4)))) return rc;
     if ((rc = dev_upload(c, c->lights, lights.data(), lights.size() * sizeof(float4)))) return rc;
+    if (!P.vine.empty() && (rc = dev_upload(c, c->vine, P.vine.data(), P.vine.size() * sizeof(float4)))) return rc;
 
     DevScene &sc = c->sc;
     sc.forks = (const float4 *)c->forks.p;
@@ -482,6 +515,10 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     sc.n_mat = (int)n_mat;
     sc.stack_entries = stack_need;
     sc.mats_in_lds = (n_mat > 0 && n_mat <= (size_t)kMaxLdsMaterials) ? 1 : 0;
+    sc.vine = P.vine.empty() ? nullptr : (const float4 *)c->vine.p;
+    sc.n_vine = (int)(P.vine.size() / 4);
+    sc.vine_uniform = P.vine_uniform;
+    if (std::getenv("GLRTX_NO_VINE_SCAN")) sc.n_vine = 0;  // A/B: force the generic tree traversal
     c->n_tri = (int)n_tri; c->n_fork = (int)(forks.size() / 4); c->n_mat = (int)n_mat; c->n_light = (int)n_light;
     c->have_scene = true;
     c->st.stack_entries = stack_need;

@@ -53,6 +53,11 @@ struct DevScene {
     int n_mat;
     int stack_entries;  // per-lane traversal stack entries in LDS
     int mats_in_lds;    // 1: materials staged into LDS at kernel start
+    // "Vine" trees -- every fork has a leaf as children.y: the brute-force scan of BASELINE config 3 expressed in the
+    // node format (glrt_bvh_build_chain) -- are also stored as a list in visiting order and scanned, see trav_scan().
+    const float4 *vine;  // n_vine x 4 float4: {fork box min, v0.x} {fork box max, v0.y} {v0.z, v1-v0} {v2-v0, triangle}
+    int n_vine;          // 0: not a vine
+    int vine_uniform;    // 1: all fork boxes are the same box (vine[0]'s)
 };
 
 struct KernelArgs {
@@ -298,6 +303,85 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
         T.cur = (int)(unsigned)e;
         if (T.h.t >= __uint_as_float((unsigned)(e >> 32))) return false;
     }
+}
+
+// intersect(Ray, Triangle) :226-257 against the running closest hit; v0 / e1 = v1-v0 / e2 = v2-v0
+template <bool CLOSEST>
+DEV void tri_test(Hit &h, int t, float ox, float oy, float oz, float dx, float dy, float dz, float v0x, float v0y, float v0z, float e1x,
+                  float e1y, float e1z, float e2x, float e2y, float e2z) {
+    const float tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+    const float px = dy * e2z - dz * e2y;
+    const float py = dz * e2x - dx * e2z;
+    const float pz = dx * e2y - dy * e2x;
+    const float det = dot3(e1x, e1y, e1z, px, py, pz);
+    const float U = dot3(tx, ty, tz, px, py, pz);
+    const float inv = 1.0f / det;
+    const float u = U * inv;
+    const float qx = ty * e1z - tz * e1y;
+    const float qy = tz * e1x - tx * e1z;
+    const float qz = tx * e1y - ty * e1x;
+    const float V = dot3(dx, dy, dz, qx, qy, qz);
+    const float v = V * inv;
+    const float tt = dot3(e2x, e2y, e2z, qx, qy, qz) * inv;
+    const bool hit = !(-PT_EPS < det && det < PT_EPS) && !(u < 0.0f || 1.0f < u) && !(v < 0.0f || 1.0f < inv * (U + V)) && !(PT_EPS >= tt);
+    const bool closer = hit && tt < h.t;
+    h.tri = closer ? t : h.tri;
+    if (CLOSEST) { h.u = closer ? u : h.u; h.v = closer ? v : h.v; }
+    h.t = hit ? __builtin_fminf(h.t, tt) : h.t;
+}
+
+// Traversal of a vine = a scan of its list in the order the reference's DFS meets the nodes: fork i (its own box is
+// tested against the current tHit, :296-298; a failed test pushes nothing, which ends the traversal), then the
+// triangle hanging off it; the last record is the final fork's other leaf, reached without a test (infinite box).
+// All lanes of a wave walk the same list position: the record address is wave-uniform, so the compiler fetches it
+// with scalar loads and broadcasts it -- no vector-memory traffic, no stack.
+template <bool CLOSEST>
+DEV Hit trav_scan(const DevScene &sc, float ox, float oy, float oz, float dx, float dy, float dz, bool valid) {
+    Hit h;
+    h.t = PT_INFTY; h.tri = -1; h.u = 0.f; h.v = 0.f;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    bool alive = valid;
+    float t0u = 0.f, t1u = 0.f;
+    if (sc.vine_uniform) {  // one box for every fork: its slab interval is a per-ray constant
+        const float4 lo = sc.vine[0], hi = sc.vine[1];
+        const float fx = (hi.x - ox) * ix, fy = (hi.y - oy) * iy, fz = (hi.z - oz) * iz;
+        const float nx = (lo.x - ox) * ix, ny = (lo.y - oy) * iy, nz = (lo.z - oz) * iz;
+        t1u = __builtin_fminf(__builtin_fmaxf(fx, nx), __builtin_fminf(__builtin_fmaxf(fy, ny), __builtin_fmaxf(fz, nz)));
+        t0u = __builtin_fmaxf(__builtin_fminf(fx, nx), __builtin_fmaxf(__builtin_fminf(fy, ny), __builtin_fminf(fz, nz)));
+    }
+    const int n = sc.n_vine;
+    // Records come in through the scalar cache (the list position is wave-uniform), one record ahead of the arithmetic:
+    // 16 SGPRs per record, two sets used alternately.  (As plain loads the compiler issues them on the vector-memory
+    // path, per lane.)  The waits are explicit because the compiler does not count loads issued from inline asm.
+    typedef float rec_t __attribute__((ext_vector_type(16)));
+    auto issue = [&](rec_t &r, int i) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(sc.vine + 4 * (size_t)i) : "memory"); };
+    auto arrive = [&](rec_t &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r) : : "memory"); };  // readers of r are ordered behind the wait
+    auto step = [&](const rec_t &r, int i) {
+        if (alive) {
+            bool pass;
+            if (sc.vine_uniform && i + 1 < n) pass = __builtin_fminf(t1u, h.t) >= t0u;
+            else {
+                float t0;
+                pass = box_pass(make_float4(r[0], r[1], r[2], 0.f), make_float4(r[4], r[5], r[6], 0.f), ox, oy, oz, ix, iy, iz, h.t, t0);
+            }
+            alive = pass;
+            if (pass) tri_test<CLOSEST>(h, __float_as_int(r[15]), ox, oy, oz, dx, dy, dz, r[3], r[7], r[8], r[9], r[10], r[11], r[12], r[13], r[14]);
+        }
+    };
+    rec_t r0, r1;
+    issue(r0, 0);
+    arrive(r0);
+    for (int i = 0; i < n; i += 2) {
+        if (!__any(alive)) break;
+        if (i + 1 < n) issue(r1, i + 1);
+        step(r0, i);
+        if (i + 1 >= n) break;
+        arrive(r1);
+        if (i + 2 < n) issue(r0, i + 2);
+        step(r1, i + 1);
+        if (i + 2 < n) arrive(r0);
+    }
+    return h;
 }
 
 template <bool CLOSEST>
@@ -1077,9 +1161,28 @@ __device__ uint4 g_trip_log[16][64];
 // needed (64 at a time through *ray_head, an LDS counter).  A refill therefore touches no memory: the idle lane with
 // rank r takes the record held by lane (consumed + r) through a cross-lane read.  (Fetching a ray when a lane fell
 // idle -- queue index, then path state, two dependent round trips -- cost 14 % of the phase.)
+template <bool VINE>
 DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned &rays) {
     const int lane = threadIdx.x & 63;
+    if (VINE) {  // list scan: every ray takes the same number of steps, so waves simply take 64 rays at a time
+        for (;;) {
+            int base = 0;
+            if (lane == 0) base = (int)atomicAdd(ray_head, 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n_rays) break;
+            float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID)), d = o;
+            if (base + lane < n_rays) { o = rq[2 * (size_t)(base + lane)]; d = rq[2 * (size_t)(base + lane) + 1]; }
+            const unsigned r = __float_as_uint(o.w);
+            const Hit h = trav_scan<true>(a.sc, o.x, o.y, o.z, d.x, d.y, d.z, r != WF_INVALID);
+            if (r != WF_INVALID) {
+                rays++;
+                if (r & 1u) w.HS[r >> 1] = make_float2(h.t, __int_as_float(h.tri));
+                else w.H[r >> 1] = make_float4(h.t, __int_as_float(h.tri), h.u, h.v);
+            }
+        }
+        return;
+    }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float4 none = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID));
     float4 cur_o = none, cur_d = none, next_o = none, next_d = none;  // this lane's record of the current / next chunk
@@ -1216,7 +1319,7 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
     }
 }
 
-template <bool COUNT_RAYS>
+template <bool COUNT_RAYS, bool VINE>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // LDS: materials | stack | ctl[16].  The workgroup's ray/path queues live in its private slice of a
@@ -1293,7 +1396,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 
         // ---- traverse phase: lanes pull rays; a lane whose ray is finished takes the next one
         PH_STAMP(pt0);
-        wg_traverse_phase(a, w, stack, rq, n_rays, &ctl[1], rays);
+        wg_traverse_phase<VINE>(a, w, stack, rq, n_rays, &ctl[1], rays);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written
         PH_STAMP(pt2);

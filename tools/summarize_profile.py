@@ -40,7 +40,7 @@ for k, cs in agg.items():
               "counters_avg_per_launch": {c: sum(v) / len(v) for c, v in sorted(cs.items())}}
 (dst / f"{tag}_pmc.json").write_text(json.dumps(out, indent=1))
 
-main = [k for k in out if "<false>" in k or "Lb0" in k]
+main = [k for k in out if "wgwf<false" in k or "wgwfILb0" in k]
 if main:
     c = out[main[0]]["counters_avg_per_launch"]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
