@@ -335,3 +335,19 @@ def test_frames_in_flight_are_chunked_by_the_memory_budget(gpu_device, monkeypat
         st = d.stats()
         assert st.launches == 7 and st.kernel_launches == launches, (budget_mb, st.kernel_launches)
         assert_bit_equal(d.read_accum(), want, f"budget {budget_mb} MB")
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 2), (17, 1), (1, 33), (9, 9)])
+def test_tiny_images_single_and_in_flight(gpu_device, w, h):
+    """Images far smaller than a tile / a workgroup's path set: one frame per launch and four in flight vs the oracle."""
+    from oracle import pt_oracle
+    d = gpu_device
+    scene, params = scenes.config_c1(width=w, height=h, max_depth=4, n_samples=2, subdiv=1)
+    seeds = _seeds(4)
+    ref = None
+    for sd in seeds:
+        ref, _ = pt_oracle.render(scene, dict(params, seed=sd), accum=ref)
+    seq, _ = gpu_render(d, scene, params, frames=seeds)
+    assert_bit_equal(seq, ref, f"{w}x{h} consecutive launches")
+    d.clear(); d.render_frames(params, seeds); d.sync()
+    assert_bit_equal(d.read_accum(), ref, f"{w}x{h} frames in flight")
