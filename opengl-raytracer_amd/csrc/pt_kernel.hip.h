@@ -197,9 +197,23 @@ DEV void trav_stats_iter(int cur) {
 // Traversal state of one ray: the DFS above as an explicit state machine, so that the megakernels
 // (run it to completion) and the wavefront traversal kernel (one step per loop trip, lanes refilled
 // with fresh rays as they finish) execute literally the same code.
+// Shadow rays (sampleDirect, :337-403) are closest-hit queries in the reference, but their result is used for one thing
+// only: "hit && |dist - tHit| < EPS" (:367).  That outcome is settled early in two ways, both exact:
+//  * no hit at or beyond `limit` = max(dist + 2 EPS, the float after dist) can be accepted (dist - t <= -EPS for all of
+//    them, also after rounding), and if the closest hit lies out there the test fails whatever it is -- so the search starts
+//    with tHit = limit instead of INFTY and reports a miss in that case (same outcome: rejected);
+//  * once any hit with dist - t >= EPS is known the test has failed: the final tHit can only be smaller, and rounding is
+//    monotonic -- so the traversal stops there.
+// A path's own rays use limit = INFTY and stop_d = -inf, which switches both off.
+DEV float shadow_limit(float dist) {
+    const float m = __builtin_fmaxf(dist + 2.0f * PT_EPS, __uint_as_float(__float_as_uint(dist) + 1u));
+    return fmin_c(m, PT_INFTY);  // NaN distance: INFTY, i.e. the unrestricted search
+}
+
 struct Trav {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz;
     Hit h;
+    float stop_d;  // shadow rays: the light sample's distance; others: -inf
     int cur, sp;
 #ifdef GLRTX_TRAV_STATS
     unsigned iters;
@@ -207,10 +221,12 @@ struct Trav {
 };
 
 // Returns false if the ray is finished before the first step (root box missed).
-DEV bool trav_init(const DevScene &sc, Trav &T, float ox, float oy, float oz, float dx, float dy, float dz) {
+DEV bool trav_init(const DevScene &sc, Trav &T, float ox, float oy, float oz, float dx, float dy, float dz,
+                   float limit = PT_INFTY, float stop_d = -__builtin_inff()) {
     T.ox = ox; T.oy = oy; T.oz = oz; T.dx = dx; T.dy = dy; T.dz = dz;
     T.ix = 1.0f / dx; T.iy = 1.0f / dy; T.iz = 1.0f / dz;  // :260 (loop-invariant there)
-    T.h.t = PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
+    T.h.t = limit; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
+    T.stop_d = stop_d;
     T.sp = 0;
     T.cur = sc.root_ref;
 #ifdef GLRTX_TRAV_STATS
@@ -288,6 +304,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
         T.h.tri = closer ? t : T.h.tri;
         if (CLOSEST) { T.h.u = closer ? u : T.h.u; T.h.v = closer ? v : T.h.v; }
         T.h.t = hit ? __builtin_fminf(T.h.t, tt) : T.h.t;
+        if (T.stop_d - T.h.t >= PT_EPS) { TS_DONE; return true; }  // shadow ray: an occluder is known, the light test has failed
     }
     if (!need_pop) return false;
     // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298
@@ -336,9 +353,10 @@ DEV void tri_test(Hit &h, int t, float ox, float oy, float oz, float dx, float d
 // All lanes of a wave walk the same list position: the record address is wave-uniform, so the compiler fetches it
 // with scalar loads and broadcasts it -- no vector-memory traffic, no stack.
 template <bool CLOSEST>
-DEV Hit trav_scan(const DevScene &sc, float ox, float oy, float oz, float dx, float dy, float dz, bool valid) {
+DEV Hit trav_scan(const DevScene &sc, float ox, float oy, float oz, float dx, float dy, float dz, bool valid,
+              float limit = PT_INFTY, float stop_d = -__builtin_inff()) {
     Hit h;
-    h.t = PT_INFTY; h.tri = -1; h.u = 0.f; h.v = 0.f;
+    h.t = limit; h.tri = -1; h.u = 0.f; h.v = 0.f;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     bool alive = valid;
     float t0u = 0.f, t1u = 0.f;
@@ -365,7 +383,10 @@ DEV Hit trav_scan(const DevScene &sc, float ox, float oy, float oz, float dx, fl
                 pass = box_pass(make_float4(r[0], r[1], r[2], 0.f), make_float4(r[4], r[5], r[6], 0.f), ox, oy, oz, ix, iy, iz, h.t, t0);
             }
             alive = pass;
-            if (pass) tri_test<CLOSEST>(h, __float_as_int(r[15]), ox, oy, oz, dx, dy, dz, r[3], r[7], r[8], r[9], r[10], r[11], r[12], r[13], r[14]);
+            if (pass) {
+                tri_test<CLOSEST>(h, __float_as_int(r[15]), ox, oy, oz, dx, dy, dz, r[3], r[7], r[8], r[9], r[10], r[11], r[12], r[13], r[14]);
+                if (stop_d - h.t >= PT_EPS) alive = false;  // shadow ray: occluded for certain (see Trav)
+            }
         }
     };
     rec_t r0, r1;
@@ -385,9 +406,10 @@ DEV Hit trav_scan(const DevScene &sc, float ox, float oy, float oz, float dx, fl
 }
 
 template <bool CLOSEST>
-DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, float dx, float dy, float dz) {
+DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, float dx, float dy, float dz,
+                 float limit = PT_INFTY, float stop_d = -__builtin_inff()) {
     Trav T;
-    if (trav_init(sc, T, ox, oy, oz, dx, dy, dz))
+    if (trav_init(sc, T, ox, oy, oz, dx, dy, dz, limit, stop_d))
         while (!trav_step<CLOSEST>(sc, stack, T)) {}
     return T.h;
 }
@@ -722,7 +744,7 @@ DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rn
     shade_hit(a, lds_mats, rng, P, h, sh);
     bool ok = false;
     if (sh.has_shadow) {
-        const Hit s = traverse<false>(a.sc, stack, P.ox, P.oy, P.oz, sh.sdx, sh.sdy, sh.sdz);
+        const Hit s = traverse<false>(a.sc, stack, P.ox, P.oy, P.oz, sh.sdx, sh.sdy, sh.sdz, shadow_limit(sh.dist), sh.dist);
         rays++;
         ok = nee_accepted(sh.dist, s.t, s.tri >= 0);
     }
@@ -1117,7 +1139,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         if (push_sh) w.A4[id] = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f);
         ray_o = make_float4(P.ox, P.oy, P.oz, 0.f);  // the next ray and the shadow ray leave from the same point
         ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
-        ray_sd = make_float4(sh.sdx, sh.sdy, sh.sdz, 0.f);
+        ray_sd = make_float4(sh.sdx, sh.sdy, sh.sdz, sh.dist);
     }
 }
 
@@ -1174,7 +1196,9 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
             float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID)), d = o;
             if (base + lane < n_rays) { o = rq[2 * (size_t)(base + lane)]; d = rq[2 * (size_t)(base + lane) + 1]; }
             const unsigned r = __float_as_uint(o.w);
-            const Hit h = trav_scan<true>(a.sc, o.x, o.y, o.z, d.x, d.y, d.z, r != WF_INVALID);
+            const bool shadow = (r & 1u) != 0u;
+            const Hit h = trav_scan<true>(a.sc, o.x, o.y, o.z, d.x, d.y, d.z, r != WF_INVALID, shadow ? shadow_limit(d.w) : PT_INFTY,
+                                          shadow ? d.w : -__builtin_inff());
             if (r != WF_INVALID) {
                 rays++;
                 if (r & 1u) w.HS[r >> 1] = make_float2(h.t, __int_as_float(h.tri));
@@ -1245,12 +1269,15 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
                 const float ox = __shfl(cur_o.x, src), oy = __shfl(cur_o.y, src), oz = __shfl(cur_o.z, src);
                 const unsigned new_rid = (unsigned)__shfl((int)__float_as_uint(cur_o.w), src);
                 const float dx = __shfl(cur_d.x, src), dy = __shfl(cur_d.y, src), dz = __shfl(cur_d.z, src);
+                const float dist = __shfl(cur_d.w, src);  // shadow rays: distance of the light sample
                 if (!active && rank < take) {
                     if (unsaved) save_hit();
                     rid = new_rid;
                     if (rid != WF_INVALID) {
                         rays++;
-                        active = trav_init(a.sc, T, ox, oy, oz, dx, dy, dz);
+                        const bool shadow = (rid & 1u) != 0u;
+                        active = trav_init(a.sc, T, ox, oy, oz, dx, dy, dz, shadow ? shadow_limit(dist) : PT_INFTY,
+                                           shadow ? dist : -__builtin_inff());
                         unsaved = !active;  // root box missed: the (miss) record is already final
                     }
                 }
