@@ -481,6 +481,8 @@ struct Shade {
     float dist;           // |p - x| for the acceptance test |dist - tHit| < EPS
     float Lpx, Lpy, Lpz;  // L with the light sample accepted (== L itself when !has_shadow)
     float Lfx, Lfy, Lfz;  // L with it rejected
+    bool untraced;        // the reference traces a shadow ray here, but both outcomes give the same L bit for bit (no
+                          // contribution: a cosine <= 0, or one too small to register): counted as a ray, not traced
 };
 
 DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &P, const Hit &h, Shade &out) {
@@ -723,10 +725,16 @@ DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &
     P.depth = depth + 1;
     out.ended = done || P.depth >= a.max_depth;
     out.has_shadow = has_shadow;
+    out.untraced = false;
     out.sdx = sdx; out.sdy = sdy; out.sdz = sdz; out.dist = sdist;
     if (has_shadow) {
         out.Lpx = Lx + px_; out.Lpy = Ly + py_; out.Lpz = Lz + pz_;
         out.Lfx = Lx + zx_; out.Lfy = Ly + zy_; out.Lfz = Lz + zz_;
+        if (__float_as_uint(out.Lpx) == __float_as_uint(out.Lfx) && __float_as_uint(out.Lpy) == __float_as_uint(out.Lfy) &&
+            __float_as_uint(out.Lpz) == __float_as_uint(out.Lfz)) {
+            out.has_shadow = false;  // whatever the shadow ray finds, L is the same
+            out.untraced = true;
+        }
     } else {
         out.Lpx = out.Lfx = Lx; out.Lpy = out.Lfy = Ly; out.Lpz = out.Lfz = Lz;
     }
@@ -747,6 +755,8 @@ DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rn
         const Hit s = traverse<false>(a.sc, stack, P.ox, P.oy, P.oz, sh.sdx, sh.sdy, sh.sdz, shadow_limit(sh.dist), sh.dist);
         rays++;
         ok = nee_accepted(sh.dist, s.t, s.tri >= 0);
+    } else if (sh.untraced) {
+        rays++;  // an execution of intersect() in the reference; its result cannot change L (Shade::untraced)
     }
     P.Lx = ok ? sh.Lpx : sh.Lfx; P.Ly = ok ? sh.Lpy : sh.Lfy; P.Lz = ok ? sh.Lpz : sh.Lfz;
     return sh.ended;
@@ -1081,7 +1091,7 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id, float4 &r
 // sample (and start the pixel's next one) or run shade_hit() on the new hit.  Outputs which rays to
 // queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray.
 DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, unsigned id, bool &push_ext, bool &push_sh,
-                       float4 &ray_o, float4 &ray_d, float4 &ray_sd) {
+                       float4 &ray_o, float4 &ray_d, float4 &ray_sd, unsigned &rays) {
     int lx, lrow;
     wf_pixel(a, w, (int)id, lx, lrow);
     const int gy = local_row_to_y(a, lrow);
@@ -1112,6 +1122,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         Hit h;
         h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
         shade_hit(a, lds_mats, rng, P, h, sh);
+        if (sh.untraced) rays++;  // counted as the reference's intersect() call, not traced (Shade::untraced)
         if (sh.ended && !sh.has_shadow) { P.Lx = sh.Lpx; P.Ly = sh.Lpy; P.Lz = sh.Lpz; }
         ended = sh.ended && !sh.has_shadow;  // with a shadow ray in flight the sample closes next trip
     }
@@ -1312,7 +1323,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
 // goes through wf_shade_path(); the rays and paths of the next trip are appended to rq_next / pq_next
 // (wave-aggregated, one LDS atomic per wave and queue on *n_rays_next / *n_paths_next).
 DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const unsigned *pq, int n_paths,
-                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next) {
+                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned &rays) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int j0 = 0; j0 < n_paths; j0 += kBlockThreads) {
@@ -1321,7 +1332,7 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         unsigned id = WF_INVALID;
         float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro, rsd = ro;
         if (i < n_paths) id = pq[i];
-        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, id, push_ext, push_sh, ro, rd, rsd);
+        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, id, push_ext, push_sh, ro, rd, rsd, rays);
         const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
         unsigned br = 0, bp = 0;
         if (lane == 0) {
@@ -1432,7 +1443,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 
         // ---- shade phase: the live paths; appends go to the other queue pair
         wg_shade_phase(a, w, lds_mats, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
-                       &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)]);
+                       &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], rays);
         PH_STAMP(ps1);
         __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
         PH_STAMP(ps2);
