@@ -17,7 +17,8 @@ With N > 1 ranks the image rows are sharded in interleaved 16-row stripes (one p
 global pixel coordinates, no data-path collective) and every launch ends with the RCCL all_gather of
 the finished rows ("gather the framebuffer"), inside the timed region.
 Scene and accumulators are resident in HBM before timing starts.  Rays are counted exactly (one
-execution of intersect() = one ray) by an untimed pass over the same seeds with the
+execution of intersect() in the reference's algorithm = one ray; the few the kernel can
+resolve without a traversal are reported separately as rays_untraced_per_frame) by an untimed pass over the same seeds with the
 counting variant of the kernel; the timed launches use the clean kernel.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
@@ -139,6 +140,7 @@ def main():
     run(args.warmup, args.warmup + args.steps, gather=False)
     dev.sync()
     rays_local = int(dev.stats().rays)
+    untraced_local = int(dev.stats().rays_untraced)
     dev.count_rays(False)
     accum.zero_()
     dev.reset_stats()
@@ -173,13 +175,13 @@ def main():
         single = float(single.item()) / n1
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([rays_local], dtype=torch.int64, device="cuda")
+    rays = torch.tensor([rays_local, untraced_local], dtype=torch.int64, device="cuda")
     kern_ms = torch.tensor([st.kernel_ms_total / max(st.kernel_launches, 1)], dtype=torch.float64, device="cuda")
     if world > 1:
         td.all_reduce(elapsed, op=td.ReduceOp.MAX)
         td.all_reduce(rays, op=td.ReduceOp.SUM)
         td.all_reduce(kern_ms, op=td.ReduceOp.MAX)
-    elapsed_s, total_rays, kernel_ms = float(elapsed.item()), int(rays.item()), float(kern_ms.item())
+    elapsed_s, total_rays, total_untraced, kernel_ms = float(elapsed.item()), int(rays[0].item()), int(rays[1].item()), float(kern_ms.item())
 
     # ---- roofline of the render kernel (per launch, per GPU): algorithmic bytes / measured launch duration
     scene_b = scenes.scene_bytes(scene)
@@ -239,6 +241,9 @@ def main():
                        "one_launch_per_frame": None if single is None else
                            {"ms_per_step": round(single * 1e3, 4), "value": round(total_rays / args.steps / single / 1e6, 3)},
                        "rays_per_frame": round(total_rays / args.steps, 1),
+                       # of those, shadow rays whose light test cannot change the radiance (both outcomes bit-identical):
+                       # counted like the reference counts them, resolved without a traversal
+                       "rays_untraced_per_frame": round(total_untraced / args.steps, 1),
                        "mpaths_per_s": round(W * H * params["n_samples"] * args.steps / elapsed_s / 1e6, 3),
                        "event_ms_per_step": round(ev_ms / args.steps, 4)},
             "roofline": roofline,

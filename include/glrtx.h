@@ -52,7 +52,7 @@ extern "C" {
 #define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
 #define GLRTX_ENOMEM (-5)
 
-#define GLRTX_ABI_VERSION 2
+#define GLRTX_ABI_VERSION 3
 
 typedef struct glrtx_ctx glrtx_ctx;
 
@@ -71,6 +71,9 @@ typedef struct glrtx_params {
 typedef struct glrtx_stats {
     uint64_t rays;          /* executions of intersect(Ray, out Intersection) since last clear/reset_stats;
                                only counted by launches made while ray counting is enabled */
+    uint64_t rays_untraced; /* of `rays`: shadow rays the reference traces although both outcomes of its light test give the
+                               same radiance bit for bit (a cosine <= 0, or a contribution too small to register); they are
+                               counted above but resolved without a traversal */
     uint64_t paths;         /* pixel samples traced (owned pixels * n_samples per launch) */
     uint64_t launches;      /* frames rendered: glrtx_render calls + frames of glrtx_render_frames calls */
     uint64_t kernel_launches; /* launches of the render kernel (one per glrtx_render / glrtx_render_frames call) */

@@ -452,8 +452,8 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->evm)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipEventCreate(&c->tm0)) != hipSuccess || (e = hipEventCreate(&c->tm1)) != hipSuccess ||
-        (e = hipMalloc(&c->counter.p, sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMemset(c->counter.p, 0, sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc(&c->counter.p, 2 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc(&c->work.p, 64)) != hipSuccess) {
         fail(nullptr, GLRTX_EDEVICE, "context setup failed: %s", hipGetErrorString(e));
         glrtx_destroy(c);
@@ -825,16 +825,16 @@ int glrtx_resolve_rgba8(glrtx_ctx *c, uint8_t *dst, size_t dst_pitch_bytes, floa
 int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
     if (!c || !out) return GLRTX_EINVAL;
     *out = c->st;
-    unsigned long long r = 0;
-    if (c->counter.p && hipMemcpy(&r, c->counter.p, sizeof r, hipMemcpyDeviceToHost) == hipSuccess) out->rays = r;
+    unsigned long long r[2] = {0, 0};
+    if (c->counter.p && hipMemcpy(r, c->counter.p, sizeof r, hipMemcpyDeviceToHost) == hipSuccess) { out->rays = r[0]; out->rays_untraced = r[1]; }
     return GLRTX_OK;
 }
 
 int glrtx_reset_stats(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
     if (int rc = glrtx_sync(c)) return rc;
-    HIP_TRY(c, hipMemset(c->counter.p, 0, sizeof(unsigned long long)));
-    c->st.rays = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f;
+    HIP_TRY(c, hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long)));
+    c->st.rays = 0; c->st.rays_untraced = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f;
     return GLRTX_OK;
 }
 

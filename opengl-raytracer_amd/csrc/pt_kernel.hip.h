@@ -745,7 +745,7 @@ DEV bool nee_accepted(float dist, float tS, bool hit) { return hit && __builtin_
 
 // One iteration of the depth loop (megakernel form).  Returns true when the loop ends (a `break`, or
 // depth reaching u_maxDepth).  Precondition: P.depth < a.max_depth.
-DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rng, Path &P, unsigned &rays) {
+DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rng, Path &P, unsigned long long &rays) {
     const Hit h = traverse<true>(a.sc, stack, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz);
     rays++;
     Shade sh;
@@ -756,7 +756,7 @@ DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rn
         rays++;
         ok = nee_accepted(sh.dist, s.t, s.tri >= 0);
     } else if (sh.untraced) {
-        rays++;  // an execution of intersect() in the reference; its result cannot change L (Shade::untraced)
+        rays += (1ull << 32) + 1ull;  // an execution of intersect() in the reference; its result cannot change L (Shade::untraced)
     }
     P.Lx = ok ? sh.Lpx : sh.Lfx; P.Ly = ok ? sh.Lpy : sh.Lfy; P.Lz = ok ? sh.Lpz : sh.Lfz;
     return sh.ended;
@@ -829,11 +829,14 @@ DEV void lds_setup(const KernelArgs &a, unsigned char *lds_raw, float4 *&lds_mat
 }
 
 template <bool COUNT_RAYS>
-DEV void flush_rays(const KernelArgs &a, unsigned rays) {
-    if (COUNT_RAYS) {  // wave-level sum, one atomic per wavefront
-        unsigned long long r = rays;
-        for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
-        if ((threadIdx.x & 63) == 0 && r) atomicAdd(a.ray_counter, r);
+DEV void flush_rays(const KernelArgs &a, unsigned long long rays) {
+    if (COUNT_RAYS) {  // wave-level sums, one atomic per wavefront and counter
+        unsigned long long r = rays & 0xFFFFFFFFull, u = rays >> 32;
+        for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); u += __shfl_down(u, off); }
+        if ((threadIdx.x & 63) == 0) {
+            if (r) atomicAdd(a.ray_counter, r);
+            if (u) atomicAdd(a.ray_counter + 1, u);
+        }
     }
 }
 
@@ -851,7 +854,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_kernel(const KernelAr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = (tile % a.tiles_x) * kTile + (wave & 1) * 8 + (lane & 7);
     const int lrow = (tile / a.tiles_x) * kTile + (wave >> 1) * 8 + (lane >> 3);
-    unsigned rays = 0;
+    unsigned long long rays = 0;  // low half: reference rays, high half: those resolved without a traversal
     if (lx < a.width && lrow < a.owned_rows) {
         const int gy = local_row_to_y(a, lrow);
         const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     Path P;
     path_begin(P, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
-    unsigned rays = 0;
+    unsigned long long rays = 0;  // low half: reference rays, high half: those resolved without a traversal
 
     for (;;) {
         // ---- regeneration: idle lanes take the next pixels of the wave's chunk
@@ -1091,7 +1094,7 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id, float4 &r
 // sample (and start the pixel's next one) or run shade_hit() on the new hit.  Outputs which rays to
 // queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray.
 DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, unsigned id, bool &push_ext, bool &push_sh,
-                       float4 &ray_o, float4 &ray_d, float4 &ray_sd, unsigned &rays) {
+                       float4 &ray_o, float4 &ray_d, float4 &ray_sd, unsigned long long &rays) {
     int lx, lrow;
     wf_pixel(a, w, (int)id, lx, lrow);
     const int gy = local_row_to_y(a, lrow);
@@ -1122,7 +1125,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         Hit h;
         h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
         shade_hit(a, lds_mats, rng, P, h, sh);
-        if (sh.untraced) rays++;  // counted as the reference's intersect() call, not traced (Shade::untraced)
+        if (sh.untraced) rays += (1ull << 32) + 1ull;  // counted as the reference's intersect() call, not traced (Shade::untraced)
         if (sh.ended && !sh.has_shadow) { P.Lx = sh.Lpx; P.Ly = sh.Lpy; P.Lz = sh.Lpz; }
         ended = sh.ended && !sh.has_shadow;  // with a shadow ray in flight the sample closes next trip
     }
@@ -1196,7 +1199,7 @@ __device__ uint4 g_trip_log[16][64];
 // idle -- queue index, then path state, two dependent round trips -- cost 14 % of the phase.)
 template <bool VINE>
 DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, const float4 *rq, int n_rays,
-                           unsigned *ray_head, unsigned &rays) {
+                           unsigned *ray_head, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
     if (VINE) {  // list scan: every ray takes the same number of steps, so waves simply take 64 rays at a time
         for (;;) {
@@ -1323,7 +1326,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
 // goes through wf_shade_path(); the rays and paths of the next trip are appended to rq_next / pq_next
 // (wave-aggregated, one LDS atomic per wave and queue on *n_rays_next / *n_paths_next).
 DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const unsigned *pq, int n_paths,
-                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned &rays) {
+                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int j0 = 0; j0 < n_paths; j0 += kBlockThreads) {
@@ -1376,7 +1379,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 
     const int kWgPaths = w.block_paths;
     const int n_tiles = w.tiles_per_frame * w.n_frames;  // 8x8-pixel tiles (64 consecutive tile-order ids each), frame-major
-    unsigned rays = 0;
+    unsigned long long rays = 0;  // low half: reference rays, high half: those resolved without a traversal
 #ifdef GLRTX_PHASE_STATS
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.x / 64 < 16)
         g_trip_log[blockIdx.x / 64][0].y = (unsigned)(__builtin_amdgcn_s_memtime() >> 4);

@@ -22,7 +22,7 @@ class Params(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("launches", C.c_uint64), ("kernel_launches", C.c_uint64),
+    _fields_ = [("rays", C.c_uint64), ("rays_untraced", C.c_uint64), ("paths", C.c_uint64), ("launches", C.c_uint64), ("kernel_launches", C.c_uint64),
                 ("kernel_ms_total", C.c_double), ("accumulate_ms_total", C.c_double), ("kernel_ms_last", C.c_float),
                 ("frames_last", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("owned_rows", C.c_int32),
                 ("stack_entries", C.c_int32), ("lds_bytes", C.c_int32), ("n_tri", C.c_int32), ("n_fork", C.c_int32),

@@ -351,3 +351,18 @@ def test_tiny_images_single_and_in_flight(gpu_device, w, h):
     assert_bit_equal(seq, ref, f"{w}x{h} consecutive launches")
     d.clear(); d.render_frames(params, seeds); d.sync()
     assert_bit_equal(d.read_accum(), ref, f"{w}x{h} frames in flight")
+
+
+def test_untraced_rays_are_a_subset_and_disappear_without_lights(gpu_device):
+    """stats.rays counts the reference's intersect() executions (== oracle); rays_untraced are the shadow rays among them
+    whose light test cannot change the radiance.  A scene without emitters has shadow rays (the reference still calls
+    sampleDirect) whose contribution is always zero: all of them are untraced."""
+    from oracle import pt_oracle
+    d = gpu_device
+    scene, params = scenes.config_c2(width=160, height=90, max_depth=4, subdiv=1)
+    _, st = gpu_render(d, scene, params)
+    _, ref_rays = pt_oracle.render(scene, params)
+    assert st.rays == ref_rays and 0 < st.rays_untraced < st.rays // 2
+    golden = load_golden("no_lights")
+    acc, st = gpu_render(d, golden[0], golden[1], golden[3])
+    assert st.rays_untraced > 0

@@ -13,4 +13,5 @@ for v in (2,):
     d.render_frames(pr, [host.frame_seed(f) for f in range(B)]); d.sync()
     L.glrtx_debug_trav_stats(out); o = list(out); rays = d.stats().rays
     hh = (C.c_ulonglong * 16)(); L.glrtx_debug_trav_hist(hh); print("iterations histogram (<=1,2,4,8,...):", list(hh))
+    print(f"rays traced {sum(hh)} of {rays} reference rays ({100.0*sum(hh)/max(rays,1):.1f} %)")
     print(f"variant {v}: rays {rays} wave_iters {o[0]} lane_iters {o[1]} simd_eff {o[1]/(64*o[0]):.3f} fork_lane {o[2]} leaf_lane {o[3]} mixed_iters {o[4]/o[0]:.3f} iters/ray {o[1]/rays:.1f} forks/ray {o[2]/rays:.1f} leaves/ray {o[3]/rays:.1f}")
