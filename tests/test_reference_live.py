@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import assert_bit_equal
+from fuzz_scenes import CASES as FUZZ_CASES, case_scene_and_params
 from glrt_amd import scenes
 from oracle import glref, pt_oracle
 
@@ -44,3 +45,14 @@ def test_random_seeds_sweep(gl):
         rgb, cnt = gl.render_reference(sc, p)
         acc, _ = pt_oracle.render(sc, p)
         assert_bit_equal(acc[..., :3], rgb, f"seed {p['seed']}")
+
+
+@pytest.mark.parametrize("case", FUZZ_CASES, ids=[f"seed{c[0]}" for c in FUZZ_CASES])
+def test_oracle_bit_exact_vs_live_reference_on_adversarial_scenes(gl, case):
+    """The scenes of tests/test_gpu_fuzz.py (ties, degenerate and axis-aligned geometry, large distances, 1-2 triangles)
+    through the reference's own shader: pins the oracle where the GPU tests rely on it."""
+    sc, pr = case_scene_and_params(case)
+    rgb, cnt = gl.render_reference(sc, pr)
+    acc, _ = pt_oracle.render(sc, pr)
+    assert_bit_equal(acc[..., :3], rgb, "rgb")
+    assert_bit_equal(acc[..., 3], cnt, "count")
