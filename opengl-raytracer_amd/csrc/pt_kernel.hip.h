@@ -1167,7 +1167,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 // shade kernel per trip lost ~300 us per trip to that wait, nine times a frame).  One launch covers one frame, or
 // several frames in flight (WfArgs).  Path state lives in HBM as float4 SoA.
 #ifndef GLRTX_STEPS_PER_TRIP
-#define GLRTX_STEPS_PER_TRIP 2
+#define GLRTX_STEPS_PER_TRIP 4
 #endif
 constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes its queues); the host picks block_paths <= this so
                                    // that the launch has that many pixels for every resident workgroup
