@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="headline", help="headline | c2 | c3 | c4 | c5 (parity-test configs)")
+    ap.add_argument("--bvh", default="default", help="default (the config's CPU SAH tree) | lbvh (linear BVH built on the GPU, glrtx_build_lbvh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-gather", action="store_true", help="skip the framebuffer gather (N > 1)")
@@ -98,6 +99,9 @@ def main():
     n_tri = int(scene["tri"].shape[0])
 
     dev = device.Device(local_rank)
+    if args.bvh == "lbvh":  # BASELINE config 5: "linear-BVH traversal"
+        nodes, depth, build_ms = dev.build_lbvh(scene["vert"], scene["tri"])
+        scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"lbvh, built on the GPU in {build_ms:.2f} ms")
     dev.upload_scene(scene)
     dev.set_partition(rank, world, STRIPE)
     dev.resize(W, H)
