@@ -1437,7 +1437,11 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 
         // ---- traverse phase: lanes pull rays; a lane whose ray is finished takes the next one
         PH_STAMP(pt0);
+        // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
+        // their loads get going earlier (measured 1-2 %)
+        __builtin_amdgcn_s_setprio(3);
         wg_traverse_phase<VINE>(a, w, stack, rq, n_rays, &ctl[1], rays);
+        __builtin_amdgcn_s_setprio(0);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written
         PH_STAMP(pt2);
