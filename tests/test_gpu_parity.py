@@ -366,3 +366,29 @@ def test_untraced_rays_are_a_subset_and_disappear_without_lights(gpu_device):
     golden = load_golden("no_lights")
     acc, st = gpu_render(d, golden[0], golden[1], golden[3])
     assert st.rays_untraced > 0
+
+
+def test_more_materials_than_fit_in_lds(gpu_device):
+    """> 256 materials: the material table stays in global memory instead of being staged into LDS."""
+    from oracle import pt_oracle
+    rng = np.random.default_rng(77)
+    pos, nrm, _ = scenes.random_triangles(600, 78, 1.0, 1.0)
+    b = scenes.SceneBuilder()
+    ids = [b.add_material(scenes.diffuse(tuple(rng.uniform(0.1, 0.9, 3)))) for _ in range(280)]
+    ids += [b.add_material(scenes.conductor(scenes.COPPER["eta"], scenes.COPPER["kappa"], float(rng.uniform(0.05, 0.5)))) for _ in range(40)]
+    ids += [b.add_material(scenes.emitter(tuple(rng.uniform(1.0, 9.0, 3)))) for _ in range(20)]
+    b.add_mesh(pos, nrm, np.asarray(ids)[rng.integers(0, len(ids), 600)])
+    scene = b.build("sah")
+    assert scene["mat"].reshape(-1, 18).shape[0] == 340
+    c2w, s2c = scenes.camera((1.0, 0.8, 3.0), (0, 0, 0), (0, 1, 0), 45.0, 72, 40)
+    params = scenes.make_params(c2w, s2c, 72, 40, 6, 2)
+    ref, ref_rays = pt_oracle.render(scene, params)
+    d = gpu_device
+    try:
+        for variant in (2, 0, 1):
+            d.set_variant(variant)
+            acc, st = gpu_render(d, scene, params)
+            assert st.rays == ref_rays
+            assert_bit_equal(acc, ref, f"340 materials, variant {variant}")
+    finally:
+        d.set_variant(2)
