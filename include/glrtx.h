@@ -16,6 +16,9 @@
  *   glrtx_render                     first half of Window::render(): uniform upload + the single
  *                                    glDrawArrays(GL_TRIANGLES, 0, 6) that runs raytrace.frag on every pixel
  *                                    src/core/window.cpp:213-295; shader src/shaders/raytrace.frag:565-614
+ *   glrtx_render_frames              n consecutive iterations of the accumulation loop in Window::mainloop
+ *                                    (src/core/window.cpp:121-169 calling render(), with the fresh u_seed of
+ *                                    :226-238 per frame and a static camera), issued as one launch
  *   glrtx_params                     the uniforms set per frame, window.cpp:230-243, plus u_maxDepth which
  *                                    the reference leaves at its shader default 16 (raytrace.frag:47)
  *   glrtx_read_accum                 reading fbo[select] colour attachments 0/1 (RGB32F + R32F)
