@@ -40,7 +40,10 @@ def test_fuzz_scene_matches_oracle(gpu_device, case):
         d.set_variant(2)
 
 
-@pytest.mark.parametrize("seed", range(1000, 1024))
+import os
+
+
+@pytest.mark.parametrize("seed", range(1000, 1000 + int(os.environ.get("GLRT_FUZZ_SEEDS", "24"))))
 def test_fuzz_random_parameters(gpu_device, seed):
     """Parameters drawn from the seed: triangle count, tree builder, image size, depth, samples, lens, flags."""
     from oracle import pt_oracle
