@@ -1,0 +1,40 @@
+"""bench.py's output contract: one JSON line with the driver's keys plus `roofline` and `cpu_baseline`."""
+import json
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def test_bench_prints_one_contract_json_line():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--frames-in-flight", "4",
+                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 6 and out["warmup"] == 2
+    assert out["unit"] == "Mrays/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert out["dtype"] == "f32" and out["data"] == "synthetic" and out["scaling"] == "strong"
+    assert "1920x1080" in out["metric"] and "workload" in out["config"] and "model" not in out["config"]
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    # value = rays of the timed frames / elapsed: consistent with ms_per_step and the exact ray count
+    assert abs(out["value"] - out["config"]["rays_per_frame"] / out["ms_per_step"] / 1e3) / out["value"] < 1e-3
+    assert 0 <= out["config"]["rays_untraced_per_frame"] < out["config"]["rays_per_frame"]
+    rf = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms_avg"] * 1e-3) / 1e9) / rf["achieved"] < 1e-3
+    cb = out["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] == "port" and cb["unit"] == "Mrays/s" and cb["cores"] >= 1 and cb["value"] > 0
