@@ -244,3 +244,35 @@ bool loadObj(const std::string &filename, std::vector<Vertex> &out, std::string 
 }
 
 }  // namespace glrt
+
+// ---------------------------------------------------------------------------------------------- test hook
+// Host-only probe for the parser tests (no GPU): parses a JSON scene with the CPU builders and reports what Window
+// would upload.  counts = {width, height, vertices, triangles, materials, lights, nodes, bvh depth};
+// buffers (any may be NULL) receive the flat arrays in the wire format.
+namespace glrt {
+struct SceneProbe {
+    static int run(const char *json, const char *bvh_kind, long long counts[8], float view[16], float proj[16], float lens[2], float *vert,
+                   float *tri, float *mat, float *light, float *nodes) {
+        Scene sc;
+        if (bvh_kind && *bvh_kind) sc.setBvhBuilder(bvh_kind);
+        sc.parse(json);
+        const long long c[8] = {sc.width, sc.height, (long long)sc.vertices.size(), (long long)sc.triangles.size(),
+                                (long long)sc.materials.size(), (long long)sc.lights.size(), (long long)sc.nodes.size(), sc.bvhDepth_};
+        for (int i = 0; i < 8; i++) counts[i] = c[i];
+        if (view) std::memcpy(view, sc.viewM, sizeof sc.viewM);
+        if (proj) std::memcpy(proj, sc.projM, sizeof sc.projM);
+        if (lens) { lens[0] = sc.apertureRadius; lens[1] = sc.focalLength; }
+        if (vert && !sc.vertices.empty()) std::memcpy(vert, sc.vertices.data(), sc.vertices.size() * sizeof(Vertex));
+        if (tri && !sc.triangles.empty()) std::memcpy(tri, sc.triangles.data(), sc.triangles.size() * sizeof(Triangle));
+        if (mat && !sc.materials.empty()) std::memcpy(mat, sc.materials.data(), sc.materials.size() * sizeof(Material));
+        if (light && !sc.lights.empty()) std::memcpy(light, sc.lights.data(), sc.lights.size() * sizeof(Triangle));
+        if (nodes && !sc.nodes.empty()) std::memcpy(nodes, sc.nodes.data(), sc.nodes.size() * sizeof(BVHNode));
+        return 0;
+    }
+};
+}  // namespace glrt
+
+extern "C" GLRT_API int glrt_scene_probe(const char *json, const char *bvh_kind, long long counts[8], float view[16], float proj[16],
+                                         float lens[2], float *vert, float *tri, float *mat, float *light, float *nodes) {
+    return glrt::SceneProbe::run(json, bvh_kind, counts, view, proj, lens, vert, tri, mat, light, nodes);
+}

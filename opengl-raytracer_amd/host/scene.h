@@ -58,6 +58,7 @@ private:
     std::string bvhBuilder_ = "sah";
 
     friend class Window;
+    friend struct SceneProbe;
 };
 
 // OBJ triangles the way the reference's loader yields them (trimesh.cpp:113-191): three fresh
