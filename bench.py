@@ -1,29 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- the headline benchmark: Mrays/s and ms/frame at 1920x1080, 8 bounces (BASELINE.json).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: spawns its own N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one frame: one pass of the path-tracing hot path (raytrace.frag::main on every pixel of
-the 1920x1080 image, u_maxDepth = 8, 1 sample/pixel, fresh u_seed per frame) accumulated into the
-resident float4 framebuffer.  Frames are issued --frames-in-flight B at a time (default 16 per rank) through
-glrtx_render_frames: ONE launch of the render kernel (pt_render_wgwf, the workgroup-local wavefront)
-covers B consecutive frames and adds their samples to the accumulator in frame order, so the result
-is bit-identical to B separate launches (tests/test_gpu_parity.py) while the GPU stays full across
-frame boundaries.  K steps are therefore ceil(K / B) launches; B = 1 gives one launch per frame, and
-the JSON line also carries that figure ("one_launch_per_frame"), measured after the timed region.
-With N > 1 ranks the image rows are sharded in interleaved 16-row stripes (one process per GPU,
-global pixel coordinates, no data-path collective) and every launch ends with the RCCL all_gather of
-the finished rows ("gather the framebuffer"), inside the timed region.
-Scene and accumulators are resident in HBM before timing starts.  Rays are counted exactly (one
-execution of intersect() in the reference's algorithm = one ray; the few the kernel can
-resolve without a traversal are reported separately as rays_untraced_per_frame) by an untimed pass over the same seeds with the
-counting variant of the kernel; the timed launches use the clean kernel.
+The workload is the reference's progressive accumulation loop (Window::mainloop calling render() once per
+frame with a fresh u_seed, window.cpp:121-169, :226-252) on the 1920x1080 image at u_maxDepth = 8, 1 sample
+per pixel and frame, every frame added to the resident float4 accumulator.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- HBM roofline of the render kernel from ALGORITHMIC bytes / measured launch time
-  cpu_baseline -- the CPU restatement (oracle/, "port") timed on this box's host cores (N = 1 only)
+One STEP = one pass of the hot path over one batch: with N ranks a step is N consecutive frames of that loop,
+the image rows sharded over the ranks in interleaved 16-row stripes (one process per GPU, global pixel
+coordinates, no data-path collective).  Every GPU therefore traces one full frame's worth of paths
+(2,073,600) per step whatever N is -- "scaling": "weak"; at N = 1 a step is exactly one frame.  The JSON line
+reports ms_per_step and config.ms_per_frame = ms_per_step / N.
+
+Frames are issued through glrtx_render_frames: ONE launch of the render kernel (pt_render_wgwf, the
+workgroup-local wavefront) covers a batch of consecutive frames and adds their samples to the accumulator in
+frame order, bit-identical to separate launches (tests/test_gpu_parity.py).  The K steps are cut into
+ceil(K / --steps-per-launch) launches of (nearly) equal size, so a K that is not a multiple of the batch does
+not leave an under-filled remainder launch.  With N > 1 the finished rows are gathered to rank 0 over RCCL
+ONCE, at the end of the timed region (the accumulators stay resident on their GPUs in between, SURVEY.md
+8(e)); --gather-every L gathers after every L-th launch instead.
+
+Scene and accumulators are resident in HBM before timing starts.  Rays are counted exactly by an untimed pass
+over the same seeds with the counting variant of the kernel; the timed launches use the clean kernel.  `value`
+counts the rays that were actually TRAVERSED; the reference's algorithm additionally executes intersect() for
+shadow rays whose light test cannot change the radiance (config.rays_reference_equivalent_per_frame).
+
+`python bench.py --gpus N` without WORLD_SIZE in the environment re-launches itself as N ranks under
+torch.distributed.run (child process; the parent never touches the GPU) and exits with the child's status.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with three extra objects:
+  roofline      -- HBM roofline of the render kernel from ALGORITHMIC bytes / measured launch time
+  roofline_valu -- vector-ALU issue roofline of the same kernel (the bound that actually applies)
+  cpu_baseline  -- the CPU restatement (oracle/, "port") timed on this box's host cores (N = 1 only)
 """
 from __future__ import annotations
 
@@ -31,6 +42,8 @@ import argparse
 import json
 import os
 import pathlib
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,7 +54,13 @@ sys.path.insert(0, str(ROOT / "opengl-raytracer_amd" / "python"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINST = 1024 * 2.4 / 2  # wave64 VALU instructions/ns the chip can issue: 1024 SIMDs x 2.4 GHz / 2 cycles each
 STRIPE = 16
+STEPS_PER_LAUNCH = 16  # frames' worth of paths in flight on every GPU (frames in flight)
+
+# Test hook: tests/ replace this with a factory of CPU renderers (same interface as GpuRenderer) to rehearse the
+# N > 1 control flow under gloo.  The product path never sets it.
+RENDERER_FACTORY = None
 
 
 def effective_cpus(omp_max: int) -> int:
@@ -60,7 +79,95 @@ def effective_cpus(omp_max: int) -> int:
     return max(1, n)
 
 
-def main():
+def launch_plan(steps: int, per_launch: int):
+    """Cut `steps` into ceil(steps / per_launch) launches of nearly equal size: [(first_step, n_steps), ...]."""
+    if steps <= 0:
+        return []
+    n = -(-steps // max(per_launch, 1))
+    base, extra = divmod(steps, n)
+    plan, s = [], 0
+    for i in range(n):
+        k = base + (1 if i < extra else 0)
+        plan.append((s, k))
+        s += k
+    return plan
+
+
+def spawn_ranks(n: int) -> int:
+    """Parent of a self-launched N-rank run: start torch.distributed.run as a CHILD and return its exit status.
+    Nothing in this process has touched HIP (no torch.cuda call, no libglrtx call)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+class GpuRenderer:
+    """One rank's share of the image on one MI355X through the C ABI (libglrtx.so); there is no CPU fallback."""
+
+    def __init__(self, rank, world, local_rank, scene, params, bvh):
+        import torch
+        from glrt_amd import device, dist
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        self.torch = torch
+        self.dev = device.Device(local_rank)
+        self.scene = scene
+        if bvh == "lbvh":  # BASELINE config 5: "linear-BVH traversal"
+            nodes, depth, build_ms = self.dev.build_lbvh(scene["vert"], scene["tri"])
+            self.scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"lbvh, built on the GPU in {build_ms:.2f} ms")
+        W, H = params["width"], params["height"]
+        self.params = params
+        self.dev.upload_scene(self.scene)
+        self.dev.set_partition(rank, world, STRIPE)
+        self.dev.resize(W, H)
+        pad_rows = dist.max_owned_rows(world, STRIPE, H)
+        # the accumulator lives in a torch tensor so that RCCL can gather it; the kernel writes it in place
+        self.accum = torch.zeros((pad_rows, W, 4), dtype=torch.float32, device="cuda")
+        self.dev.bind_accum(self.accum.data_ptr(), W * 16, pad_rows)
+        self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.device = torch.device("cuda", local_rank)
+
+    def render_frames(self, f0, n, seed_of):
+        if n == 1:
+            self.dev.render(dict(self.params, seed=seed_of(f0)))
+        else:
+            self.dev.render_frames(self.params, [seed_of(f0 + i) for i in range(n)])
+
+    def device_sync(self):
+        self.torch.cuda.synchronize()
+
+    def count_rays(self, on):
+        self.dev.count_rays(on)
+
+    def sync(self):
+        self.dev.sync()
+
+    def stats(self):
+        return self.dev.stats()
+
+    def reset_stats(self):
+        self.dev.reset_stats()
+
+    def timer_begin(self):
+        self.dev.timer_begin()
+
+    def timer_end(self):
+        return self.dev.timer_end()
+
+    def close(self):
+        self.dev.set_stream(0)
+        self.dev.bind_accum(0, 0, 0)
+        self.dev.close()
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
@@ -70,145 +177,154 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-gather", action="store_true", help="skip the framebuffer gather (N > 1)")
+    ap.add_argument("--gather-every", type=int, default=0, help="gather the framebuffer to rank 0 after every L-th launch (0: once, at the end of the timed region)")
     ap.add_argument("--no-single", action="store_true", help="skip the extra one-launch-per-frame measurement (profiling runs)")
-    ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames per launch of the render kernel (1 = one launch per frame; default 16 x N ranks: "
-                         "16 full frames' worth of paths in flight on every GPU, whatever share of the rows it owns)")
-    args = ap.parse_args()
+    ap.add_argument("--steps-per-launch", "--frames-in-flight", dest="steps_per_launch", type=int, default=STEPS_PER_LAUNCH,
+                    help="steps per launch of the render kernel (at N ranks a step is N frames, so a launch covers N x this many frames: "
+                         "this many full frames' worth of paths in flight on every GPU; 1 = one step per launch)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the CPU rehearsal in tests/)")
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: before torch.cuda / libglrtx are touched in this process
+        raise SystemExit(spawn_ranks(args.gpus))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as td
 
-    from glrt_amd import device, dist, host, scenes
+    from glrt_amd import dist, host, scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or without WORLD_SIZE set (bench.py then spawns its ranks itself)")
 
     scene, params = scenes.CONFIGS[args.config]()
     W, H = params["width"], params["height"]
     n_tri = int(scene["tri"].shape[0])
 
-    dev = device.Device(local_rank)
-    if args.bvh == "lbvh":  # BASELINE config 5: "linear-BVH traversal"
-        nodes, depth, build_ms = dev.build_lbvh(scene["vert"], scene["tri"])
-        scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"lbvh, built on the GPU in {build_ms:.2f} ms")
-    dev.upload_scene(scene)
-    dev.set_partition(rank, world, STRIPE)
-    dev.resize(W, H)
+    factory = RENDERER_FACTORY or GpuRenderer
+    R = factory(rank, world, local_rank, scene, params, args.bvh)
+    scene = R.scene
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": R.device} if args.backend == "nccl" else {}
+        td.init_process_group(args.backend, rank=rank, world_size=world, **kw)
     ys = dist.owned_rows(rank, world, STRIPE, H)
-    pad_rows = dist.max_owned_rows(world, STRIPE, H)
-    # the accumulator lives in a torch tensor so that RCCL can gather it; the kernel writes it in place
-    accum = torch.zeros((pad_rows, W, 4), dtype=torch.float32, device="cuda")
-    dev.bind_accum(accum.data_ptr(), W * 16)
-    stream = torch.cuda.current_stream()
-    dev.set_stream(stream.cuda_stream)
+    gatherer = dist.RowGather(world, STRIPE, H, R.accum) if world > 1 else None  # index tensors built once, here
 
     def seed(f):
         return host.frame_seed(f)
 
-    B = args.frames_in_flight if args.frames_in_flight > 0 else min(16 * world, 256)
+    S = max(1, args.steps_per_launch)
 
-    def run(f0, f1, gather=True, per_launch=None):
-        """Frames [f0, f1): per_launch frames per launch of the render kernel, the framebuffer gathered after every launch."""
-        per_launch = per_launch or B
-        img = accum
-        for g in range(f0, f1, per_launch):
-            n = min(per_launch, f1 - g)
-            if n == 1:
-                dev.render(dict(params, seed=seed(g)))
-            else:
-                dev.render_frames(params, [seed(g + i) for i in range(n)])
-            if world > 1 and gather and not args.no_gather:
-                img = dist.gather_rows(accum, H, STRIPE)
+    def run(s0, n_steps, per_launch=None, gather=True):
+        """Steps [s0, s0 + n_steps) = frames [s0*N, (s0+n_steps)*N), in balanced launches; returns the gathered image (rank 0) or None."""
+        img = None
+        plan = launch_plan(n_steps, per_launch or S)
+        for i, (a, k) in enumerate(plan):
+            R.render_frames((s0 + a) * world, k * world, seed)
+            last = i + 1 == len(plan)
+            if gatherer is not None and gather and not args.no_gather and (last or (args.gather_every > 0 and (i + 1) % args.gather_every == 0)):
+                img = gatherer.gather_to_root(R.accum)
         return img
 
     def barrier():
-        torch.cuda.synchronize()
+        R.device_sync()
         if world > 1:
             td.barrier()
-        torch.cuda.synchronize()
+        R.device_sync()
 
-    # ---- exact ray count for the timed frames (untimed, counting kernel variant)
-    dev.count_rays(True)
-    dev.reset_stats()
-    run(args.warmup, args.warmup + args.steps, gather=False)
-    dev.sync()
-    rays_local = int(dev.stats().rays)
-    untraced_local = int(dev.stats().rays_untraced)
-    dev.count_rays(False)
-    accum.zero_()
-    dev.reset_stats()
+    # ---- exact ray count for the timed steps (untimed, counting kernel variant)
+    R.count_rays(True)
+    R.reset_stats()
+    run(args.warmup, args.steps, gather=False)
+    R.sync()
+    rays_local = int(R.stats().rays)
+    untraced_local = int(R.stats().rays_untraced)
+    R.count_rays(False)
+    R.accum.zero_()
+    R.reset_stats()
 
-    # ---- warm-up, then K timed frames
+    # ---- warm-up, then K timed steps
     run(0, args.warmup)
-    dev.sync()
-    dev.reset_stats()
+    R.sync()
+    R.reset_stats()
     barrier()
     t0 = time.perf_counter()
-    dev.timer_begin()
-    img = run(args.warmup, args.warmup + args.steps)
-    ev_ms = dev.timer_end()
+    R.timer_begin()
+    img = run(args.warmup, args.steps)
+    ev_ms = R.timer_end()
     barrier()
     t1 = time.perf_counter()
-    dev.sync()
-    st = dev.stats()
+    R.sync()
+    st = R.stats()
     del img
 
-    # ---- the same frames once more, one launch per frame (reported next to the headline figure)
+    # ---- the same steps once more, one frame per launch (reported next to the headline figure; N = 1 only)
     single = None
-    if B > 1 and not args.no_single:
+    if world == 1 and S > 1 and not args.no_single:
         n1 = min(args.steps, 20)
         run(0, 2, per_launch=1)
         barrier()
         t2 = time.perf_counter()
-        run(args.warmup, args.warmup + n1, per_launch=1)
+        run(args.warmup, n1, per_launch=1)
         barrier()
-        single = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device="cuda")
-        if world > 1:
-            td.all_reduce(single, op=td.ReduceOp.MAX)
-        single = float(single.item()) / n1
+        single = (time.perf_counter() - t2) / n1
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([rays_local, untraced_local], dtype=torch.int64, device="cuda")
-    kern_ms = torch.tensor([st.kernel_ms_total / max(st.kernel_launches, 1)], dtype=torch.float64, device="cuda")
+    dev0 = R.accum.device
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev0)
+    rays = torch.tensor([rays_local, untraced_local], dtype=torch.int64, device=dev0)
+    kern_ms = torch.tensor([st.kernel_ms_total / max(st.kernel_launches, 1)], dtype=torch.float64, device=dev0)
     if world > 1:
         td.all_reduce(elapsed, op=td.ReduceOp.MAX)
         td.all_reduce(rays, op=td.ReduceOp.SUM)
         td.all_reduce(kern_ms, op=td.ReduceOp.MAX)
-    elapsed_s, total_rays, total_untraced, kernel_ms = float(elapsed.item()), int(rays[0].item()), int(rays[1].item()), float(kern_ms.item())
+    elapsed_s, ref_rays, total_untraced, kernel_ms = float(elapsed.item()), int(rays[0].item()), int(rays[1].item()), float(kern_ms.item())
+    traced_rays = ref_rays - total_untraced
+    n_frames = args.steps * world
 
-    # ---- roofline of the render kernel (per launch, per GPU): algorithmic bytes / measured launch duration
+    # ---- rooflines of the render kernel (per launch, per GPU)
     scene_b = scenes.scene_bytes(scene)
     frames_per_launch = st.launches / max(st.kernel_launches, 1)
-    # per frame 16 B read + 16 B write per owned pixel (SURVEY.md 8(d)), times the frames one launch covers, + one read of the compact scene
+    # HBM: per frame 16 B read + 16 B write per owned pixel (SURVEY.md 8(d)), times the frames one launch covers, + one read of the compact scene
     algo_bytes = int(len(ys) * W * 32 * frames_per_launch) + scene_b
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None
-    pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
-    if pmc.exists() and args.config == "headline" and world == 1:
-        try:
-            prof = json.loads(pmc.read_text())  # measured per launch of prof["frames_per_launch"] frames; scaled to this run's launches
-            traffic = prof["hbm_bytes_per_launch"] / prof.get("frames_per_launch", 1) * frames_per_launch
-        except Exception:
-            traffic = None
+    traffic, valu = None, None
+    prof = None
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        if (ROOT / "profiles" / name).exists():
+            try:
+                prof = json.loads((ROOT / "profiles" / name).read_text())
+                prof["file"] = f"profiles/{name}"
+                break
+            except Exception:
+                prof = None
+    if prof is not None and args.config == "headline":
+        # PMC counters cannot be collected inside this run (rocprofv3 wraps the process): the per-frame figures come from the
+        # committed profile of this same command and are scaled to the full frames' worth of pixels a launch covers on this GPU
+        frames_equiv = frames_per_launch * len(ys) / H
+        traffic = prof["hbm_bytes_per_frame"] * frames_equiv
+        vi = prof["valu_insts_per_frame"] * frames_equiv
+        rate = vi / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        valu = {"bound": "valu-issue", "achieved": round(rate, 2), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                "frac": round(rate / VALU_PEAK_GINST, 4), "lane_util": prof.get("lane_util"),
+                "effective_fp32_lane_frac": None if prof.get("lane_util") is None else round(rate / VALU_PEAK_GINST * prof["lane_util"], 4),
+                "valu_insts_per_launch": int(vi), "source": prof["file"],
+                "note": "SQ_INSTS_VALU per frame from the committed rocprofv3 --pmc pass of this command / kernel time measured in this run; "
+                        "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; lane_util = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64"}
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "traffic_source": None if traffic is None else f"{prof['file']} (separate --pmc FETCH_SIZE / WRITE_SIZE passes, {prof.get('traffic_note', '')})",
                 "kernel": "pt_render_wgwf<false, false>", "kernel_ms_avg": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes, "frames_per_launch": round(frames_per_launch, 3),
-                "note": "branchy scalar-FP32 traversal: VALU/latency-bound, not HBM-bound (DESIGN.md section 6)"}
+                "note": "branchy scalar-FP32 traversal: VALU/latency-bound, not HBM-bound (DESIGN.md section 6); see roofline_valu"}
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and RENDERER_FACTORY is None:
         from oracle import pt_oracle
         cores = effective_cpus(pt_oracle.max_threads())
         acc = np.zeros((H, W, 4), np.float32)
@@ -223,41 +339,49 @@ def main():
         dt = time.perf_counter() - t
         cpu_baseline = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                         "sample": f"{n} full frames of the same workload (same seeds as the first timed frames), "
-                                  f"{dt:.1f} s, OpenMP over rows", "ms_per_frame": round(dt / n * 1e3, 2)}
+                                  f"{dt:.1f} s, OpenMP over rows; counts every intersect() execution of the reference's algorithm",
+                        "ms_per_frame": round(dt / n * 1e3, 2)}
 
     if rank == 0:
+        gather_note = "" if world == 1 else (", no gather" if args.no_gather else
+                                             (f", RCCL gather of the framebuffer to rank 0 every {args.gather_every} launches and at the end of the timed region"
+                                              if args.gather_every > 0 else ", RCCL gather of the framebuffer to rank 0 once, at the end of the timed region"))
         out = {
             "metric": "Mrays/s at 1920x1080, 8 bounces" if args.config == "headline" else f"Mrays/s ({args.config})",
-            "value": round(total_rays / elapsed_s / 1e6, 3),
+            "value": round(traced_rays / elapsed_s / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_s / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {n_tri} triangles (BVH {scene['bvh_kind']}), {W}x{H}, "
                                    f"u_maxDepth={params['max_depth']}, {params['n_samples']} spp/frame",
-                       "partition": f"{world} x interleaved {STRIPE}-row stripes" + ("" if world == 1 else
-                                    (", no gather" if args.no_gather else ", RCCL all_gather of the framebuffer after every launch")),
-                       "frames_in_flight": B,
+                       "step": f"{world} consecutive frame(s) of the accumulation loop = one full frame's worth of pixels per GPU",
+                       "frames_per_step": world,
+                       "ms_per_frame": round(elapsed_s / n_frames * 1e3, 4),
+                       "partition": f"{world} x interleaved {STRIPE}-row stripes" + gather_note,
+                       "steps_per_launch": S,
+                       "launches": [k for _, k in launch_plan(args.steps, S)],
                        "one_launch_per_frame": None if single is None else
-                           {"ms_per_step": round(single * 1e3, 4), "value": round(total_rays / args.steps / single / 1e6, 3)},
-                       "rays_per_frame": round(total_rays / args.steps, 1),
-                       # of those, shadow rays whose light test cannot change the radiance (both outcomes bit-identical):
-                       # counted like the reference counts them, resolved without a traversal
-                       "rays_untraced_per_frame": round(total_untraced / args.steps, 1),
-                       "mpaths_per_s": round(W * H * params["n_samples"] * args.steps / elapsed_s / 1e6, 3),
+                           {"ms_per_step": round(single * 1e3, 4), "value": round(traced_rays / args.steps / single / 1e6, 3)},
+                       "rays_per_frame": round(traced_rays / n_frames, 1),
+                       # the reference's algorithm also executes intersect() for shadow rays whose light test cannot change the
+                       # radiance (both outcomes bit-identical); those are resolved without a traversal and NOT part of `value`
+                       "rays_reference_equivalent_per_frame": round(ref_rays / n_frames, 1),
+                       "rays_untraced_per_frame": round(total_untraced / n_frames, 1),
+                       "mrays_per_s_reference_equivalent": round(ref_rays / elapsed_s / 1e6, 3),
+                       "mpaths_per_s": round(W * H * params["n_samples"] * n_frames / elapsed_s / 1e6, 3),
                        "event_ms_per_step": round(ev_ms / args.steps, 4)},
             "roofline": roofline,
+            "roofline_valu": valu,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)
 
-    dev.set_stream(0)
-    dev.bind_accum(0, 0)
-    dev.close()
+    R.close()
     if world > 1:
         td.destroy_process_group()
 

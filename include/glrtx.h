@@ -55,7 +55,7 @@ extern "C" {
 #define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
 #define GLRTX_ENOMEM (-5)
 
-#define GLRTX_ABI_VERSION 3
+#define GLRTX_ABI_VERSION 4
 
 typedef struct glrtx_ctx glrtx_ctx;
 
@@ -131,8 +131,10 @@ int glrtx_set_partition(glrtx_ctx *ctx, int rank, int world, int stripe_rows);
 int glrtx_local_row_to_y(const glrtx_ctx *ctx, int local_row);
 
 /* Optional: render into caller-owned device memory (e.g. a torch tensor that RCCL gathers)
- * instead of the ctx's own buffer: owned_rows rows of pitch_bytes, width float4 each.  NULL unbinds. */
-int glrtx_bind_accum(glrtx_ctx *ctx, void *device_ptr, size_t pitch_bytes);
+ * instead of the ctx's own buffer: capacity_rows (>= owned_rows) rows of pitch_bytes, width float4 each.
+ * While bound, glrtx_resize / glrtx_set_partition fail with GLRTX_EINVAL for a shape that does not fit
+ * the buffer (the ctx cannot grow memory it does not own).  NULL unbinds. */
+int glrtx_bind_accum(glrtx_ctx *ctx, void *device_ptr, size_t pitch_bytes, int capacity_rows);
 /* Optional: launch on a caller-owned hipStream_t (passed as void*); NULL restores the ctx stream. */
 int glrtx_set_stream(glrtx_ctx *ctx, void *hip_stream);
 

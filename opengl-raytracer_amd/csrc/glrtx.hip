@@ -61,6 +61,7 @@ struct glrtx_ctx {
     float4 *accum = nullptr;  // own or bound
     size_t pitch_bytes = 0;
     bool bound = false;
+    int bound_rows = 0;       // rows the caller's buffer holds (glrtx_bind_accum)
 
     bool count_rays = false;
     bool launch_pending = false;  // ev1 recorded, kernel time not yet folded into stats
@@ -422,6 +423,9 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     return GLRTX_OK;
 }
 
+// Whether the wavefront variant's packed path state can represent this launch (meta = depth | sample << 8 | flags << 28).
+bool wgwf_can_hold(const glrtx_params *p) { return p->max_depth <= kWfDepthMax && p->n_samples <= kWfSampleMax; }
+
 }  // namespace
 
 extern "C" {
@@ -572,6 +576,8 @@ int glrtx_set_partition(glrtx_ctx *c, int rank, int world, int stripe_rows) {
         return fail(c, GLRTX_EINVAL, "glrtx_set_partition: bad rank/world/stripe %d/%d/%d", rank, world, stripe_rows);
     if (stripe_rows % kTile != 0)
         return fail(c, GLRTX_EINVAL, "glrtx_set_partition: stripe_rows must be a multiple of %d", kTile);
+    if (c->bound && c->width > 0 && owned_rows_of(c->height, rank, world, stripe_rows) > c->bound_rows)
+        return fail(c, GLRTX_EINVAL, "glrtx_set_partition: the new partition does not fit the bound accumulator (%d rows); unbind it first", c->bound_rows);
     c->rank = rank; c->world = world; c->stripe = stripe_rows;
     if (c->width > 0) return glrtx_resize(c, c->width, c->height);
     return GLRTX_OK;
@@ -587,6 +593,12 @@ int glrtx_resize(glrtx_ctx *c, int width, int height) {
     if (width < 1 || height < 1 || width > 65536 || height > 65536) return fail(c, GLRTX_EINVAL, "glrtx_resize: bad size %dx%d", width, height);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->bound) {  // a caller-owned accumulator is bound: the new shape must fit it (nothing here can grow it)
+        const int rows = owned_rows_of(height, c->rank, c->world, c->stripe);
+        if ((size_t)width * sizeof(float4) > c->pitch_bytes || rows > c->bound_rows)
+            return fail(c, GLRTX_EINVAL, "glrtx_resize: %dx%d (%d owned rows) does not fit the bound accumulator (%zu-byte rows, %d rows); unbind it first",
+                        width, height, rows, c->pitch_bytes, c->bound_rows);
+    }
     c->width = width; c->height = height;
     c->owned_rows = owned_rows_of(height, c->rank, c->world, c->stripe);
     c->st.width = width; c->st.height = height; c->st.owned_rows = c->owned_rows;
@@ -613,17 +625,22 @@ int glrtx_clear(glrtx_ctx *c) {
     return GLRTX_OK;
 }
 
-int glrtx_bind_accum(glrtx_ctx *c, void *device_ptr, size_t pitch_bytes) {
+int glrtx_bind_accum(glrtx_ctx *c, void *device_ptr, size_t pitch_bytes, int capacity_rows) {
     if (!c) return GLRTX_EINVAL;
     if (c->width < 1) return fail(c, GLRTX_EINVAL, "glrtx_bind_accum: call glrtx_resize first");
+    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (!device_ptr) {
         c->bound = false;
+        c->bound_rows = 0;
         return glrtx_resize(c, c->width, c->height);
     }
     if (pitch_bytes < (size_t)c->width * sizeof(float4) || pitch_bytes % sizeof(float4) != 0 || ((uintptr_t)device_ptr & 15) != 0)
         return fail(c, GLRTX_EINVAL, "glrtx_bind_accum: pitch/alignment invalid");
+    if (capacity_rows < c->owned_rows)
+        return fail(c, GLRTX_EINVAL, "glrtx_bind_accum: the buffer holds %d rows, this partition owns %d", capacity_rows, c->owned_rows);
     c->bound = true;
+    c->bound_rows = capacity_rows;
     c->accum = (float4 *)device_ptr;
     c->pitch_bytes = pitch_bytes;
     return GLRTX_OK;
@@ -654,7 +671,7 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
     if (!c || !p) return GLRTX_EINVAL;
     if (n_frames < 0 || (n_frames > 0 && !seeds_xy)) return fail(c, GLRTX_EINVAL, "glrtx_render_frames: bad seeds/n_frames");
     if (n_frames == 0) return GLRTX_OK;
-    if (n_frames == 1 || c->variant != 2) {  // the megakernel variants have no frames-in-flight form: one launch per frame
+    if (n_frames == 1 || c->variant != 2 || !wgwf_can_hold(p)) {  // the megakernel variants have no frames-in-flight form: one launch per frame
         for (int f = 0; f < n_frames; f++) {
             glrtx_params q = *p;
             q.seed[0] = seeds_xy[2 * f]; q.seed[1] = seeds_xy[2 * f + 1];
@@ -731,8 +748,11 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     if ((size_t)a.pitch_f4 * (size_t)c->owned_rows >= (size_t)INT32_MAX)
         return fail(c, GLRTX_EINVAL, "accumulator too large for 32-bit pixel offsets");
 
-    if (c->variant == 2) return launch_wgwf(c, a, p, c->frames_seeds, c->frames_n);
-    if (c->variant == 1) {
+    // The wavefront variant packs depth and sample index into one word of the path state (kWfDepthMax, kWfSampleMax);
+    // a launch beyond those ranges runs on the persistent megakernel instead (bit-identical, no packed state).
+    const int variant = (c->variant == 2 && !wgwf_can_hold(p)) ? 1 : c->variant;
+    if (variant == 2) return launch_wgwf(c, a, p, c->frames_seeds, c->frames_n);
+    if (variant == 1) {
         // persistent kernel: grid = what is resident at once (occupancy x CUs), capped by the work available
         const int ci = c->count_rays ? 1 : 0;
         if (lds > 64 * 1024) {

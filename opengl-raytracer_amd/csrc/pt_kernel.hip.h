@@ -1016,6 +1016,10 @@ struct WfArgs {
     int pid_mask;         // (1 << frame_shift) - 1
     int tiles_per_frame;  // total >> 6
 };
+// meta word of the path state: depth in bits 0-7 (it reaches max_depth before the path ends), sample index in bits 8-27.
+// The host sends launches beyond these ranges to the persistent megakernel (glrtx_render).
+constexpr int kWfDepthMax = 255;
+constexpr int kWfSampleMax = (1 << 20) - 1;
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
 constexpr unsigned WF_FINISHING = 1u << 29;  // the path has ended; only that shadow ray is awaited
 constexpr unsigned WF_INVALID = 0xFFFFFFFFu; // queue entry to skip

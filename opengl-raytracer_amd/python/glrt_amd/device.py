@@ -64,7 +64,7 @@ def lib():
         L.glrtx_clear.argtypes = [vp]
         L.glrtx_set_partition.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.glrtx_local_row_to_y.argtypes = [vp, C.c_int]
-        L.glrtx_bind_accum.argtypes = [vp, vp, C.c_size_t]
+        L.glrtx_bind_accum.argtypes = [vp, vp, C.c_size_t, C.c_int]
         L.glrtx_set_stream.argtypes = [vp, vp]
         L.glrtx_set_variant.argtypes = [vp, C.c_int]
         L.glrtx_count_rays.argtypes = [vp, C.c_int]
@@ -155,8 +155,8 @@ class Device:
     def clear(self):
         self._ck(self.L.glrtx_clear(self.h))
 
-    def bind_accum(self, device_ptr, pitch_bytes):
-        self._ck(self.L.glrtx_bind_accum(self.h, C.c_void_p(device_ptr), pitch_bytes))
+    def bind_accum(self, device_ptr, pitch_bytes, capacity_rows):
+        self._ck(self.L.glrtx_bind_accum(self.h, C.c_void_p(device_ptr), pitch_bytes, int(capacity_rows)))
 
     def set_stream(self, hip_stream):
         self._ck(self.L.glrtx_set_stream(self.h, C.c_void_p(hip_stream)))

@@ -2,8 +2,12 @@
 framebuffer gather (glrt_amd.dist).  The per-rank renderer here is the oracle standing in for the
 device kernel -- test infrastructure only; what is under test is the partition arithmetic (global
 coordinates, full windowSize) and the gather/de-interleave, which bench.py runs over RCCL."""
+import json
 import os
+import pathlib
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -50,3 +54,57 @@ def test_partitioned_render_plus_gather_equals_single_process(tmp_path, world, s
         got = np.load(tmp_path / f"rank{r}.npy")
         assert got.shape == ref.shape
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"rank {r} image differs"
+
+
+def test_bench_self_spawns_its_ranks_and_gathers_to_root(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.main re-launches itself as 2 ranks under
+    torch.distributed.run (tests/bench_rehearsal.py swaps the device renderer for the oracle on CPU tensors and the
+    backend for gloo).  Checks the JSON line, that the ranks rendered the frames the step plan assigns, and that the
+    image gathered to rank 0 at the end of the timed region equals a single-process render of the same frames."""
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GLRT_REHEARSAL_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+    steps, warm, spl = 5, 2, 2
+    r = subprocess.run([sys.executable, str(root / "tests" / "bench_rehearsal.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
+                        "--steps-per-launch", str(spl), "--config", "rehearsal", "--backend", "gloo", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak"
+    assert out["config"]["frames_per_step"] == 2 and out["config"]["launches"] == [2, 2, 1]
+    assert abs(out["config"]["ms_per_frame"] * 2 - out["ms_per_step"]) < 1e-3 * out["ms_per_step"] + 1e-4
+    assert out["value"] > 0 and out["cpu_baseline"] is None
+    # the counting pass, the warm-up and the timed region cover these frames, in this order, on every rank
+    timed = list(range(warm * 2, (warm + steps) * 2))
+    want = timed + list(range(0, warm * 2)) + timed
+    for k in range(2):
+        assert np.load(tmp_path / f"frames_rank{k}.npy").tolist() == want
+    # image: warm-up frames + timed frames accumulated from zero (the counting pass is cleared), gathered to rank 0
+    from glrt_amd import host
+    from tests.bench_rehearsal import small_config
+    sc, pr = small_config()
+    ref = np.zeros((pr["height"], pr["width"], 4), np.float32)
+    for f in list(range(0, warm * 2)) + timed:
+        pt_oracle.render(sc, dict(pr, seed=host.frame_seed(f)), accum=ref, threads=2)
+    got = np.load(tmp_path / "gathered.npy")
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_launch_plan_is_balanced():
+    import bench
+    assert bench.launch_plan(20, 16) == [(0, 10), (10, 10)]
+    assert bench.launch_plan(48, 16) == [(0, 16), (16, 16), (32, 16)]
+    assert bench.launch_plan(5, 2) == [(0, 2), (2, 2), (4, 1)]
+    assert bench.launch_plan(3, 16) == [(0, 3)] and bench.launch_plan(0, 16) == []
+
+
+def test_row_gather_index_matches_owned_rows():
+    for world, stripe, h in ((1, 16, 40), (2, 16, 64), (3, 16, 56), (8, 16, 1080)):
+        src = dist.source_rows(world, stripe, h)
+        pad = dist.max_owned_rows(world, stripe, h)
+        assert sorted(src.tolist()) == sorted(r * pad + i for r in range(world) for i in range(len(dist.owned_rows(r, world, stripe, h))))
+        for r in range(world):
+            ys = dist.owned_rows(r, world, stripe, h)
+            assert np.array_equal(src[ys], r * pad + np.arange(len(ys)))

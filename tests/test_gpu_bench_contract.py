@@ -11,29 +11,37 @@ ROOT = pathlib.Path(__file__).resolve().parents[1]
 
 
 def test_bench_prints_one_contract_json_line():
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--frames-in-flight", "4",
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--steps-per-launch", "4",
                         "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "dtype", "data", "config", "roofline", "roofline_valu", "cpu_baseline"):
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 6 and out["warmup"] == 2
     assert out["unit"] == "Mrays/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
-    assert out["dtype"] == "f32" and out["data"] == "synthetic" and out["scaling"] == "strong"
+    assert out["dtype"] == "f32" and out["data"] == "synthetic" and out["scaling"] == "weak"
     assert "1920x1080" in out["metric"] and "workload" in out["config"] and "model" not in out["config"]
     assert out["value"] > 0 and out["ms_per_step"] > 0
     # value = rays of the timed frames / elapsed: consistent with ms_per_step and the exact ray count
     assert abs(out["value"] - out["config"]["rays_per_frame"] / out["ms_per_step"] / 1e3) / out["value"] < 1e-3
-    assert 0 <= out["config"]["rays_untraced_per_frame"] < out["config"]["rays_per_frame"]
+    cfg = out["config"]
+    assert cfg["frames_per_step"] == 1 and cfg["launches"] == [3, 3] and abs(cfg["ms_per_frame"] - out["ms_per_step"]) < 1e-6
+    # `value` counts traversed rays only; the reference's algorithm executes intersect() for the untraced ones too
+    assert 0 <= cfg["rays_untraced_per_frame"] < cfg["rays_per_frame"]
+    assert abs(cfg["rays_reference_equivalent_per_frame"] - cfg["rays_per_frame"] - cfg["rays_untraced_per_frame"]) < 1.0
     rf = out["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms_avg"] * 1e-3) / 1e9) / rf["achieved"] < 1e-3
+    rv = out["roofline_valu"]
+    if rv is not None:  # needs the committed PMC summary under profiles/
+        assert rv["unit"] == "G wave-instructions/s" and abs(rv["frac"] - rv["achieved"] / rv["peak"]) < 1e-3 and 0 < rv["lane_util"] <= 1
+        assert rf["traffic"] is not None and rf["traffic"] > rf["algorithmic_bytes_per_launch"]
     cb = out["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key

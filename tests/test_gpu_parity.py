@@ -145,16 +145,26 @@ def test_bound_torch_accumulator_and_stream(gpu_device):
     scene, params = scenes.config_c1(160, 96, max_depth=3, n_samples=1)
     ref, _ = gpu_render(d, scene, params)
     t = torch.zeros((96, 160, 4), dtype=torch.float32, device="cuda")
-    d.bind_accum(t.data_ptr(), 160 * 16)
+    d.bind_accum(t.data_ptr(), 160 * 16, 96)
     d.set_stream(torch.cuda.current_stream().cuda_stream)
     try:
         d.render(params)
         d.sync()
         torch.cuda.synchronize()
         assert_bit_equal(t.cpu().numpy(), ref, "bound accumulator")
+        # a shape that does not fit the caller's buffer is refused while it is bound (the ctx cannot grow it)
+        for call in (lambda: d.resize(160, 97), lambda: d.resize(161, 96)):
+            with pytest.raises(device.GlrtxError) as e:
+                call()
+            assert e.value.code == device.GLRTX_EINVAL and "bound accumulator" in str(e.value)
+        with pytest.raises(device.GlrtxError):
+            d.bind_accum(t.data_ptr(), 160 * 16, 95)  # fewer rows than the partition owns
+        d.bind_accum(t.data_ptr(), 160 * 16, 96)
+        d.set_partition(0, 2, 16)  # half the rows: fits
+        d.set_partition(0, 1, 16)
     finally:
         d.set_stream(0)
-        d.bind_accum(0, 0)
+        d.bind_accum(0, 0, 0)
 
 
 def test_error_behaviour(gpu_device):

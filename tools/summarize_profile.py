@@ -2,11 +2,12 @@
 """Turn gpurun_out/prof_<tag>/ (written by tools/profile.sh on the GPU box) into committed summaries:
    profiles/<tag>_kernel_stats.csv   -- rocprofv3 --kernel-trace --stats table (verbatim)
    profiles/<tag>_pmc.json           -- per-launch averages of the PMC counters for the render kernel(s)
-   profiles/r01_pmc_traffic.json     -- HBM bytes per launch (what bench.py reports as roofline.traffic)
+   profiles/<tag>_pmc_summary.json   -- per-FRAME figures bench.py reports: HBM bytes (roofline.traffic), VALU instructions, lane utilisation
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are in KiB
-units, collected in separate passes; on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x,
-but this kernel's reads are scattered 16-byte gathers (uncalibrated width), so no correction factor is applied
-and both the raw and the x2 upper bound are recorded."""
+units, collected in separate passes; on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x.
+The kernel's HBM-side reads are dominated by unit-stride float4 streams (path state, ray records), so the x2
+correction is applied; the uncorrected sum is recorded next to it.
+Usage: summarize_profile.py <tag> [kernel substring] [frames per launch of the profiled command]"""
 import collections
 import csv
 import glob
@@ -35,21 +36,37 @@ for f in glob.glob(str(src / "pmc_*" / "*" / "*_counter_collection.csv")):
             meta[k] = dict(vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]), lds=int(r["LDS_Block_Size"]),
                            scratch=int(r["Scratch_Size"]), grid=int(r["Grid_Size"]), wg=int(r["Workgroup_Size"]))
 out = {}
+if not agg and (dst / f"{tag}_pmc.json").exists():  # re-summarise a committed table
+    out = json.loads((dst / f"{tag}_pmc.json").read_text())
 for k, cs in agg.items():
     out[k] = {"launches_sampled": max(len(v) for v in cs.values()), **meta[k],
               "counters_avg_per_launch": {c: sum(v) / len(v) for c, v in sorted(cs.items())}}
-(dst / f"{tag}_pmc.json").write_text(json.dumps(out, indent=1))
+if agg:
+    (dst / f"{tag}_pmc.json").write_text(json.dumps(out, indent=1))
 
 main = [k for k in out if "wgwf<false" in k or "wgwfILb0" in k]
 if main:
-    c = out[main[0]]["counters_avg_per_launch"]
+    FRAMES = int(sys.argv[3]) if len(sys.argv) > 3 else 16  # frames per launch of the profiled command (tools/profile.sh)
+    m = out[main[0]]
+    c = m["counters_avg_per_launch"]
+    summ = {"kernel": main[0], "source": f"profiles/{tag}_pmc.json", "frames_per_launch": FRAMES,
+            "vgpr": m["vgpr"], "sgpr": m["sgpr"], "scratch": m["scratch"]}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
-        (dst / "r01_pmc_traffic.json").write_text(json.dumps({
-            "kernel": main[0], "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
-            "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
-            "hbm_bytes_per_launch": fetch + write,
-            "frames_per_launch": 16,  # tools/profile.sh: every launch of the profiled command covers 16 frames
-            "hbm_bytes_per_launch_upper_bound_fetch_x2": 2 * fetch + write,
-            "note": "FETCH_SIZE/WRITE_SIZE are KiB; scattered 16-B gathers, no gfx950 x2 streaming correction applied"}, indent=1))
-print(json.dumps(out, indent=1)[:3000])
+        summ.update(fetch_bytes_per_frame_raw=fetch / FRAMES, write_bytes_per_frame=write / FRAMES,
+                    hbm_bytes_per_frame=(2 * fetch + write) / FRAMES, hbm_bytes_per_frame_uncorrected=(fetch + write) / FRAMES,
+                    traffic_note="KiB units; FETCH_SIZE doubled (gfx950 counts a 128-B read request as 64 B: MI355X_MICROARCH.md, HBM) -- exact for "
+                                 "the unit-stride float4 state/ray-record streams that dominate, an upper bound for the scattered node gathers; "
+                                 "Infinity-Cache hits are included in both counters")
+    if "SQ_INSTS_VALU" in c:
+        summ["valu_insts_per_frame"] = c["SQ_INSTS_VALU"] / FRAMES
+    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles, SQ_THREAD_CYCLES_VALU thread-cycles: lanes = threads / (4 * quad-cycles)... both as rocprofv3
+        # reports them for this kernel give thread-cycles per active VALU cycle; divided by 64 lanes
+        summ["lane_util"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"] / 64.0
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        summ["wave_cycles_waiting_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        summ["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(summ, indent=1))
+    print(json.dumps(summ, indent=1))
