@@ -42,7 +42,7 @@ struct glrtx_ctx {
     std::string err;
 
     DevBuf forks, tris, nrms, mats, lights, vine, accum_own, counter, rgba8, work;
-    DevBuf wfA[5], wfH, wfHS, wfQ;  // wavefront path state + per-workgroup queues (variant 2)
+    DevBuf wfState, wfQ;      // wavefront path state (7 planes of float4 x ids) + per-workgroup queues (variant 2)
     DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
     DevBuf bvhVert, bvhTri, bvhNodes;  // glrtx_build_lbvh staging
     lbvh::Workspace bvhWs;
@@ -65,6 +65,9 @@ struct glrtx_ctx {
 
     bool count_rays = false;
     bool launch_pending = false;  // ev1 recorded, kernel time not yet folded into stats
+    const char *last_kernel = "";  // name of the last render kernel launched (error reports)
+    mutable bool counters_stale = false;          // a counting launch was issued since the device counters were last read
+    mutable unsigned long long counters_host[2] = {0, 0};
     glrtx_stats st{};
 };
 
@@ -113,7 +116,12 @@ inline float as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
 // Fold the last launch's event pair into the stats (needs the stream to have passed ev1).
 int fold_launch_time(glrtx_ctx *c) {
     if (!c->launch_pending) return GLRTX_OK;
-    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    if (hipError_t e = hipEventSynchronize(c->ev1); e != hipSuccess) {
+        // a fault inside the kernel surfaces here, not at the launch call: say which launch it was
+        c->launch_pending = false;
+        return fail(c, GLRTX_EDEVICE, "render launch failed on the device (%s): %s, %dx%d (%d owned rows), %d frame(s), device %d", hipGetErrorString(e),
+                    c->last_kernel, c->width, c->height, c->owned_rows, c->st.frames_last, c->device);
+    }
     float ms = 0.f, ms2 = 0.f;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->evm));   // render kernel
     HIP_TRY(c, hipEventElapsedTime(&ms2, c->evm, c->ev1));  // plane accumulation (frames in flight), else ~0
@@ -355,14 +363,11 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     }
     const size_t ids = n_frames > 1 ? ((size_t)n_frames << shift) : total;
     int rc;
-    for (auto &b : c->wfA) if ((rc = ensure(c, b, ids * sizeof(float4)))) return rc;
-    if ((rc = ensure(c, c->wfH, ids * sizeof(float4)))) return rc;
-    if ((rc = ensure(c, c->wfHS, ids * sizeof(float2)))) return rc;
+    if ((rc = ensure(c, c->wfState, kWfStatePlanes * ids * sizeof(float4)))) return rc;
     WfArgs w;
     std::memset(&w, 0, sizeof w);
-    w.A0 = (float4 *)c->wfA[0].p; w.A1 = (float4 *)c->wfA[1].p; w.A2 = (float4 *)c->wfA[2].p;
-    w.A3 = (float4 *)c->wfA[3].p; w.A4 = (float4 *)c->wfA[4].p;
-    w.H = (float4 *)c->wfH.p; w.HS = (float2 *)c->wfHS.p;
+    w.state = (float4 *)c->wfState.p;
+    w.ids = ids;
     w.total = (int)total;
     w.tiles8_x = tiles8_x;
     w.refill_min = kRefillMin;
@@ -382,7 +387,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     }
 
     const int lds = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
-                    16 * (int)sizeof(unsigned);
+                    16 * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4);  // ctl | root box | camera block
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
     // four instantiations: ray counting on/off x generic tree traversal / list scan of a vine (brute-force) tree
     using Kernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *);
@@ -405,8 +410,24 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     w.gss_div = 4 * grid;
     if (const char *v = std::getenv("GLRTX_GSS_DIV")) w.gss_div = std::max(0, std::atoi(v));
     if ((rc = ensure(c, c->wfQ, (size_t)grid * kWgQueueF4 * sizeof(float4)))) return rc;  // per-workgroup queues
+    // Shape invariants of the hand-written kernel, checked on the host before every launch (an access past one of these
+    // buffers is a GPU memory fault, not an error code): every path id the launch can form indexes inside the state arrays;
+    // every workgroup of the grid has its own queue slice; a slice holds both halves of the double-buffered ray queue
+    // (2 rays per live path: the next ray and the shadow ray) and of the path-id queue; every (frame, sample) has its plane.
+    {
+        const size_t max_id = (n_frames > 1 ? ((size_t)(n_frames - 1) << shift) : 0) | (total - 1);
+        const size_t slice_f4 = 2 * (size_t)2 * 2 * block_paths /* ray records */ + (2 * (size_t)block_paths * sizeof(unsigned) + 15) / 16 /* path ids */;
+        bool ok = max_id < ids && 2 * max_id + 1 < (size_t)WF_INVALID && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
+                  block_paths <= kWgPathsMax && slice_f4 <= kWgQueueF4 && c->wfQ.bytes >= (size_t)grid * kWgQueueF4 * sizeof(float4) &&
+                  c->wfState.bytes >= kWfStatePlanes * ids * sizeof(float4) && w.ids == ids && grid >= 1 && grid <= resident &&
+                  p->max_depth <= kWfDepthMax && p->n_samples <= kWfSampleMax && c->work.p != nullptr;
+        if (n_frames > 1) ok = ok && c->wfPlanes.bytes >= (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4) && c->wfSeeds.bytes >= (size_t)n_frames * sizeof(float2);
+        if (!ok) return fail(c, GLRTX_EDEVICE, "internal: wgwf launch shapes inconsistent (ids %zu, max id %zu, grid %d, block_paths %d, frames %d)", ids, max_id, grid, block_paths, n_frames);
+    }
     HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    c->last_kernel = vine ? "pt_render_wgwf (list scan)" : "pt_render_wgwf";
+    c->counters_stale = c->counters_stale || c->count_rays;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (float4 *)c->wfQ.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->evm, c->stream));
@@ -476,8 +497,7 @@ void glrtx_destroy(glrtx_ctx *c) {
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     dev_free(c->forks); dev_free(c->tris); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights); dev_free(c->vine);
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
-    for (auto &b : c->wfA) dev_free(b);
-    dev_free(c->wfH); dev_free(c->wfHS); dev_free(c->wfQ); dev_free(c->wfSeeds); dev_free(c->wfPlanes);
+    dev_free(c->wfState); dev_free(c->wfQ); dev_free(c->wfSeeds); dev_free(c->wfPlanes);
     dev_free(c->bvhVert); dev_free(c->bvhTri); dev_free(c->bvhNodes);
     if (c->bvhWs.p) { (void)hipFree(c->bvhWs.p); c->bvhWs.p = nullptr; c->bvhWs.bytes = 0; }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -687,8 +707,8 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
     const size_t px = (size_t)((c->width + 7) / 8) * (size_t)((c->owned_rows + 7) / 8) * 64;
     size_t stride = 64;
     while (stride < px) stride <<= 1;
-    const size_t held = c->wfPlanes.bytes + c->wfH.bytes + c->wfHS.bytes + 5 * c->wfA[0].bytes;  // already ours, reusable
-    const size_t per_frame = stride * 104 + (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
+    const size_t held = c->wfPlanes.bytes + c->wfState.bytes;  // already ours, reusable
+    const size_t per_frame = stride * kWfStatePlanes * sizeof(float4) + (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
     size_t budget = std::min<size_t>((size_t)48 << 30, (free_b + held) / 2);
     if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;  // tests
     const size_t id_cap = (((size_t)1 << 30) - 1) / stride;  // path ids are 31-bit, ray ids twice that
@@ -725,9 +745,10 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
 
     KernelArgs a;
     a.sc = c->sc;
-    std::memcpy(a.c2w, p->c2w, sizeof a.c2w);
-    std::memcpy(a.s2c, p->s2c, sizeof a.s2c);
-    a.aperture = p->aperture; a.focal = p->focal;
+    static_assert(sizeof a.cam == kCamFloats * sizeof(float), "camera block layout");
+    std::memcpy(a.cam, p->c2w, 16 * sizeof(float));
+    std::memcpy(a.cam + 16, p->s2c, 16 * sizeof(float));
+    a.cam[32] = p->aperture; a.cam[33] = p->focal;
     a.seed_x = p->seed[0]; a.seed_y = p->seed[1];
     a.n_samples = p->n_samples; a.max_depth = p->max_depth;
     a.width = c->width; a.height = c->height;
@@ -771,10 +792,12 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
         c->resident_wg[ci] = grid;
         HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        c->last_kernel = "pt_render_persistent";
         if (ci) hipLaunchKernelGGL(pt_render_persistent<true>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, (unsigned *)c->work.p);
         else hipLaunchKernelGGL(pt_render_persistent<false>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, (unsigned *)c->work.p);
     } else {
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    c->last_kernel = "pt_render_kernel";
     if (c->count_rays) {
         if (lds > 64 * 1024)
             HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -788,6 +811,7 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->evm, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->counters_stale = c->counters_stale || c->count_rays;
     c->launch_pending = true;
     c->st.frames_last = 1;
     c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples;
@@ -845,8 +869,12 @@ int glrtx_resolve_rgba8(glrtx_ctx *c, uint8_t *dst, size_t dst_pitch_bytes, floa
 int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
     if (!c || !out) return GLRTX_EINVAL;
     *out = c->st;
-    unsigned long long r[2] = {0, 0};
-    if (c->counter.p && hipMemcpy(r, c->counter.p, sizeof r, hipMemcpyDeviceToHost) == hipSuccess) { out->rays = r[0]; out->rays_untraced = r[1]; }
+    // the ray counters live on the device; they are read back (a blocking copy) only when a counting launch was issued since
+    // the last read, so polling the stats of a non-counting render loop costs no device round trip
+    if (c->counters_stale && c->counter.p && hipSetDevice(c->device) == hipSuccess &&
+        hipMemcpy(c->counters_host, c->counter.p, sizeof c->counters_host, hipMemcpyDeviceToHost) == hipSuccess)
+        c->counters_stale = false;
+    out->rays = c->counters_host[0]; out->rays_untraced = c->counters_host[1];
     return GLRTX_OK;
 }
 
@@ -854,6 +882,7 @@ int glrtx_reset_stats(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
     if (int rc = glrtx_sync(c)) return rc;
     HIP_TRY(c, hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long)));
+    c->counters_host[0] = c->counters_host[1] = 0; c->counters_stale = false;
     c->st.rays = 0; c->st.rays_untraced = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f;
     return GLRTX_OK;
 }

@@ -62,9 +62,7 @@ struct DevScene {
 
 struct KernelArgs {
     DevScene sc;
-    float c2w[16];
-    float s2c[16];
-    float aperture, focal;
+    float cam[34];           // camera block: c2w[16] (u_c2wMat), s2c[16] (u_s2cMat), u_apertureRadius, u_focalLength
     float seed_x, seed_y;
     int n_samples, max_depth;
     int width, height;       // full image
@@ -77,6 +75,46 @@ struct KernelArgs {
 };
 
 #define DEV __device__ __forceinline__
+
+// Streamed data (path state, ray records, hit records, sample planes): written once and read once per trip, never
+// reused from cache.  GLRTX_STREAM_NT marks those accesses non-temporal so that they do not displace the BVH from L2.
+#ifndef GLRTX_STREAM_NT
+#define GLRTX_STREAM_NT 3
+#endif
+typedef float nfloat4 __attribute__((ext_vector_type(4)));
+typedef float nfloat2 __attribute__((ext_vector_type(2)));
+DEV float4 ld_stream(const float4 *p) {
+#if GLRTX_STREAM_NT & 1
+    const nfloat4 v = __builtin_nontemporal_load(reinterpret_cast<const nfloat4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+DEV float2 ld_stream(const float2 *p) {
+#if GLRTX_STREAM_NT & 1
+    const nfloat2 v = __builtin_nontemporal_load(reinterpret_cast<const nfloat2 *>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+DEV void st_stream(float4 *p, float4 v) {
+#if GLRTX_STREAM_NT & 2
+    nfloat4 n; n.x = v.x; n.y = v.y; n.z = v.z; n.w = v.w;
+    __builtin_nontemporal_store(n, reinterpret_cast<nfloat4 *>(p));
+#else
+    *p = v;
+#endif
+}
+DEV void st_stream(float2 *p, float2 v) {
+#if GLRTX_STREAM_NT & 2
+    nfloat2 n; n.x = v.x; n.y = v.y;
+    __builtin_nontemporal_store(n, reinterpret_cast<nfloat2 *>(p));
+#else
+    *p = v;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------ sin / cos
 // Cephes sinf/cosf with FMA, the routine the reference's GL implementation uses for sin()/cos().
@@ -182,14 +220,32 @@ DEV bool box_pass(float4 lo, float4 hi, float ox, float oy, float oz, float ix, 
 // iterations, [2] lanes on the fork path, [3] lanes on the leaf path, [4] iterations with both paths live
 __device__ unsigned long long g_trav_stats[8];
 __device__ unsigned long long g_trav_hist[16];  // rays by ceil(log2(iterations))
-DEV void trav_stats_iter(int cur) {
-    const unsigned long long m = __ballot(1), mf = __ballot(cur >= 0);
+// [5] distinct 64-byte node records, [6] distinct 128-byte lines fetched by the wave (summed over iterations), [7] lanes carrying a path ray
+DEV void trav_stats_iter(int cur, const void *rec, bool path_ray) {
+    const unsigned long long m = __ballot(1), mf = __ballot(cur >= 0), mp = __ballot(path_ray);
+    int n_rec = 0, n_line = 0;
+    const unsigned lo = (unsigned)((uintptr_t)rec >> 6), hi = (unsigned)((uintptr_t)rec >> 38);
+    for (unsigned long long rem = m; rem != 0ull;) {
+        const int l = __ffsll((long long)rem) - 1;
+        const unsigned vlo = (unsigned)__shfl((int)lo, l), vhi = (unsigned)__shfl((int)hi, l);
+        rem &= ~__ballot(lo == vlo && hi == vhi);
+        n_rec++;
+    }
+    for (unsigned long long rem = m; rem != 0ull;) {
+        const int l = __ffsll((long long)rem) - 1;
+        const unsigned vlo = (unsigned)__shfl((int)(lo >> 1), l), vhi = (unsigned)__shfl((int)hi, l);
+        rem &= ~__ballot((lo >> 1) == vlo && hi == vhi);
+        n_line++;
+    }
     if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
         atomicAdd(&g_trav_stats[0], 1ull);
         atomicAdd(&g_trav_stats[1], (unsigned long long)__popcll(m));
         atomicAdd(&g_trav_stats[2], (unsigned long long)__popcll(mf));
         atomicAdd(&g_trav_stats[3], (unsigned long long)__popcll(m & ~mf));
         if (mf != 0 && (m & ~mf) != 0) atomicAdd(&g_trav_stats[4], 1ull);
+        atomicAdd(&g_trav_stats[5], (unsigned long long)n_rec);
+        atomicAdd(&g_trav_stats[6], (unsigned long long)n_line);
+        atomicAdd(&g_trav_stats[7], (unsigned long long)__popcll(mp));
     }
 }
 #endif
@@ -221,7 +277,9 @@ struct Trav {
 };
 
 // Returns false if the ray is finished before the first step (root box missed).
-DEV bool trav_init(const DevScene &sc, Trav &T, float ox, float oy, float oz, float dx, float dy, float dz,
+// `root` = {root_lo, root_hi}: &sc.root_lo, or the workgroup's LDS copy of it (the wavefront kernel keeps launch constants
+// that only the refill and camera code read out of the scalar registers, which its traversal loop needs for itself).
+DEV bool trav_init(const DevScene &sc, const float4 *root, Trav &T, float ox, float oy, float oz, float dx, float dy, float dz,
                    float limit = PT_INFTY, float stop_d = -__builtin_inff()) {
     T.ox = ox; T.oy = oy; T.oz = oz; T.dx = dx; T.dy = dy; T.dz = dz;
     T.ix = 1.0f / dx; T.iy = 1.0f / dy; T.iz = 1.0f / dz;  // :260 (loop-invariant there)
@@ -234,7 +292,7 @@ DEV bool trav_init(const DevScene &sc, Trav &T, float ox, float oy, float oz, fl
 #endif
     if (T.cur >= 0) {  // the root fork's own box
         float t0;
-        if (!box_pass(sc.root_lo, sc.root_hi, ox, oy, oz, T.ix, T.iy, T.iz, T.h.t, t0)) return false;
+        if (!box_pass(root[0], root[1], ox, oy, oz, T.ix, T.iy, T.iz, T.h.t, t0)) return false;
     }
     return true;
 }
@@ -244,7 +302,7 @@ DEV bool trav_init(const DevScene &sc, Trav &T, float ox, float oy, float oz, fl
 template <bool CLOSEST>
 DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
 #ifdef GLRTX_TRAV_STATS
-    trav_stats_iter(T.cur);
+    trav_stats_iter(T.cur, T.cur >= 0 ? (const void *)(sc.forks + 4 * (size_t)T.cur) : (const void *)(sc.tris + 4 * (size_t)(~T.cur)), T.stop_d == -__builtin_inff());
     T.iters++;
 #define TS_DONE atomicAdd(&g_trav_hist[T.iters <= 1 ? 0 : (32 - __clz((int)T.iters - 1)) > 15 ? 15 : (32 - __clz((int)T.iters - 1))], 1ull)
 #else
@@ -274,11 +332,22 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
         // leaf children are never box-tested (:310-331); an absent child never passes
         const bool pl = l != REF_ABSENT && (l < 0 || bl);
         const bool pr = r != REF_ABSENT && (r < 0 || br);
+#ifdef GLRTX_NEAR_FIRST_EXPERIMENT
+        // MEASUREMENT ONLY (never shipped: ties may resolve differently from the reference): a path ray visits the nearer child first
+        const float kl = l < 0 ? -PT_INFTY : t0l, kr = r < 0 ? -PT_INFTY : t0r;
+        const bool lf = pl && pr && T.stop_d == -__builtin_inff() && kl < kr;
+        if (pl && pr) {
+            reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = lf ? make_int2(r, __float_as_int(kr)) : make_int2(l, __float_as_int(kl));
+            T.sp++;
+        }
+        T.cur = lf ? l : (pr ? r : l);
+#else
         if (pl && pr) {  // continue with the right child, the left one waits on the stack
             reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = make_int2(l, __float_as_int(l < 0 ? -PT_INFTY : t0l));  // one ds_write_b64
             T.sp++;
         }
         T.cur = pr ? r : l;
+#endif
         need_pop = !(pl || pr);
     } else {
         // leaf :310-331 with intersect(Ray, Triangle) :226-257; A = {v0, material}, B = v1-v0, C = v2-v0
@@ -409,7 +478,7 @@ template <bool CLOSEST>
 DEV Hit traverse(const DevScene &sc, int *stack, float ox, float oy, float oz, float dx, float dy, float dz,
                  float limit = PT_INFTY, float stop_d = -__builtin_inff()) {
     Trav T;
-    if (trav_init(sc, T, ox, oy, oz, dx, dy, dz, limit, stop_d))
+    if (trav_init(sc, &sc.root_lo, T, ox, oy, oz, dx, dy, dz, limit, stop_d))
         while (!trav_step<CLOSEST>(sc, stack, T)) {}
     return T.h;
 }
@@ -438,12 +507,20 @@ DEV float ggx(float hx, float hy, float hz, float ax, float ay) {
 struct Mat {
     float4 m0, m1, m2;  // {emission, type} {param0, alpha.x} {param1, alpha.y}
 };
+// Explicit address spaces: left generic, the two arms are merged into one flat_load through a selected pointer, and a flat
+// access to LDS takes the vector-memory path instead of ds_read.
+typedef const __attribute__((address_space(3))) nfloat4 *lds_cf4;
+typedef const __attribute__((address_space(1))) nfloat4 *glb_cf4;
+typedef const __attribute__((address_space(1))) nfloat2 *glb_cf2;
+DEV float4 to_f4(nfloat4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 DEV Mat load_mat(const DevScene &sc, const float4 *lds_mats, int m) {
     Mat r;
     if (sc.mats_in_lds) {
-        r.m0 = lds_mats[3 * m]; r.m1 = lds_mats[3 * m + 1]; r.m2 = lds_mats[3 * m + 2];
+        const lds_cf4 q = (lds_cf4)lds_mats + 3 * m;
+        r.m0 = to_f4(q[0]); r.m1 = to_f4(q[1]); r.m2 = to_f4(q[2]);
     } else {
-        r.m0 = sc.mats[3 * m]; r.m1 = sc.mats[3 * m + 1]; r.m2 = sc.mats[3 * m + 2];
+        const glb_cf4 q = (glb_cf4)sc.mats + 3 * m;
+        r.m0 = to_f4(q[0]); r.m1 = to_f4(q[1]); r.m2 = to_f4(q[2]);
     }
     return r;
 }
@@ -763,9 +840,13 @@ DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rn
 }
 
 // primary ray of one sample, main() :577-607
-DEV void camera_ray(const KernelArgs &a, Rng &rng, float fcx, float fcy, Path &P) {
+// `cam` = the launch's camera block {c2w[16], s2c[16], aperture, focal}: a.cam, or the
+// workgroup's LDS copy of it.
+constexpr int kCamFloats = 34;  // == sizeof(KernelArgs::cam) / 4
+DEV void camera_ray(const KernelArgs &a, const float *cam, Rng &rng, float fcx, float fcy, Path &P) {
     const float W = (float)a.width, H = (float)a.height;
-    const float *S = a.s2c, *C = a.c2w;
+    const float *S = cam + 16, *C = cam;
+    const float aperture = cam[32], focal = cam[33];
     const float r0 = pt_rand(rng);
     const float r1 = pt_rand(rng);
     const float nx = ((fcx + r0) / W) * 2.0f + -1.0f;
@@ -779,14 +860,14 @@ DEV void camera_ray(const KernelArgs &a, Rng &rng, float fcx, float fcy, Path &P
     const float rn = rsq((cz * cz + cy * cy) + cx * cx);
     float dx = cx * rn, dy = cy * rn, dz = cz * rn;
     float lox = 0.0f, loy = 0.0f;
-    if (0.0f < a.aperture) {  // thin lens :589-598
+    if (0.0f < aperture) {  // thin lens :589-598
         const float ra = pt_rand(rng);
         const float rb = pt_rand(rng);
-        const float r = __builtin_sqrtf(ra) * a.aperture;
+        const float r = __builtin_sqrtf(ra) * aperture;
         const float th = PT_2PI * rb;
         lox = r * pt_cos(th);
         loy = r * pt_sin(th);
-        const float ft = (-a.focal) / dz;
+        const float ft = (-focal) / dz;
         const float fx = dx * ft - lox, fy = dy * ft - loy, fz = dz * ft;
         const float rf = rsq((fz * fz + fy * fy) + fx * fx);
         dx = fx * rf; dy = fy * rf; dz = fz * rf;
@@ -864,7 +945,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_kernel(const KernelAr
         float4 acc = *px;  // previous (L, count): read-modify-write replaces the ping-pong FBOs (:570-572)
         for (int i = 0; i < a.n_samples; i++) {
             Path P;
-            camera_ray(a, rng, fcx, fcy, P);
+            camera_ray(a, a.cam, rng, fcx, fcy, P);
             if (a.max_depth > 0)
                 while (!bounce(a, lds_mats, stack, rng, P, rays)) {}
             acc.x = acc.x + fmin_c(P.Lx, 100.0f);  // :558, :608
@@ -953,7 +1034,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
         // ---- one step for every live lane: (new sample ->) one bounce
         if (alive) {
             if (fresh) {
-                camera_ray(a, rng, fcx, fcy, P);
+                camera_ray(a, a.cam, rng, fcx, fcy, P);
                 fresh = false;
             }
             bool finished = true;
@@ -990,15 +1071,22 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
 // queues -- was built and measured first: 5.3 ms per headline frame, of which ~3.4 ms was nine
 // device-wide waits for each trip's longest ray.  The workgroup-local form below replaced it.)
 struct WfArgs {
-    float4 *A0;  // {next ray origin (= shadow ray origin), rng.x}
-    float4 *A1;  // {next ray direction, rng.y}
-    float4 *A2;  // {beta, meta}           meta = depth | sample << 8 | flags
-    float4 *A3;  // {L if the pending light sample is accepted (or L), dist}
-    float4 *A4;  // {L if it is rejected, -}
+    // Path state: seven float4-wide planes of `ids` entries each in ONE allocation (one base pointer and one stride in scalar
+    // registers instead of seven pointers), plane k of path id at state[k * ids + id]:
+    //   0: {next ray origin (= shadow ray origin), rng.x}      1: {next ray direction, rng.y}
+    //   2: {beta, meta}   meta = depth | sample << 8 | flags   3: {L if the pending light sample is accepted (or L), dist}
+    //   4: {L if it is rejected, -}                             5: closest hit of the path's ray {t, tri, u, v}
+    //   6: closest hit of the shadow ray {t, tri} (first 8 bytes of the entry)
     // (ray origins/directions for the traversal travel in the workgroup's ray queue: 32-byte records
     //  {origin, ray id} {direction, -} in queue order, read with unit stride)
-    float4 *H;   // closest hit of the path's ray {t, tri, u, v}
-    float2 *HS;  // closest hit of the shadow ray {t, tri}
+    float4 *state;
+    size_t ids;
+    // The plane offset is recomputed where it is used (an opaque move keeps the compiler from hoisting seven derived base
+    // pointers out of the persistent loop, where they would sit in scalar registers the traversal loop has to spill).
+    DEV size_t plane(int k) const { size_t n = ids; asm volatile("" : "+s"(n)); return (size_t)k * n; }
+    DEV float4 *A(int k, unsigned id) const { return state + plane(k) + id; }
+    DEV float4 *H(unsigned id) const { return state + plane(5) + id; }
+    DEV float2 *HS(unsigned id) const { return reinterpret_cast<float2 *>(state + plane(6) + id); }
     int total;        // tile-order ids: tiles8_x * tiles8_y * 64
     int tiles8_x;
     int refill_min;   // refill a traversal wave once this many lanes are idle
@@ -1018,6 +1106,7 @@ struct WfArgs {
 };
 // meta word of the path state: depth in bits 0-7 (it reaches max_depth before the path ends), sample index in bits 8-27.
 // The host sends launches beyond these ranges to the persistent megakernel (glrtx_render).
+constexpr int kWfStatePlanes = 7;  // float4-wide planes of WfArgs::state
 constexpr int kWfDepthMax = 255;
 constexpr int kWfSampleMax = (1 << 20) - 1;
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
@@ -1035,7 +1124,11 @@ DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lr
 
 // u_seed of the frame a path belongs to
 DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, int id) {
-    return w.n_frames > 1 ? w.seeds[id >> w.frame_shift] : make_float2(a.seed_x, a.seed_y);
+    if (w.n_frames > 1) {
+        const nfloat2 v = ((glb_cf2)w.seeds)[id >> w.frame_shift];
+        return make_float2(v.x, v.y);
+    }
+    return make_float2(a.seed_x, a.seed_y);
 }
 
 // A finished sample: radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609).
@@ -1043,8 +1136,8 @@ DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, int id) {
 DEV void wf_add_sample(const KernelArgs &a, const WfArgs &w, int id, int lx, int lrow, unsigned sample, float Lx, float Ly, float Lz) {
     if (w.n_frames > 1) {
         const size_t slot = (size_t)(id >> w.frame_shift) * (size_t)a.n_samples + sample;
-        w.planes[(slot * (size_t)a.owned_rows + (size_t)lrow) * (size_t)a.pitch_f4 + lx] =
-            make_float4(fmin_c(Lx, 100.0f), fmin_c(Ly, 100.0f), fmin_c(Lz, 100.0f), 1.0f);
+        st_stream(&w.planes[(slot * (size_t)a.owned_rows + (size_t)lrow) * (size_t)a.pitch_f4 + lx],
+                  make_float4(fmin_c(Lx, 100.0f), fmin_c(Ly, 100.0f), fmin_c(Lz, 100.0f), 1.0f));
     } else {
         float4 *px = a.accum + (size_t)lrow * a.pitch_f4 + lx;
         float4 acc = *px;
@@ -1058,10 +1151,10 @@ DEV void wf_add_sample(const KernelArgs &a, const WfArgs &w, int id, int lx, int
 
 // Start the pixel's next sample(s): camera ray -> state; returns true if a ray must be traced.
 // With u_maxDepth <= 0 a sample is finished as soon as it starts (main() still draws its jitter).
-DEV bool wf_start(const KernelArgs &a, const WfArgs &w, int id, int lx, int lrow, Rng &rng, float fcx, float fcy, Path &P, unsigned &sample) {
+DEV bool wf_start(const KernelArgs &a, const WfArgs &w, const float *cam, int id, int lx, int lrow, Rng &rng, float fcx, float fcy, Path &P, unsigned &sample) {
     for (;;) {
         if ((int)sample >= a.n_samples) return false;
-        camera_ray(a, rng, fcx, fcy, P);
+        camera_ray(a, cam, rng, fcx, fcy, P);
         if (a.max_depth > 0) return true;
         wf_add_sample(a, w, id, lx, lrow, sample, 0.0f, 0.0f, 0.0f);  // min(L, 100) of L = 0
         sample++;
@@ -1070,7 +1163,7 @@ DEV bool wf_start(const KernelArgs &a, const WfArgs &w, int id, int lx, int lrow
 
 // Start path `id` (frame | tile-order pixel id): seed its RNG, draw sample 0's camera ray, store the path state.
 // Returns true if a ray was queued (false: outside the image, or nothing to trace).
-DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id, float4 &ray_o, float4 &ray_d) {
+DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam, int id, float4 &ray_o, float4 &ray_d) {
     int lx, lrow;
     bool go = false;
     const float2 sd = wf_seed(a, w, id);
@@ -1081,13 +1174,13 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id, float4 &r
         const int gy = local_row_to_y(a, lrow);
         const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
         rng.x = fcx / (float)a.width; rng.y = fcy / (float)a.height;  // :567
-        go = wf_start(a, w, id, lx, lrow, rng, fcx, fcy, P, sample);
+        go = wf_start(a, w, cam, id, lx, lrow, rng, fcx, fcy, P, sample);
     }
     if (go) {
-        w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
-        w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
-        w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
-        w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+        st_stream(w.A(0, id), make_float4(P.ox, P.oy, P.oz, rng.x));
+        st_stream(w.A(1, id), make_float4(P.dx, P.dy, P.dz, rng.y));
+        st_stream(w.A(2, id), make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8)));
+        st_stream(w.A(3, id), make_float4(0.f, 0.f, 0.f, 0.f));
         ray_o = make_float4(P.ox, P.oy, P.oz, __uint_as_float((unsigned)id * 2u));
         ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
     }
@@ -1097,13 +1190,13 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, int id, float4 &r
 // One path of the shade stage: resolve the light sample of the previous bounce, then either close the
 // sample (and start the pixel's next one) or run shade_hit() on the new hit.  Outputs which rays to
 // queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray.
-DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, unsigned id, bool &push_ext, bool &push_sh,
+DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, unsigned id, bool &push_ext, bool &push_sh,
                        float4 &ray_o, float4 &ray_d, float4 &ray_sd, unsigned long long &rays) {
     int lx, lrow;
     wf_pixel(a, w, (int)id, lx, lrow);
     const int gy = local_row_to_y(a, lrow);
     const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
-    const float4 s0 = w.A0[id], s1 = w.A1[id], s2 = w.A2[id], s3 = w.A3[id];
+    const float4 s0 = ld_stream(w.A(0, id)), s1 = ld_stream(w.A(1, id)), s2 = ld_stream(w.A(2, id)), s3 = ld_stream(w.A(3, id));
     const float2 sd = wf_seed(a, w, (int)id);
     Rng rng = {s0.w, s1.w, sd.x, sd.y};
     const unsigned meta = __float_as_uint(s2.w);
@@ -1115,9 +1208,9 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     // resolve the light sample of the previous bounce (:367, :539)
     P.Lx = s3.x; P.Ly = s3.y; P.Lz = s3.z;
     if (meta & WF_PENDING) {
-        const float2 hs = w.HS[id];
+        const float2 hs = ld_stream(w.HS(id));
         if (!nee_accepted(s3.w, hs.x, __float_as_int(hs.y) >= 0)) {
-            const float4 s4 = w.A4[id];
+            const float4 s4 = ld_stream(w.A(4, id));
             P.Lx = s4.x; P.Ly = s4.y; P.Lz = s4.z;
         }
     }
@@ -1125,7 +1218,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     Shade sh;
     sh.has_shadow = false;
     if (!ended) {
-        const float4 hh = w.H[id];
+        const float4 hh = ld_stream(w.H(id));
         Hit h;
         h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
         shade_hit(a, lds_mats, rng, P, h, sh);
@@ -1136,12 +1229,12 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     if (ended) {
         wf_add_sample(a, w, (int)id, lx, lrow, sample, P.Lx, P.Ly, P.Lz);
         sample++;
-        push_ext = wf_start(a, w, (int)id, lx, lrow, rng, fcx, fcy, P, sample);  // the pixel's next sample, if any
+        push_ext = wf_start(a, w, cam, (int)id, lx, lrow, rng, fcx, fcy, P, sample);  // the pixel's next sample, if any
         if (push_ext) {
-            w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
-            w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
-            w.A2[id] = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
-            w.A3[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+            st_stream(w.A(0, id), make_float4(P.ox, P.oy, P.oz, rng.x));
+            st_stream(w.A(1, id), make_float4(P.dx, P.dy, P.dz, rng.y));
+            st_stream(w.A(2, id), make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8)));
+            st_stream(w.A(3, id), make_float4(0.f, 0.f, 0.f, 0.f));
             ray_o = make_float4(P.ox, P.oy, P.oz, 0.f);
             ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
         }
@@ -1150,11 +1243,11 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         push_sh = sh.has_shadow;
         push_ext = !sh.ended;
         const unsigned m2 = (unsigned)P.depth | (sample << 8) | (push_sh ? WF_PENDING : 0u) | (sh.ended ? WF_FINISHING : 0u);
-        w.A0[id] = make_float4(P.ox, P.oy, P.oz, rng.x);
-        w.A1[id] = make_float4(P.dx, P.dy, P.dz, rng.y);
-        w.A2[id] = make_float4(P.bx, P.by, P.bz, __uint_as_float(m2));
-        w.A3[id] = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist);
-        if (push_sh) w.A4[id] = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f);
+        st_stream(w.A(0, id), make_float4(P.ox, P.oy, P.oz, rng.x));
+        st_stream(w.A(1, id), make_float4(P.dx, P.dy, P.dz, rng.y));
+        st_stream(w.A(2, id), make_float4(P.bx, P.by, P.bz, __uint_as_float(m2)));
+        st_stream(w.A(3, id), make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist));
+        if (push_sh) st_stream(w.A(4, id), make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f));
         ray_o = make_float4(P.ox, P.oy, P.oz, 0.f);  // the next ray and the shadow ray leave from the same point
         ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
         ray_sd = make_float4(sh.sdx, sh.sdy, sh.sdz, sh.dist);
@@ -1171,7 +1264,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 // shade kernel per trip lost ~300 us per trip to that wait, nine times a frame).  One launch covers one frame, or
 // several frames in flight (WfArgs).  Path state lives in HBM as float4 SoA.
 #ifndef GLRTX_STEPS_PER_TRIP
-#define GLRTX_STEPS_PER_TRIP 4
+#define GLRTX_STEPS_PER_TRIP 6
 #endif
 constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes its queues); the host picks block_paths <= this so
                                    // that the launch has that many pixels for every resident workgroup
@@ -1202,7 +1295,7 @@ __device__ uint4 g_trip_log[16][64];
 // rank r takes the record held by lane (consumed + r) through a cross-lane read.  (Fetching a ray when a lane fell
 // idle -- queue index, then path state, two dependent round trips -- cost 14 % of the phase.)
 template <bool VINE>
-DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, const float4 *rq, int n_rays,
+DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
     if (VINE) {  // list scan: every ray takes the same number of steps, so waves simply take 64 rays at a time
@@ -1212,15 +1305,15 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= n_rays) break;
             float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID)), d = o;
-            if (base + lane < n_rays) { o = rq[2 * (size_t)(base + lane)]; d = rq[2 * (size_t)(base + lane) + 1]; }
+            if (base + lane < n_rays) { o = ld_stream(&rq[2 * (size_t)(base + lane)]); d = ld_stream(&rq[2 * (size_t)(base + lane) + 1]); }
             const unsigned r = __float_as_uint(o.w);
             const bool shadow = (r & 1u) != 0u;
             const Hit h = trav_scan<true>(a.sc, o.x, o.y, o.z, d.x, d.y, d.z, r != WF_INVALID, shadow ? shadow_limit(d.w) : PT_INFTY,
                                           shadow ? d.w : -__builtin_inff());
             if (r != WF_INVALID) {
                 rays++;
-                if (r & 1u) w.HS[r >> 1] = make_float2(h.t, __int_as_float(h.tri));
-                else w.H[r >> 1] = make_float4(h.t, __int_as_float(h.tri), h.u, h.v);
+                if (r & 1u) st_stream(w.HS(r >> 1), make_float2(h.t, __int_as_float(h.tri)));
+                else st_stream(w.H(r >> 1), make_float4(h.t, __int_as_float(h.tri), h.u, h.v));
             }
         }
         return;
@@ -1236,8 +1329,8 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
         int cnt = n_rays - base;
         cnt = cnt < 0 ? 0 : (cnt > 64 ? 64 : cnt);
         if (lane < cnt) {
-            o = rq[2 * (size_t)(base + lane)];
-            d = rq[2 * (size_t)(base + lane) + 1];
+            o = ld_stream(&rq[2 * (size_t)(base + lane)]);
+            d = ld_stream(&rq[2 * (size_t)(base + lane) + 1]);
         }
         return cnt;
     };
@@ -1257,8 +1350,8 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
     T.h.t = PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
     auto save_hit = [&]() {
         const unsigned id = rid >> 1;
-        if (rid & 1u) w.HS[id] = make_float2(T.h.t, __int_as_float(T.h.tri));
-        else w.H[id] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
+        if (rid & 1u) st_stream(w.HS(id), make_float2(T.h.t, __int_as_float(T.h.tri)));
+        else st_stream(w.H(id), make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v));
         unsaved = false;
     };
     for (;;) {
@@ -1294,7 +1387,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
                     if (rid != WF_INVALID) {
                         rays++;
                         const bool shadow = (rid & 1u) != 0u;
-                        active = trav_init(a.sc, T, ox, oy, oz, dx, dy, dz, shadow ? shadow_limit(dist) : PT_INFTY,
+                        active = trav_init(a.sc, root, T, ox, oy, oz, dx, dy, dz, shadow ? shadow_limit(dist) : PT_INFTY,
                                            shadow ? dist : -__builtin_inff());
                         unsaved = !active;  // root box missed: the (miss) record is already final
                     }
@@ -1329,7 +1422,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, int *stack, con
 // Shade phase of one trip, run by a whole workgroup: every live path (pq[0..n_paths))
 // goes through wf_shade_path(); the rays and paths of the next trip are appended to rq_next / pq_next
 // (wave-aggregated, one LDS atomic per wave and queue on *n_rays_next / *n_paths_next).
-DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const unsigned *pq, int n_paths,
+DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, const unsigned *pq, int n_paths,
                         float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1339,7 +1432,7 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         unsigned id = WF_INVALID;
         float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro, rsd = ro;
         if (i < n_paths) id = pq[i];
-        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, id, push_ext, push_sh, ro, rd, rsd, rays);
+        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, cam, id, push_ext, push_sh, ro, rd, rsd, rays);
         const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
         unsigned br = 0, bp = 0;
         if (lane == 0) {
@@ -1352,16 +1445,32 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         bp = __builtin_amdgcn_readfirstlane(bp);
         if (push_ext) {
             float4 *r = rq_next + 2 * (size_t)(br + __popcll(me & lt_mask));
-            r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u));
-            r[1] = rd;
+            st_stream(&r[0], make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u)));
+            st_stream(&r[1], rd);
         }
         if (push_sh) {
             float4 *r = rq_next + 2 * (size_t)(br + __popcll(me) + __popcll(ms & lt_mask));
-            r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u + 1u));
-            r[1] = rsd;
+            st_stream(&r[0], make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u + 1u)));
+            st_stream(&r[1], rsd);
         }
         if (push_ext || push_sh) pq_next[bp + __popcll(mp & lt_mask)] = id;
     }
+}
+
+// The kernel's by-value arguments as they lie in the kernarg segment (same layout rules as a struct).  The shade and top-up
+// phases read their launch constants from there, through a pointer the compiler cannot see through, instead of from the
+// by-value copies: those would be loaded once at kernel entry and stay live -- in ~100 scalar registers -- across the
+// traversal loop.  Read where they are used they are scalar-cache hits with short live ranges.
+struct WgwfKernArgs {
+    KernelArgs a;
+    WfArgs w;
+    unsigned *work_counter;
+    float4 *wg_queues;
+};
+DEV const WgwfKernArgs *wgwf_kernargs() {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();  // constant address space
+    asm volatile("" : "+s"(p));  // opaque: loads through it stay behind this point
+    return (const WgwfKernArgs *)p;
 }
 
 template <bool COUNT_RAYS, bool VINE>
@@ -1375,6 +1484,13 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
     unsigned *ctl = reinterpret_cast<unsigned *>(pl);            // 0: first new tile, 1: ray head, 2..3: nRays[2], 4..5: nPaths[2], 6: new tiles, 7: frame exhausted
+    // launch constants that only the refill / camera code reads: kept in LDS, not in scalar registers (the kernel arguments alone
+    // would occupy ~100 of the 102 SGPRs and spill into VGPR lanes inside the traversal loop)
+    float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));      // {root_lo, root_hi}
+    float *lds_cam = reinterpret_cast<float *>(pl + 16 * sizeof(unsigned) + 32);     // {c2w, s2c, aperture, focal}
+    if (threadIdx.x < kCamFloats) lds_cam[threadIdx.x] = a.cam[threadIdx.x];
+    if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
+    if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
     // per-workgroup slice of the queue buffer: ray records float4[2][2 * block_paths][2], then path ids unsigned[2][block_paths]
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
     unsigned *pathQ = reinterpret_cast<unsigned *>(rayQ + 8 * (size_t)w.block_paths);
@@ -1419,13 +1535,14 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
             const int nr = (int)ctl[2 + cur], np = (int)ctl[4 + cur];
             float4 *rq_w = rayQ + 2 * ((size_t)cur * 2 * kWgPaths + nr);
             unsigned *pq_w = pathQ + cur * kWgPaths + np;
+            const WgwfKernArgs *kt = wgwf_kernargs();
             for (int k = threadIdx.x; k < got; k += kBlockThreads) {
-                const int g = tile0 + (k >> 6), f = g / w.tiles_per_frame;
-                const int id = (f << w.frame_shift) | ((g - f * w.tiles_per_frame) * 64 + (k & 63));
+                const int g = tile0 + (k >> 6), f = g / kt->w.tiles_per_frame;
+                const int id = (f << kt->w.frame_shift) | ((g - f * kt->w.tiles_per_frame) * 64 + (k & 63));
                 float4 ro = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID)), rd = ro;
-                const bool go = wf_generate_one(a, w, id, ro, rd);  // pixels outside the image leave skip markers
-                rq_w[2 * k] = ro;
-                rq_w[2 * k + 1] = rd;
+                const bool go = wf_generate_one(kt->a, kt->w, lds_cam, id, ro, rd);  // pixels outside the image leave skip markers
+                st_stream(&rq_w[2 * k], ro);
+                st_stream(&rq_w[2 * k + 1], rd);
                 pq_w[k] = go ? (unsigned)id : WF_INVALID;
             }
             __syncthreads();  // everyone has read the counts
@@ -1444,7 +1561,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
         // their loads get going earlier (measured 1-2 %)
         __builtin_amdgcn_s_setprio(3);
-        wg_traverse_phase<VINE>(a, w, stack, rq, n_rays, &ctl[1], rays);
+        wg_traverse_phase<VINE>(a, w, lds_root, stack, rq, n_rays, &ctl[1], rays);
         __builtin_amdgcn_s_setprio(0);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written
@@ -1453,7 +1570,8 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         PH_ADD(2, pt1, pt2);
 
         // ---- shade phase: the live paths; appends go to the other queue pair
-        wg_shade_phase(a, w, lds_mats, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
+        const WgwfKernArgs *ks = wgwf_kernargs();
+        wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
                        &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], rays);
         PH_STAMP(ps1);
         __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
