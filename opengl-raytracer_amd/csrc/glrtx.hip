@@ -41,7 +41,7 @@ struct glrtx_ctx {
     hipEvent_t tm0 = nullptr, tm1 = nullptr;      // glrtx_timer_*
     std::string err;
 
-    DevBuf forks, tris, nrms, mats, lights, vine, accum_own, counter, rgba8, work;
+    DevBuf forks, nrms, mats, lights, vine, accum_own, counter, rgba8, work;
     DevBuf wfState, wfQ;      // wavefront path state (7 planes of float4 x ids) + per-workgroup queues (variant 2)
     DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
     DevBuf bvhVert, bvhTri, bvhNodes;  // glrtx_build_lbvh staging
@@ -495,7 +495,7 @@ void glrtx_destroy(glrtx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    dev_free(c->forks); dev_free(c->tris); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights); dev_free(c->vine);
+    dev_free(c->forks); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights); dev_free(c->vine);
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
     dev_free(c->wfState); dev_free(c->wfQ); dev_free(c->wfSeeds); dev_free(c->wfPlanes);
     dev_free(c->bvhVert); dev_free(c->bvhTri); dev_free(c->bvhNodes);
@@ -520,16 +520,18 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     const int root_ref = P.root_ref, stack_need = P.stack_need;
 
     int rc;
-    if ((rc = dev_upload(c, c->forks, forks.data(), forks.size() * sizeof(float4)))) return rc;
-    if ((rc = dev_upload(c, c->tris, tris.data(), tris.size() * sizeof(float4)))) return rc;
+    // one node array: triangle records in reverse order, then the forks (DevScene::forks points at fork 0)
+    std::vector<float4> nodes(tris.size() + forks.size());
+    for (size_t t = 0; t < n_tri; t++) std::memcpy(&nodes[4 * (n_tri - 1 - t)], &tris[4 * t], 4 * sizeof(float4));
+    std::memcpy(nodes.data() + tris.size(), forks.data(), forks.size() * sizeof(float4));
+    if ((rc = dev_upload(c, c->forks, nodes.data(), nodes.size() * sizeof(float4)))) return rc;
     if ((rc = dev_upload(c, c->nrms, nrms.data(), nrms.size() * sizeof(float4)))) return rc;
     if ((rc = dev_upload(c, c->mats, mats.data(), mats.size() * sizeof(float4)))) return rc;
     if ((rc = dev_upload(c, c->lights, lights.data(), lights.size() * sizeof(float4)))) return rc;
     if (!P.vine.empty() && (rc = dev_upload(c, c->vine, P.vine.data(), P.vine.size() * sizeof(float4)))) return rc;
 
     DevScene &sc = c->sc;
-    sc.forks = (const float4 *)c->forks.p;
-    sc.tris = (const float4 *)c->tris.p;
+    sc.forks = (const float4 *)c->forks.p + tris.size();
     sc.nrms = (const float4 *)c->nrms.p;
     sc.mats = (const float4 *)c->mats.p;
     sc.lights = (const float4 *)c->lights.p;

@@ -21,7 +21,8 @@
 //            ref >= 0 -> fork index, ref < 0 -> ~triangle (leaf nodes are folded into their
 //            parent's ref: the reference never tests a leaf's own box, raytrace.frag:310-331),
 //            ref == REF_ABSENT -> no child.  The root's own box is in DevScene.
-//   tris   : 4 x float4 (64 B, the shape of a fork record) per triangle {v0.xyz, materialId} {v1-v0, -} {v2-v0, -} {-}
+//   tris   : 4 x float4 (64 B, the shape of a fork record) per triangle {v0.xyz, materialId} {v1-v0, -} {v2-v0, -} {-},
+//            in the same array as the forks, triangle t at record index ~t (DevScene::forks)
 //   nrms   : 3 x float4 per triangle {n0} {n1} {n2}   (read once per ray, for the closest hit only)
 //   mats   : 3 x float4 per material {emission.xyz, type} {param0.xyz, alpha.x} {param1.xyz, alpha.y}
 //   lights : 6 x float4 per light triangle {v0, materialId} {v1} {v2} {n0} {n1} {n2}
@@ -42,8 +43,9 @@ constexpr float PT_PI = 3.14159274101257324f;
 constexpr float PT_2PI = 6.28318548202514648f;  // the GLSL compiler folds 2.0*PI into one constant
 
 struct DevScene {
-    const float4 *forks;
-    const float4 *tris;
+    const float4 *forks;  // fork f at forks[4 f]; triangle t at forks[4 ~t] = forks[-4 (t + 1)]: ONE array with the triangle records
+                          // stored (in reverse) in front of fork 0, so that a ref -- fork index or ~triangle -- is itself the
+                          // signed record index and the traversal step needs no base-pointer select
     const float4 *nrms;
     const float4 *mats;
     const float4 *lights;
@@ -302,7 +304,7 @@ DEV bool trav_init(const DevScene &sc, const float4 *root, Trav &T, float ox, fl
 template <bool CLOSEST>
 DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
 #ifdef GLRTX_TRAV_STATS
-    trav_stats_iter(T.cur, T.cur >= 0 ? (const void *)(sc.forks + 4 * (size_t)T.cur) : (const void *)(sc.tris + 4 * (size_t)(~T.cur)), T.stop_d == -__builtin_inff());
+    trav_stats_iter(T.cur, (const void *)(sc.forks + 4 * (ptrdiff_t)T.cur), T.stop_d == -__builtin_inff());
     T.iters++;
 #define TS_DONE atomicAdd(&g_trav_hist[T.iters <= 1 ? 0 : (32 - __clz((int)T.iters - 1)) > 15 ? 15 : (32 - __clz((int)T.iters - 1))], 1ull)
 #else
@@ -319,11 +321,14 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
     // before the wave splits into its fork lanes and its triangle lanes: in a mixed wave (3 of 4 iterations)
     // the two arms then cost one memory round trip, not two.
     const bool is_fork = cur >= 0;
-    const float4 *N = is_fork ? sc.forks + 4 * (size_t)cur : sc.tris + 4 * (size_t)(~cur);
+    const float4 *N = sc.forks + 4 * (ptrdiff_t)cur;
     // (Left to the compiler these become dwordx3 loads plus, on the fork arm, one more dwordx3 and two dword loads of the
     // refs: 56 bytes per fork lane, 36 per triangle lane.  Forcing four dwordx4 loads issued together was measured 9 %
     // SLOWER -- the cost of a step grows with the bytes returned per lane, about 0.017 ms of frame time per byte.)
     const float4 A = N[0], B = N[1], C = N[2], D = N[3];
+    // Two separate ifs, fork arm first: its extra loads (second box, refs) must go out BEFORE the triangle arithmetic of the
+    // wave's leaf lanes.  (As one if / else the compiler may place the leaf arm first -- it did once the address select was
+    // gone -- and the fork lanes then wait a second round trip behind it: 5 % of the frame.)
     if (is_fork) {
         const int l = __float_as_int(A.w), r = __float_as_int(B.w);
         float t0l, t0r;
@@ -349,7 +354,8 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
         T.cur = pr ? r : l;
 #endif
         need_pop = !(pl || pr);
-    } else {
+    }
+    if (!is_fork) {
         // leaf :310-331 with intersect(Ray, Triangle) :226-257; A = {v0, material}, B = v1-v0, C = v2-v0
         const int t = ~cur;
         const float tx = T.ox - A.x, ty = T.oy - A.y, tz = T.oz - A.z;
@@ -366,6 +372,8 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
         const float V = dot3(T.dx, T.dy, T.dz, qx, qy, qz);
         const float v = V * inv;
         const float tt = dot3(C.x, C.y, C.z, qx, qy, qz) * inv;
+        // (&& / || on purpose: the compiler turns the later terms into a branch that a wave skips when none of its leaf lanes
+        //  is still in the running -- most tested triangles are missed; with & and | the step was 7 % slower)
         const bool hit = !(-PT_EPS < det && det < PT_EPS) && !(u < 0.0f || 1.0f < u) &&
                          !(v < 0.0f || 1.0f < inv * (U + V)) &&  // u+v>1 is evaluated as inv*(U+V)>1
                          !(PT_EPS >= tt);
@@ -579,7 +587,7 @@ DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &
         if (h.tri < 0) break;  // miss: nothing is added and the loop ends (:497-499)
 
         // normal of the closest hit (:254), computed once instead of per candidate
-        const float4 T0 = sc.tris[4 * h.tri];
+        const float4 T0 = sc.forks[4 * (ptrdiff_t)(~h.tri)];
         float nx, ny, nz;
         {
             const float4 N0 = sc.nrms[3 * h.tri], N1 = sc.nrms[3 * h.tri + 1], N2 = sc.nrms[3 * h.tri + 2];
@@ -1289,11 +1297,12 @@ __device__ uint4 g_trip_log[16][64];
 
 // Traverse phase of one trip, run by a whole workgroup: lanes pull the workgroup's queued rays and a lane whose ray
 // is finished takes the next one once refill_min lanes of its wave are idle.  Hit records go to w.H / w.HS.
-// The queue holds the rays themselves (32-byte records {origin, ray id} {direction, -}); every wave keeps TWO chunks
-// of 64 records in registers -- lane l holds record l of each -- fetched with unit stride long before they are
-// needed (64 at a time through *ray_head, an LDS counter).  A refill therefore touches no memory: the idle lane with
-// rank r takes the record held by lane (consumed + r) through a cross-lane read.  (Fetching a ray when a lane fell
-// idle -- queue index, then path state, two dependent round trips -- cost 14 % of the phase.)
+// The queue holds the rays themselves (32-byte records {origin, ray id} {direction, -}); every wave keeps one chunk of 64
+// records in registers -- lane l holds record l -- fetched with unit stride (64 at a time through *ray_head, an LDS
+// counter).  A refill therefore touches no memory: the idle lane with rank r takes the record held by lane
+// (consumed + r) through a cross-lane read.  (Fetching a ray when a lane fell idle -- queue index, then path state, two
+// dependent round trips -- cost 14 % of the phase.  A second chunk fetched ahead of need was kept in round 1; measured
+// again after the kernel lost its spills it bought nothing (profiles/r02_ab_occupancy.txt) and its 8 registers were freed.)
 template <bool VINE>
 DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned long long &rays) {
@@ -1320,8 +1329,8 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float4 none = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID));
-    float4 cur_o = none, cur_d = none, next_o = none, next_d = none;  // this lane's record of the current / next chunk
-    int cur_pos = 0, cur_cnt = 0, next_cnt = 0;                        // wave-uniform
+    float4 cur_o = none, cur_d = none;  // this lane's record of the wave's current chunk
+    int cur_pos = 0, cur_cnt = 0;       // wave-uniform
     auto fetch = [&](float4 &o, float4 &d) -> int {                    // returns the number of records in the chunk (0: queue exhausted)
         int base = 0;
         if (lane == 0) base = (int)atomicAdd(ray_head, 64u);
@@ -1334,10 +1343,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         }
         return cnt;
     };
-    // short queues (the last trips of a launch) are handed out one chunk at a time so that all four waves get some
-    const bool ahead = n_rays >= 16 * 64;
     cur_cnt = fetch(cur_o, cur_d);
-    next_cnt = (ahead && cur_cnt == 64) ? fetch(next_o, next_d) : 0;
     bool exhausted = cur_cnt == 0;
     bool active = false;
     // A finished ray's hit record is kept in registers and written when the lane is refilled
@@ -1361,14 +1367,8 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
             const unsigned long long rf0 = __builtin_amdgcn_s_memtime();
 #endif
             while (idle != 0ull && !exhausted) {
-                if (cur_pos >= cur_cnt) {  // current chunk used up: the prefetched one takes its place, the next is requested
-                    if (ahead) {
-                        cur_o = next_o; cur_d = next_d;
-                        cur_cnt = next_cnt;
-                        next_cnt = cur_cnt == 64 ? fetch(next_o, next_d) : 0;
-                    } else {
-                        cur_cnt = cur_cnt == 64 ? fetch(cur_o, cur_d) : 0;
-                    }
+                if (cur_pos >= cur_cnt) {  // chunk used up: the next one
+                    cur_cnt = cur_cnt == 64 ? fetch(cur_o, cur_d) : 0;
                     cur_pos = 0;
                     if (cur_cnt == 0) { exhausted = true; break; }
                 }

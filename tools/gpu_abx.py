@@ -1,6 +1,6 @@
 """A/B timing of several builds of libglrtx.so (and/or environment settings) on the headline workload.
 
-    python tools/gpu_abx.py [--config headline] [--frames 16] [--rounds 6] NAME=path/to/lib.so[,ENV=VAL...] ...
+    python tools/gpu_abx.py [--config headline] [--frames 16] [--rounds 6] [--repeat 1] NAME=path/to/lib.so[,ENV=VAL...] ...
 
 Each variant runs in its own child process (one libglrtx per process), sequentially: an untimed counting launch
 (ray count + image checksum), then `rounds` timed launches of `frames` frames in flight.  Prints ms/frame (median,
@@ -43,30 +43,40 @@ def main():
     a = sys.argv[1:]
     if a and a[0] == "--child":
         return child(a[1], a[2], int(a[3]), int(a[4]))
-    config, frames, rounds, variants = "headline", 16, 6, []
+    config, frames, rounds, repeat, variants = "headline", 16, 6, 1, []
     while a:
         x = a.pop(0)
         if x == "--config": config = a.pop(0)
         elif x == "--frames": frames = int(a.pop(0))
         elif x == "--rounds": rounds = int(a.pop(0))
+        elif x == "--repeat": repeat = int(a.pop(0))
         else: variants.append(x)
-    first = None
-    for v in variants:
-        name, rest = v.split("=", 1)
-        parts = rest.split(",")
-        lib = os.path.join(ROOT, parts[0])
-        env = dict(os.environ)
-        for kv in parts[1:]:
-            k, val = kv.split("=", 1); env[k] = val
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", lib, config, str(frames), str(rounds)], env=env, capture_output=True, text=True, timeout=600)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode != 0 or not line:
-            print(f"{name:28s} FAILED rc={r.returncode} {r.stderr[-400:]}", flush=True)
-            continue
-        o = json.loads(line[-1])
-        first = first or o
-        same = "same image" if o["sha1"] == first["sha1"] and o["rays"] == first["rays"] else "IMAGE/RAYS DIFFER"
-        print(f"{name:28s} {o['ms_med']:.4f} ms/frame (min {o['ms_min']:.4f})  rays {o['rays']} untraced {o['untraced']}  {same}  {o['ms_all']}", flush=True)
+    # the variants are cycled `repeat` times (A B C A B C ...): clocks drift over a session by more than the differences of interest
+    first, res = None, {}
+    for rep in range(repeat):
+        for v in variants:
+            name, rest = v.split("=", 1)
+            parts = rest.split(",")
+            lib = os.path.join(ROOT, parts[0])
+            env = dict(os.environ)
+            for kv in parts[1:]:
+                k, val = kv.split("=", 1); env[k] = val
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", lib, config, str(frames), str(rounds)], env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                print(f"{name:28s} FAILED rc={r.returncode} {r.stderr[-400:]}", flush=True)
+                continue
+            o = json.loads(line[-1])
+            first = first or o
+            same = "same image" if o["sha1"] == first["sha1"] and o["rays"] == first["rays"] else "IMAGE/RAYS DIFFER"
+            res.setdefault(name, []).append(o["ms_med"])
+            print(f"{name:28s} {o['ms_med']:.4f} ms/frame (min {o['ms_min']:.4f})  rays {o['rays']} untraced {o['untraced']}  {same}  {o['ms_all']}", flush=True)
+    if repeat > 1:
+        base = None
+        for name, v in res.items():
+            v = sorted(v); med = v[len(v) // 2]
+            base = base or med
+            print(f"== {name:25s} median of {len(v)} passes {med:.4f} ms/frame ({(med / base - 1) * 100:+.2f} % vs {list(res)[0]})  passes {[round(x, 4) for x in v]}", flush=True)
 
 
 if __name__ == "__main__":
