@@ -387,7 +387,8 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     }
 
     const int lds = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
-                    16 * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4);  // ctl | root box | camera block
+                    16 * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block
+                    (int)sizeof(ShadeSortLds);
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
     // four instantiations: ray counting on/off x generic tree traversal / list scan of a vine (brute-force) tree
     using Kernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *);
@@ -416,7 +417,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
     // (2 rays per live path: the next ray and the shadow ray) and of the path-id queue; every (frame, sample) has its plane.
     {
         const size_t max_id = (n_frames > 1 ? ((size_t)(n_frames - 1) << shift) : 0) | (total - 1);
-        const size_t slice_f4 = 2 * (size_t)2 * 2 * block_paths /* ray records */ + (2 * (size_t)block_paths * sizeof(unsigned) + 15) / 16 /* path ids */;
+        const size_t slice_f4 = 2 * (size_t)2 * 2 * block_paths /* ray records */ + (3 * (size_t)block_paths * sizeof(unsigned) + 15) / 16 /* path ids [2] + shading order */;
         bool ok = max_id < ids && 2 * max_id + 1 < (size_t)WF_INVALID && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
                   block_paths <= kWgPathsMax && slice_f4 <= kWgQueueF4 && c->wfQ.bytes >= (size_t)grid * kWgQueueF4 * sizeof(float4) &&
                   c->wfState.bytes >= kWfStatePlanes * ids * sizeof(float4) && w.ids == ids && grid >= 1 && grid <= resident &&

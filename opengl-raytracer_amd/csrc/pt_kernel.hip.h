@@ -1276,7 +1276,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 #endif
 constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes its queues); the host picks block_paths <= this so
                                    // that the launch has that many pixels for every resident workgroup
-constexpr size_t kWgQueueF4 = 8 * (size_t)kWgPathsMax + (size_t)kWgPathsMax / 2;  // float4 units per workgroup: ray records + path ids
+constexpr size_t kWgQueueF4 = 8 * (size_t)kWgPathsMax + 3 * (size_t)kWgPathsMax / 4;  // float4 units per workgroup: ray records + path ids [2] + shading order
 #ifndef GLRTX_WGWF_WAVES
 #define GLRTX_WGWF_WAVES 4
 #endif
@@ -1422,6 +1422,85 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
 // Shade phase of one trip, run by a whole workgroup: every live path (pq[0..n_paths))
 // goes through wf_shade_path(); the rays and paths of the next trip are appended to rq_next / pq_next
 // (wave-aggregated, one LDS atomic per wave and queue on *n_rays_next / *n_paths_next).
+//
+// The paths are shaded in the order of a stable 3-way partition by the KIND of work their iteration of the depth loop
+// is (GLRTX_SHADE_SORT): 0 = nearly none (the ray missed, the path only awaits its last shadow ray, a material with
+// neither BSDF branch), 1 = diffuse (:511-519), 2 = conductor (:520-532).  shade_hit() is ~1800 vector instructions
+// when a wave holds all kinds -- every lane waits through every branch -- of which a diffuse wave needs ~1000 and a
+// wave of misses ~100; left in pixel order 26 of 64 lanes were active per instruction.  A path's arithmetic does not
+// depend on its neighbours in the wave, so results are unchanged.  The partition is stable: inside each class the
+// paths stay in pixel order.
+// MEASURED AND SWITCHED OFF (profiles/r02_shade_sort.txt): bit-identical, but 9 % SLOWER per frame.  The shade phase is
+// bound by its chains of dependent loads (state, triangle, normals, light, materials), not by vector-instruction issue
+// (the co-resident traversal waves run at raised priority and the SIMDs' VALU is 39 % busy overall), so removing
+// instructions from it buys nothing, while the partition costs three more barriers per trip and turns the unit-stride
+// state loads of a wave into three (then nine, ...) runs.  Kept behind the macro for the record.
+#ifndef GLRTX_SHADE_SORT
+#define GLRTX_SHADE_SORT 0
+#endif
+constexpr int kSortChunks = kWgPathsMax / 64;  // 64-path wave chunks of a full path queue
+struct ShadeSortLds {                          // LDS scratch of the partition (1.75 KiB)
+    unsigned long long key_lo[kSortChunks], key_hi[kSortChunks];  // per wave chunk: bit l = key bit of the chunk's l-th path
+    unsigned offs[3][kSortChunks];                                // per class and wave chunk: count, then first output position
+    unsigned total;
+};
+
+// Class of path `id` (see above); WF_INVALID queue entries (pixels outside the image) get 3 = dropped.
+DEV int wf_shade_class(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, unsigned id) {
+    if (id == WF_INVALID) return 3;
+    const unsigned meta = __float_as_uint(ld_stream(w.A(2, id)).w);
+    if (meta & WF_FINISHING) return 0;
+    const int tri = __float_as_int(ld_stream(w.H(id)).y);
+    if (tri < 0) return 0;
+    const int m = __float_as_int(a.sc.forks[4 * (ptrdiff_t)(~tri)].w);
+    const int type = __float_as_int(load_mat(a.sc, lds_mats, m).m0.w);
+    return type == 2 ? 1 : (type == 3 ? 2 : 0);
+}
+
+// pq[0..n_paths) -> sorted[0..n_sorted): stable partition by class; returns n_sorted.  Called by the whole workgroup.
+DEV int wg_shade_sort(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const unsigned *pq, int n_paths, unsigned *sorted,
+                      ShadeSortLds *L) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int n_chunks = (n_paths + 63) >> 6;
+    for (int c = wave; c < n_chunks; c += kBlockThreads / 64) {  // classify
+        const int i = c * 64 + lane;
+        const int key = wf_shade_class(a, w, lds_mats, i < n_paths ? pq[i] : WF_INVALID);
+        const unsigned long long lo = __ballot(key & 1), hi = __ballot(key & 2);
+        if (lane == 0) {
+            L->key_lo[c] = lo; L->key_hi[c] = hi;
+            L->offs[0][c] = (unsigned)__popcll(~lo & ~hi); L->offs[1][c] = (unsigned)__popcll(lo & ~hi); L->offs[2][c] = (unsigned)__popcll(~lo & hi);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive prefix over (class, chunk): one 64-lane scan per class
+        unsigned base = 0;
+        for (int k = 0; k < 3; k++) {
+            const unsigned v = lane < n_chunks ? L->offs[k][lane] : 0u;
+            unsigned incl = v;
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned t = (unsigned)__shfl_up((int)incl, d);
+                if (lane >= d) incl += t;
+            }
+            if (lane < n_chunks) L->offs[k][lane] = base + incl - v;
+            base += (unsigned)__shfl((int)incl, 63);
+        }
+        if (lane == 0) L->total = base;
+    }
+    __syncthreads();
+    for (int c = wave; c < n_chunks; c += kBlockThreads / 64) {  // scatter
+        const int i = c * 64 + lane;
+        const unsigned long long lo = L->key_lo[c], hi = L->key_hi[c];
+        const int key = (int)((lo >> lane) & 1ull) | ((int)((hi >> lane) & 1ull) << 1);
+        if (key < 3) {
+            const unsigned long long mine = (key & 1 ? lo : ~lo) & (key & 2 ? hi : ~hi);
+            sorted[L->offs[key][c] + (unsigned)__popcll(mine & lt_mask)] = pq[i];
+        }
+    }
+    __syncthreads();  // `sorted` complete (same CU: its stores are visible to the workgroup's other waves)
+    return (int)L->total;
+}
+
 DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, const unsigned *pq, int n_paths,
                         float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
@@ -1433,6 +1512,9 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro, rsd = ro;
         if (i < n_paths) id = pq[i];
         if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, cam, id, push_ext, push_sh, ro, rd, rsd, rays);
+#ifdef GLRTX_PHASE_STATS
+        if (lane == 0) { atomicAdd(&g_phase_cycles[7], 1ull); }  // wave chunks shaded
+#endif
         const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
         unsigned br = 0, bp = 0;
         if (lane == 0) {
@@ -1488,12 +1570,14 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     // would occupy ~100 of the 102 SGPRs and spill into VGPR lanes inside the traversal loop)
     float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));      // {root_lo, root_hi}
     float *lds_cam = reinterpret_cast<float *>(pl + 16 * sizeof(unsigned) + 32);     // {c2w, s2c, aperture, focal}
+    ShadeSortLds *lds_sort = reinterpret_cast<ShadeSortLds *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
     if (threadIdx.x < kCamFloats) lds_cam[threadIdx.x] = a.cam[threadIdx.x];
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
     if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
     // per-workgroup slice of the queue buffer: ray records float4[2][2 * block_paths][2], then path ids unsigned[2][block_paths]
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
     unsigned *pathQ = reinterpret_cast<unsigned *>(rayQ + 8 * (size_t)w.block_paths);
+    unsigned *sortQ = pathQ + 2 * (size_t)w.block_paths;  // this trip's shading order
     if (a.sc.mats_in_lds)
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
 
@@ -1571,8 +1655,14 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 
         // ---- shade phase: the live paths; appends go to the other queue pair
         const WgwfKernArgs *ks = wgwf_kernargs();
+#if GLRTX_SHADE_SORT
+        const int n_shade = wg_shade_sort(ks->a, ks->w, lds_mats, pq, n_paths, sortQ, lds_sort);
+        wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, sortQ, n_shade, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
+                       &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], rays);
+#else
         wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
                        &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], rays);
+#endif
         PH_STAMP(ps1);
         __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
         PH_STAMP(ps2);

@@ -1,7 +1,8 @@
 import sys, ctypes as C; sys.path.insert(0,'.'); sys.path.insert(0,'opengl-raytracer_amd/python')
 import numpy as np
 from glrt_amd import scenes, device, host
-device.lib_path = lambda: device.LIB_DIR / "libglrtx_phase.so"
+import os
+device.lib_path = lambda: device.LIB_DIR / os.environ.get("GLRTX_PHASE_LIB", "libglrtx_phase.so")
 sc, pr = scenes.config_headline()
 d = device.Device(); d.upload_scene(sc); d.resize(1920, 1080)
 L = device.lib(); out = (C.c_ulonglong * 8)()
