@@ -1570,14 +1570,14 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     // would occupy ~100 of the 102 SGPRs and spill into VGPR lanes inside the traversal loop)
     float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));      // {root_lo, root_hi}
     float *lds_cam = reinterpret_cast<float *>(pl + 16 * sizeof(unsigned) + 32);     // {c2w, s2c, aperture, focal}
-    ShadeSortLds *lds_sort = reinterpret_cast<ShadeSortLds *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
+    [[maybe_unused]] ShadeSortLds *lds_sort = reinterpret_cast<ShadeSortLds *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
     if (threadIdx.x < kCamFloats) lds_cam[threadIdx.x] = a.cam[threadIdx.x];
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
     if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
     // per-workgroup slice of the queue buffer: ray records float4[2][2 * block_paths][2], then path ids unsigned[2][block_paths]
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
     unsigned *pathQ = reinterpret_cast<unsigned *>(rayQ + 8 * (size_t)w.block_paths);
-    unsigned *sortQ = pathQ + 2 * (size_t)w.block_paths;  // this trip's shading order
+    [[maybe_unused]] unsigned *sortQ = pathQ + 2 * (size_t)w.block_paths;  // this trip's shading order (GLRTX_SHADE_SORT)
     if (a.sc.mats_in_lds)
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
 
