@@ -1705,23 +1705,55 @@ __global__ __launch_bounds__(256) void accumulate_planes_kernel(float4 *accum, i
 }
 
 // ------------------------------------------------------------------------------------------ resolve
-// screen.frag:15-25 (rgb/count, clamp, pow 1/gamma) + saveCurrentFrame's RGBA8 read-back with
-// optional vertical flip (window.cpp:383-414).  Bandwidth-bound: 16 B in, 4 B out per pixel.
+// screen.frag:15-25 (rgb / count, clamp, pow(., 1 / u_gamma)) + the RGBA8 colour buffer it is drawn into and
+// saveCurrentFrame's glReadPixels read-back with optional vertical flip (window.cpp:297-317, :383-414).
+// Byte-exact with the reference's GL implementation (fixtures tests/golden/screen_*.npz, oracle/pt_oracle.c rs_*):
+// pow(x, y) = exp2(log2(x) * y) with that implementation's minimax polynomials and fused multiply-adds, IEEE divisions,
+// x86 min/max operand order (a NaN quotient clamps to 0), round-to-nearest-even float -> unorm8.  The accumulator texel is
+// read exactly (the reference's GL_LINEAR sampler is exact at power-of-two sizes).
+// Bandwidth-bound: 16 B in, 4 B out per pixel.
+DEV float rs_log2(float x) {
+    const uint32_t i = __float_as_uint(x);
+    const float ef = (float)((int)((i & 0x7f800000u) >> 23) - 127);
+    const float m = __uint_as_float((i & 0x007fffffu) | 0x3f800000u);
+    const float t = (m - 1.0f) / (m + 1.0f);
+    const float z = t * t, z2 = z * z;
+    const float a = __builtin_fmaf(z2, 0x1.a07ab2p-2f, 0x1.27a642p-1f);
+    const float b = __builtin_fmaf(z2, 0x1.9d062cp-2f, 0x1.ec6ff2p-1f);
+    const float c = __builtin_fmaf(z2, a, 0x1.715476p+1f);
+    const float d = __builtin_fmaf(b, z, c);
+    return __builtin_fmaf(t, d, ef);  // x in (0, 1] here: the inf / 0 / negative selects of the general routine cannot trigger
+}
+DEV float rs_exp2(float t) {
+    t = (128.0f < t) ? 128.0f : t;
+    t = (-0x1.fbfffep+6f > t) ? -0x1.fbfffep+6f : t;
+    const float fl = __builtin_floorf(t);
+    const float f = t - fl;
+    const float scale = __uint_as_float((uint32_t)((int)fl + 127) << 23);
+    const float z = f * f;
+    const float a = __builtin_fmaf(z, 0x1.ec320ap-10f, 0x1.c95446p-5f);
+    const float b = __builtin_fmaf(z, 0x1.26900cp-7f, 0x1.ebd5a8p-3f);
+    const float c = __builtin_fmaf(z, a, 0x1.62e4f6p-1f);
+    const float d = __builtin_fmaf(z, b, 1.0f);
+    return scale * __builtin_fmaf(c, f, d);
+}
+DEV unsigned char rs_channel(float v, float count, float inv_gamma) {
+    float L = v / count;
+    L = (L > 0.0f) ? L : 0.0f;  // maxps(L, 0): 0 when L is NaN
+    L = (L < 1.0f) ? L : 1.0f;  // minps(L, 1)
+    float r = (L == 0.0f) ? 0.0f : rs_exp2(rs_log2(L) * inv_gamma);
+    r = (1.0f < r) ? 1.0f : r;
+    const int q = (int)__builtin_rintf(r * 255.0f);  // cvtps2dq: round to nearest even
+    return (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
+}
 __global__ __launch_bounds__(256) void resolve_kernel(const float4 *accum, int pitch_f4, int width, int rows,
                                                       uchar4 *out, int out_pitch_px, float inv_gamma, int flip) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= width || y >= rows) return;
     const float4 v = accum[(size_t)y * pitch_f4 + x];
-    float r = v.x / v.w, g = v.y / v.w, b = v.z / v.w;
-    r = __builtin_powf(__builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f), inv_gamma);
-    g = __builtin_powf(__builtin_fminf(__builtin_fmaxf(g, 0.f), 1.f), inv_gamma);
-    b = __builtin_powf(__builtin_fminf(__builtin_fmaxf(b, 0.f), 1.f), inv_gamma);
     const int oy = flip ? rows - 1 - y : y;
-    // GL float -> unorm8 conversion: round(f * 255)
-    out[(size_t)oy * out_pitch_px + x] =
-        make_uchar4((unsigned char)(r * 255.0f + 0.5f), (unsigned char)(g * 255.0f + 0.5f),
-                    (unsigned char)(b * 255.0f + 0.5f), 255);
+    out[(size_t)oy * out_pitch_px + x] = make_uchar4(rs_channel(v.x, v.w, inv_gamma), rs_channel(v.y, v.w, inv_gamma), rs_channel(v.z, v.w, inv_gamma), 255);
 }
 
 }  // namespace glrtx

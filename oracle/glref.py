@@ -75,6 +75,9 @@ class GLRef:
         L.glref_fbo.argtypes = [C.c_int, C.POINTER(C.c_uint)]
         L.glref_fbo_free.argtypes = [C.c_uint]
         L.glref_draw.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_int]
+        L.glref_tex2d_rgba8.restype = C.c_uint
+        L.glref_tex2d_rgba8.argtypes = [C.c_int, C.c_int]
+        L.glref_read_pixels_rgba8.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_void_p]
         self.L = L
         if L.glref_init() != 0:
             raise RuntimeError("glref_init: " + L.glref_last_error().decode())
@@ -227,3 +230,42 @@ class GLRef:
         for hdl in handles:
             L.glref_tbo_free(hdl[0], hdl[1])
         return rgb, cnt
+
+    # ------------------------------------------------- the reference's resolve pass
+    def render_screen(self, rgb, count, gamma=None):
+        """Run the reference's screen.{vert,frag} verbatim (src/shaders/screen.frag:15-25) the way Window::render drives it
+        (window.cpp:297-317): u_framebuffer / u_counter = the accumulation targets (RGB32F + R32F, GL_LINEAR samplers as
+        framebuffer_object.cpp creates them) on units 0 / 1, u_windowSize, one glDrawArrays(GL_TRIANGLES, 0, 6) into an RGBA8
+        colour buffer, then saveCurrentFrame's glReadPixels(GL_RGBA, GL_UNSIGNED_BYTE) (window.cpp:383-388).
+        gamma None leaves u_gamma at the shader's default (2.2), as the reference host does.
+        Returns uint8 (h, w, 4), row 0 = bottom row (GL origin; the reference flips it before writing the PNG)."""
+        L = self.L
+        vs = (REFERENCE_SHADERS / "screen.vert").read_text()
+        fs = (REFERENCE_SHADERS / "screen.frag").read_text()
+        p = self.program(vs, fs)
+        L.glref_use(p)
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        count = np.ascontiguousarray(count, np.float32)
+        h, w = count.shape
+        t_rgb = L.glref_tex2d(w, h, 3, rgb.ctypes.data)
+        t_cnt = L.glref_tex2d(w, h, 1, count.ctypes.data)
+        L.glref_bind_tex2d(0, t_rgb)
+        L.glref_uniform1i(p, b"u_framebuffer", 0)
+        L.glref_bind_tex2d(1, t_cnt)
+        L.glref_uniform1i(p, b"u_counter", 1)
+        L.glref_uniform2f(p, b"u_windowSize", float(w), float(h))
+        # (program objects are cached here and keep their uniform values: always set it; 2.2 is the shader's initialiser)
+        L.glref_uniform1f(p, b"u_gamma", 2.2 if gamma is None else float(gamma))
+        target = L.glref_tex2d_rgba8(w, h)
+        fbo = L.glref_fbo(1, (C.c_uint * 1)(target))
+        if not fbo:
+            raise RuntimeError(self.err())
+        if L.glref_draw(fbo, w, h, 1) != 0:
+            raise RuntimeError(self.err())
+        out = np.empty((h, w, 4), np.uint8)
+        if L.glref_read_pixels_rgba8(fbo, w, h, out.ctypes.data) != 0:
+            raise RuntimeError(self.err())
+        L.glref_fbo_free(fbo)
+        for t_ in (t_rgb, t_cnt, target):
+            L.glref_tex_free(t_)
+        return out

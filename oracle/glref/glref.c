@@ -92,6 +92,8 @@ GLF(void, glDrawArrays, GLenum, GLint, GLsizei);
 GLF(void, glFinish, void);
 GLF(void, glPixelStorei, GLenum, GLint);
 GLF(void, glDisable, GLenum);
+GLF(void, glReadPixels, GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, void *);
+GLF(void, glReadBuffer, GLenum);
 
 static int load_gl(void) {
 #define L(name)                                                  \
@@ -111,7 +113,7 @@ static int load_gl(void) {
     L(glBufferData); L(glTexBuffer); L(glGenFramebuffers); L(glDeleteFramebuffers); L(glBindFramebuffer);
     L(glFramebufferTexture2D); L(glCheckFramebufferStatus); L(glDrawBuffers); L(glViewport);
     L(glClearColor); L(glClear); L(glGenVertexArrays); L(glBindVertexArray); L(glDrawArrays);
-    L(glFinish); L(glPixelStorei); L(glDisable);
+    L(glFinish); L(glPixelStorei); L(glDisable); L(glReadPixels); L(glReadBuffer);
 #undef L
     return 0;
 }
@@ -293,6 +295,30 @@ void glref_bind_tex2d(int unit, unsigned tex) {
     p_glActiveTexture(GL_TEXTURE0 + unit); p_glBindTexture(GL_TEXTURE_2D, tex);
 }
 /* comps selects the read-back format (GL_RED / GL_RGB / GL_RGBA), GL_FLOAT. */
+/* RGBA8 (unorm) colour target: what the reference's screen pass renders into -- the window's default framebuffer
+ * (window.cpp:297-317) -- and what saveCurrentFrame reads back with glReadPixels(GL_RGBA, GL_UNSIGNED_BYTE) (:383-388). */
+unsigned glref_tex2d_rgba8(int w, int h) {
+    GLuint tex;
+    p_glGenTextures(1, &tex);
+    p_glActiveTexture(GL_TEXTURE0 + SCRATCH_UNIT);
+    p_glBindTexture(GL_TEXTURE_2D, tex);
+    p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA8, w, h, 0, GL_RGBA, GL_UNSIGNED_BYTE, NULL);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+    p_glBindTexture(GL_TEXTURE_2D, 0);
+    return tex;
+}
+/* glReadPixels(0, 0, w, h, GL_RGBA, GL_UNSIGNED_BYTE) of colour attachment 0 of `fbo` (row 0 = bottom row). */
+int glref_read_pixels_rgba8(unsigned fbo, int w, int h, unsigned char *out) {
+    p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+    p_glReadBuffer(GL_COLOR_ATTACHMENT0);
+    p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
+    p_glReadPixels(0, 0, w, h, GL_RGBA, GL_UNSIGNED_BYTE, out);
+    p_glBindFramebuffer(GL_FRAMEBUFFER, 0);
+    GLenum e = p_glGetError();
+    if (e != GL_NO_ERROR) { snprintf(g_err, sizeof g_err, "GL error 0x%x after glReadPixels", e); return -1; }
+    return 0;
+}
 void glref_read_tex2d(unsigned tex, int comps, float *out) {
     GLenum fmt = comps == 1 ? GL_RED : comps == 3 ? GL_RGB : GL_RGBA;
     p_glActiveTexture(GL_TEXTURE0 + SCRATCH_UNIT);

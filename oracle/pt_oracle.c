@@ -794,6 +794,79 @@ void pt_oracle_sincos(const float *x, int n, float *s, float *c) {
     for (int i = 0; i < n; i++) { s[i] = pt_sin(x[i]); c[i] = pt_cos(x[i]); }
 }
 
+/* ------------------------------------------------------------------ resolve pass
+ * screen.frag:15-25 -- L = rgb / count; L = pow(clamp(L, 0, 1), 1 / u_gamma); out = (L, 1) -- rendered into an RGBA8 colour
+ * buffer (window.cpp:297-317) and read back with glReadPixels(GL_RGBA, GL_UNSIGNED_BYTE) (window.cpp:383-388).
+ * Restated as llvmpipe (Mesa 23.2.1, LLVM 15) evaluates it, from its compiler's debug output for the reference's
+ * unmodified shader and pinned by tests/golden/screen_*.npz:
+ *   - rgb / count and 1 / u_gamma are IEEE divisions; clamp = min(max(x, 0), 1) with x86 maxps/minps operand order
+ *     (a NaN quotient clamps to 0);
+ *   - pow(x, y) = exp2(log2(x) * y), 0 for x == 0;
+ *     log2: e = exponent, m = mantissa in [1, 2), t = (m - 1) / (m + 1), z = t * t, minimax polynomial in z evaluated with
+ *           FUSED multiply-adds in the grouping below, result = fma(t, P, e);
+ *     exp2: argument clamped to [-126.99999, 128], split by floor, minimax polynomial in the fraction with fused
+ *           multiply-adds, scaled by 2^floor through the exponent bits;
+ *   - float -> unorm8: min(v, 1) * 255, cvtps2dq (round to nearest even), saturating packs; alpha = 255.
+ * The reference samples the accumulators through GL_LINEAR samplers at gl_FragCoord / u_windowSize: exactly the texel at
+ * power-of-two sizes; at other sizes a neighbour leaks in at the 1e-7 level, which this restatement and
+ * the device kernel do not reproduce (fixture screen_npot_* records how many bytes that moves). */
+INL float rs_log2(float x) {
+    uint32_t i; memcpy(&i, &x, 4);
+    const float ef = (float)((int)((i & 0x7f800000u) >> 23) - 127);
+    const uint32_t mi = (i & 0x007fffffu) | 0x3f800000u;
+    float m; memcpy(&m, &mi, 4);
+    const float t = (m - 1.0f) / (m + 1.0f);
+    const float z = t * t, z2 = z * z;
+    const float a = fmaf(z2, 0x1.a07ab2p-2f, 0x1.27a642p-1f);
+    const float b = fmaf(z2, 0x1.9d062cp-2f, 0x1.ec6ff2p-1f);
+    const float c = fmaf(z2, a, 0x1.715476p+1f);
+    const float d = fmaf(b, z, c);
+    float r = fmaf(t, d, ef);
+    if (!(x < INFINITY)) r = INFINITY;       /* fcmp uge x, inf (true for NaN) */
+    if (!(x < 0.0f) && !(x > 0.0f)) r = -INFINITY; /* fcmp ueq x, 0 */
+    if (!(x >= 0.0f)) r = NAN;               /* fcmp ult x, 0 */
+    return r;
+}
+INL float rs_exp2(float t) {
+    t = (128.0f < t) ? 128.0f : t;                         /* minps(128, t) */
+    t = (-0x1.fbfffep+6f > t) ? -0x1.fbfffep+6f : t;     /* maxps(-126.99999, t) */
+    const float fl = floorf(t);
+    const float f = t - fl;
+    const uint32_t ei = (uint32_t)((int)fl + 127) << 23;
+    float scale; memcpy(&scale, &ei, 4);
+    const float z = f * f;
+    const float a = fmaf(z, 0x1.ec320ap-10f, 0x1.c95446p-5f);
+    const float b = fmaf(z, 0x1.26900cp-7f, 0x1.ebd5a8p-3f);
+    const float c = fmaf(z, a, 0x1.62e4f6p-1f);
+    const float d = fmaf(z, b, 1.0f);
+    return scale * fmaf(c, f, d);
+}
+INL unsigned char rs_channel(float v, float count, float inv_gamma) {
+    float L = v / count;
+    L = (L > 0.0f) ? L : 0.0f;  /* maxps(L, 0): 0 when L is NaN */
+    L = (L < 1.0f) ? L : 1.0f;  /* minps(L, 1) */
+    float r = (!(L < 0.0f) && !(L > 0.0f)) ? 0.0f : rs_exp2(rs_log2(L) * inv_gamma);
+    r = (1.0f < r) ? 1.0f : r;  /* minps(1, r) */
+    long q = lrintf(r * 255.0f); /* cvtps2dq under the default rounding mode */
+    return (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
+}
+
+__attribute__((target_clones("default", "fma")))
+void pt_oracle_resolve(const float *accum, size_t pitch_bytes, int width, int height, float gamma, int flip_y, unsigned char *out,
+                       size_t out_pitch_bytes) {
+    const float inv_gamma = 1.0f / gamma;
+    for (int y = 0; y < height; y++) {
+        const float *row = (const float *)((const char *)accum + (size_t)y * pitch_bytes);
+        unsigned char *o = out + (size_t)(flip_y ? height - 1 - y : y) * out_pitch_bytes;
+        for (int x = 0; x < width; x++) {
+            o[4 * x + 0] = rs_channel(row[4 * x + 0], row[4 * x + 3], inv_gamma);
+            o[4 * x + 1] = rs_channel(row[4 * x + 1], row[4 * x + 3], inv_gamma);
+            o[4 * x + 2] = rs_channel(row[4 * x + 2], row[4 * x + 3], inv_gamma);
+            o[4 * x + 3] = 255;
+        }
+    }
+}
+
 #ifdef PT_ORDERED_EXPERIMENT
 void pt_oracle_exp_stats(unsigned long long *out) { for (int i = 0; i < 16; i++) out[i] = g_exp[i]; }
 #endif

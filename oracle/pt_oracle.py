@@ -50,6 +50,8 @@ def lib():
                                             C.c_void_p]
         L.pt_oracle_sincos.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pt_oracle_max_threads.restype = C.c_int
+        L.pt_oracle_resolve.restype = None
+        L.pt_oracle_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -94,6 +96,16 @@ def sincos(x):
     c = np.zeros_like(x)
     lib().pt_oracle_sincos(x.ctypes.data, x.size, s.ctypes.data, c.ctypes.data)
     return s, c
+
+
+def resolve(accum, gamma=2.2, flip_y=False):
+    """The reference's resolve pass (screen.frag:15-25 + the RGBA8 read-back of window.cpp:383-388) on an (H, W, 4) float32
+    accumulator [L.rgb, count]: returns uint8 (H, W, 4).  flip_y: row 0 of the result is the top image row (saveCurrentFrame)."""
+    a = np.ascontiguousarray(accum, np.float32)
+    h, w = a.shape[:2]
+    out = np.zeros((h, w, 4), np.uint8)
+    lib().pt_oracle_resolve(a.ctypes.data, w * 16, w, h, gamma, int(flip_y), out.ctypes.data, w * 4)
+    return out
 
 
 def max_threads() -> int:

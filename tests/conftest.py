@@ -30,7 +30,23 @@ _ensure_built()
 
 
 def golden_names():
-    return sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith("math_"))
+    return sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith(("math_", "screen_")))
+
+
+def screen_cases():
+    """Resolve-pass fixtures (tests/golden/make_golden_screen.py): (name, accum (H, W, 4) float32, gamma, expected bytes (H, W, 4))."""
+    out = []
+    z = np.load(GOLDEN / "screen_sweep.npz")
+    n = 1024
+    x = np.linspace(0, 1, n * n * 3, dtype=np.float64).astype(np.float32).reshape(n, n, 3)
+    out.append(("sweep_count1", np.concatenate([x, np.ones((n, n, 1), np.float32)], -1), 2.2, z["out1"]))
+    out.append(("sweep_count3", np.concatenate([(x * np.float32(3.0)).astype(np.float32), np.full((n, n, 1), 3.0, np.float32)], -1), 2.2, z["out3"]))
+    for name in ("screen_random", "screen_render"):
+        z = np.load(GOLDEN / f"{name}.npz")
+        acc = np.concatenate([z["rgb"], z["count"][..., None]], -1).astype(np.float32)
+        for gm, o in zip(z["gammas"], z["out"]):
+            out.append((f"{name[7:]}_gamma{float(gm):.1f}", acc, float(gm), o))
+    return out
 
 
 def load_golden(name):

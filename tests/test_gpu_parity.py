@@ -6,7 +6,7 @@ Bar: bit-exact float32 (stricter than north_star's 1e-4; the tolerance is assert
 import numpy as np
 import pytest
 
-from conftest import assert_bit_equal, golden_names, load_golden
+from conftest import screen_cases, assert_bit_equal, golden_names, load_golden
 from glrt_amd import device, dist, host, scenes
 
 pytestmark = pytest.mark.gpu
@@ -124,17 +124,36 @@ def test_4k_16spp_one_pass_equals_16_counts(gpu_device):
     assert np.isfinite(acc).all() and acc[..., :3].max() <= 200.0
 
 
-def test_resolve_rgba8_matches_numpy(gpu_device):
+def test_resolve_rgba8_byte_exact_on_a_render(gpu_device):
+    from oracle import pt_oracle
+    """glrtx_resolve_rgba8 on a rendered image == the oracle's restatement of screen.frag + the RGBA8 read-back, byte for byte."""
     d = gpu_device
     scene, params = scenes.config_c1(256, 128, max_depth=4, n_samples=4)
     acc, _ = gpu_render(d, scene, params)
     img = d.resolve_rgba8(gamma=2.2, flip_y=True)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        ref = np.clip(acc[..., :3] / acc[..., 3:4], 0.0, 1.0) ** np.float32(1.0 / 2.2)
-    ref8 = np.floor(ref * 255.0 + 0.5).astype(np.int32)[::-1]
     assert img.shape == (128, 256, 4) and np.all(img[..., 3] == 255)
-    assert np.abs(img[..., :3].astype(np.int32) - ref8).max() <= 1  # pow() implementations differ by ulps
+    assert np.array_equal(img, pt_oracle.resolve(acc, 2.2, flip_y=True))
     assert np.array_equal(d.resolve_rgba8(gamma=2.2, flip_y=False), img[::-1])
+
+
+@pytest.mark.parametrize("case", screen_cases(), ids=lambda c: c[0])
+def test_resolve_rgba8_reproduces_reference_bytes(gpu_device, case):
+    """The HIP resolve kernel against the bytes the reference's own screen.frag produced on llvmpipe (tests/golden/screen_*.npz):
+    every byte boundary of pow(x, 1/2.2) (sweep), random radiances / counts / gammas with NaN, zero-count and denormal texels, and a
+    rendered image.  The accumulator contents are fed through a bound torch tensor."""
+    import torch
+    name, acc, gamma, want = case
+    d = gpu_device
+    h, w = acc.shape[:2]
+    d.resize(w, h)
+    t = torch.from_numpy(np.ascontiguousarray(acc)).cuda()
+    d.bind_accum(t.data_ptr(), w * 16, h)
+    try:
+        got = d.resolve_rgba8(gamma=gamma, flip_y=False)
+        assert np.array_equal(got, want), f"{name}: {int((got != want).sum())} bytes differ"
+        assert np.array_equal(d.resolve_rgba8(gamma=gamma, flip_y=True), want[::-1])
+    finally:
+        d.bind_accum(0, 0, 0)
 
 
 def test_bound_torch_accumulator_and_stream(gpu_device):

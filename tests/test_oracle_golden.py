@@ -59,3 +59,26 @@ def test_f6_parallel_receiver_dark_perpendicular_lit():
     wall = lum[20:42, 8:56]    # middle rows: back wall
     assert (floor > 0).mean() < 0.05
     assert (wall > 0).mean() > 0.5
+
+
+# ---------------------------------------------------------------- resolve pass (screen.frag + RGBA8 read-back)
+from conftest import GOLDEN, screen_cases  # noqa: E402
+
+
+@pytest.mark.parametrize("case", screen_cases(), ids=lambda c: c[0])
+def test_resolve_restatement_reproduces_reference_bytes(case):
+    """oracle/pt_oracle.c rs_* == the reference's screen.frag drawn into RGBA8 on llvmpipe, byte for byte (power-of-two sizes)."""
+    _, acc, gamma, want = case
+    got = pt_oracle.resolve(acc, gamma)
+    assert got.shape == want.shape and np.array_equal(got, want), f"{int((got != want).sum())} bytes differ"
+    assert np.array_equal(pt_oracle.resolve(acc, gamma, flip_y=True), want[::-1])  # saveCurrentFrame's vertical flip (window.cpp:391-398)
+
+
+def test_resolve_npot_fixture_documents_the_sampler_leak():
+    """At a non-power-of-two size the reference's GL_LINEAR samplers let a neighbour texel leak in; on white noise --
+    the worst case -- that moves the recorded number of bytes by a few LSB.  The exact-texel restatement must differ by exactly that."""
+    z = np.load(GOLDEN / "screen_npot_50x38.npz")
+    acc = np.concatenate([z["rgb"], z["count"][..., None]], -1).astype(np.float32)
+    got = pt_oracle.resolve(acc, 2.2)
+    d = np.abs(got.astype(int) - z["out"][0].astype(int))
+    assert int((d != 0).sum()) == int(z["exact_texel_mismatching_bytes"]) and int((d != 0).sum()) <= 8 and d.max() <= 8

@@ -56,3 +56,19 @@ def test_oracle_bit_exact_vs_live_reference_on_adversarial_scenes(gl, case):
     acc, _ = pt_oracle.render(sc, pr)
     assert_bit_equal(acc[..., :3], rgb, "rgb")
     assert_bit_equal(acc[..., 3], cnt, "count")
+
+
+def test_resolve_restatement_vs_live_screen_shader(gl):
+    """The reference's screen.frag drawn into RGBA8 and read back, live, against the oracle's resolve on fresh random accumulators
+    (power-of-two size, several gammas) and on a rendered image."""
+    rng = np.random.default_rng(99)
+    for h, w in ((128, 256), (32, 32)):
+        rgb = (rng.random((h, w, 3), dtype=np.float32) ** 2 * 60).astype(np.float32)
+        cnt = rng.integers(1, 65, (h, w)).astype(np.float32)
+        for gamma in (2.2, 1.8, 1.0, 3.0):
+            ref = gl.render_screen(rgb, cnt, gamma)
+            got = pt_oracle.resolve(np.concatenate([rgb, cnt[..., None]], -1), gamma)
+            assert np.array_equal(got, ref), f"{h}x{w} gamma {gamma}: {int((got != ref).sum())} bytes differ"
+    sc, pr = scenes.config_c2(64, 32, max_depth=4, n_samples=8, subdiv=1)
+    acc, _ = pt_oracle.render(sc, pr)
+    assert np.array_equal(pt_oracle.resolve(acc, 2.2), gl.render_screen(acc[..., :3].copy(), acc[..., 3].copy()))
