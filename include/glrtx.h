@@ -55,7 +55,7 @@ extern "C" {
 #define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
 #define GLRTX_ENOMEM (-5)
 
-#define GLRTX_ABI_VERSION 4
+#define GLRTX_ABI_VERSION 5
 
 typedef struct glrtx_ctx glrtx_ctx;
 
@@ -172,6 +172,32 @@ int glrtx_reset_stats(glrtx_ctx *ctx);
 /* HIP-event stopwatch on the stream launches go to: begin, N x render, end -> elapsed device ms. */
 int glrtx_timer_begin(glrtx_ctx *ctx);
 int glrtx_timer_end(glrtx_ctx *ctx, float *elapsed_ms_out);
+
+/* ---- Groups: the same device layer on several GPUs of one node, behind one handle and one host thread.
+ * No reference counterpart (the reference is single-GPU); SURVEY.md 8(b) sketches glrtx_create(ctx**, device_ids, n) with a
+ * gathering read_accum -- this is that, kept apart from the single-context calls.  Member i owns the 16-row stripes s with
+ * s % n == i (global pixel coordinates, resident accumulator rows, its own stream); rendering exchanges nothing; read_accum
+ * and resolve_rgba8 first copy the stripes device-to-device into a full frame on member 0's GPU (xGMI peer copies), i.e. they
+ * return the FULL image.  device_ids may name the same GPU more than once (partition emulation, used by the tests).
+ * glrtx_group_ctx borrows a member for the per-context knobs (glrtx_set_variant, glrtx_count_rays, glrtx_get_stats);
+ * do not resize, partition or destroy a member directly.  glrtx_group_get_stats sums rays / paths / rows and takes the
+ * maximum of the kernel times (the members run concurrently). */
+typedef struct glrtx_group glrtx_group;
+int glrtx_group_create(glrtx_group **out, const int *device_ids, int n_devices);
+void glrtx_group_destroy(glrtx_group *grp);
+const char *glrtx_group_last_error(const glrtx_group *grp);
+int glrtx_group_size(const glrtx_group *grp);
+glrtx_ctx *glrtx_group_ctx(glrtx_group *grp, int i);
+int glrtx_group_upload_scene(glrtx_group *grp, const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat,
+                             size_t n_mat, const float *light, size_t n_light, const float *bvh, size_t n_nodes);
+int glrtx_group_resize(glrtx_group *grp, int width, int height);
+int glrtx_group_clear(glrtx_group *grp);
+int glrtx_group_render(glrtx_group *grp, const glrtx_params *params);
+int glrtx_group_render_frames(glrtx_group *grp, const glrtx_params *params, const float *seeds_xy, int n_frames);
+int glrtx_group_sync(glrtx_group *grp);
+int glrtx_group_read_accum(glrtx_group *grp, float *dst_rgba, size_t dst_pitch_bytes);
+int glrtx_group_resolve_rgba8(glrtx_group *grp, uint8_t *dst, size_t dst_pitch_bytes, float gamma, int flip_y);
+int glrtx_group_get_stats(const glrtx_group *grp, glrtx_stats *out);
 
 #ifdef __cplusplus
 }

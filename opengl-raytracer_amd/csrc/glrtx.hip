@@ -937,4 +937,215 @@ int glrtx_timer_end(glrtx_ctx *c, float *ms) {
     return GLRTX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- groups
+// Several contexts -- one per GPU of the node -- behind one handle, driven by one host thread: the multi-GPU form of the
+// same entry points.  Context i owns the 16-row stripes s with s % n == i (glrtx_set_partition), renders
+// them on its own stream with global pixel coordinates, and keeps its accumulator rows resident.  Nothing is exchanged while
+// rendering.  Only when an image is wanted (read_accum / resolve) are the stripes copied, device to device, into a full-frame
+// buffer on the first context's GPU (peer copies over xGMI; hipMemcpyPeerAsync also serves the same-device case the tests use).
+}  // extern "C"
+
+struct glrtx_group {
+    std::vector<glrtx_ctx *> ctx;
+    std::vector<hipEvent_t> done;  // per context: "its render stream has reached this point"
+    DevBuf full, full8;            // on ctx[0]'s device: gathered accumulator (pitch = ctx[0]'s), resolved RGBA8
+    int width = 0, height = 0;
+    std::string err;
+};
+
+namespace {
+
+int gfail(glrtx_group *g, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g) g->err = buf; else g_create_error = buf;
+    return code;
+}
+// forward a member context's failure
+int gsub(glrtx_group *g, int i, int rc) {
+    if (rc != GLRTX_OK) g->err = "context " + std::to_string(i) + " (device " + std::to_string(g->ctx[i]->device) + "): " + g->ctx[i]->err;
+    return rc;
+}
+#define GHIP_TRY(g, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) return gfail(g, GLRTX_EDEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// All stripes -> g->full on ctx[0]'s device, ordered behind every context's outstanding work; leaves the copies on ctx[0]'s stream.
+int group_gather(glrtx_group *g) {
+    glrtx_ctx *r = g->ctx[0];
+    if (g->width < 1) return gfail(g, GLRTX_EINVAL, "glrtx_group: call glrtx_group_resize first");
+    const size_t pitch = r->pitch_bytes;
+    GHIP_TRY(g, hipSetDevice(r->device));
+    if (g->full.bytes < pitch * (size_t)g->height) {
+        dev_free(g->full);
+        GHIP_TRY(g, hipMalloc(&g->full.p, pitch * (size_t)g->height));
+        g->full.bytes = pitch * (size_t)g->height;
+    }
+    const int n = (int)g->ctx.size();
+    for (int i = 0; i < n; i++) {
+        glrtx_ctx *c = g->ctx[i];
+        if (c->pitch_bytes != pitch) return gfail(g, GLRTX_EINVAL, "glrtx_group: member accumulators have different pitches");
+        GHIP_TRY(g, hipSetDevice(c->device));
+        GHIP_TRY(g, hipEventRecord(g->done[i], c->stream));
+        GHIP_TRY(g, hipSetDevice(r->device));
+        GHIP_TRY(g, hipStreamWaitEvent(r->stream, g->done[i], 0));
+        for (int row = 0; row < c->owned_rows; row += c->stripe) {  // one contiguous block per stripe
+            const int rows = std::min(c->stripe, c->owned_rows - row);
+            const int y = ((row / c->stripe) * c->world + c->rank) * c->stripe;
+            GHIP_TRY(g, hipMemcpyPeerAsync((char *)g->full.p + (size_t)y * pitch, r->device, (const char *)c->accum + (size_t)row * pitch, c->device,
+                                           (size_t)rows * pitch, r->stream));
+        }
+    }
+    return GLRTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int glrtx_group_create(glrtx_group **out, const int *device_ids, int n_devices) {
+    if (!out) return gfail(nullptr, GLRTX_EINVAL, "glrtx_group_create: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) return gfail(nullptr, GLRTX_EINVAL, "glrtx_group_create: need 1..64 device ids");
+    glrtx_group *g = new (std::nothrow) glrtx_group;
+    if (!g) return gfail(nullptr, GLRTX_ENOMEM, "out of host memory");
+    for (int i = 0; i < n_devices; i++) {
+        glrtx_ctx *c = nullptr;
+        const int rc = glrtx_create(&c, device_ids[i]);
+        if (rc != GLRTX_OK) { glrtx_group_destroy(g); return rc; }  // message already in the create-error slot
+        g->ctx.push_back(c);
+        hipEvent_t ev = nullptr;
+        if (hipSetDevice(c->device) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            glrtx_group_destroy(g);
+            return gfail(nullptr, GLRTX_EDEVICE, "glrtx_group_create: event creation failed on device %d", device_ids[i]);
+        }
+        g->done.push_back(ev);
+    }
+    // direct peer access from the gathering device where the platform offers it (the copies work, staged, without it)
+    for (int i = 1; i < n_devices; i++) {
+        int can = 0;
+        if (g->ctx[i]->device != g->ctx[0]->device && hipDeviceCanAccessPeer(&can, g->ctx[0]->device, g->ctx[i]->device) == hipSuccess && can) {
+            (void)hipSetDevice(g->ctx[0]->device);
+            (void)hipDeviceEnablePeerAccess(g->ctx[i]->device, 0);
+            (void)hipGetLastError();  // "already enabled" is fine
+        }
+    }
+    *out = g;
+    return GLRTX_OK;
+}
+
+void glrtx_group_destroy(glrtx_group *g) {
+    if (!g) return;
+    for (size_t i = 0; i < g->done.size(); i++) { (void)hipSetDevice(g->ctx[i]->device); (void)hipEventDestroy(g->done[i]); }
+    if (!g->ctx.empty()) { (void)hipSetDevice(g->ctx[0]->device); (void)hipStreamSynchronize(g->ctx[0]->stream); dev_free(g->full); dev_free(g->full8); }
+    for (glrtx_ctx *c : g->ctx) glrtx_destroy(c);
+    delete g;
+}
+
+const char *glrtx_group_last_error(const glrtx_group *g) { return g ? g->err.c_str() : g_create_error.c_str(); }
+int glrtx_group_size(const glrtx_group *g) { return g ? (int)g->ctx.size() : 0; }
+glrtx_ctx *glrtx_group_ctx(glrtx_group *g, int i) { return (g && i >= 0 && i < (int)g->ctx.size()) ? g->ctx[i] : nullptr; }
+
+int glrtx_group_upload_scene(glrtx_group *g, const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat, size_t n_mat,
+                             const float *light, size_t n_light, const float *bvh, size_t n_nodes) {
+    if (!g) return GLRTX_EINVAL;
+    for (size_t i = 0; i < g->ctx.size(); i++)  // the scene is replicated: <= 27 MB even for 100k triangles
+        if (int rc = gsub(g, (int)i, glrtx_upload_scene(g->ctx[i], vert, n_vert, tri, n_tri, mat, n_mat, light, n_light, bvh, n_nodes))) return rc;
+    return GLRTX_OK;
+}
+
+int glrtx_group_resize(glrtx_group *g, int width, int height) {
+    if (!g) return GLRTX_EINVAL;
+    const int n = (int)g->ctx.size();
+    for (int i = 0; i < n; i++) {
+        glrtx_ctx *c = g->ctx[i];
+        c->rank = i; c->world = n; c->stripe = kTile;  // == glrtx_set_partition(c, i, n, 16) without the intermediate resize
+        if (int rc = gsub(g, i, glrtx_resize(c, width, height))) return rc;
+    }
+    g->width = width; g->height = height;
+    return GLRTX_OK;
+}
+
+int glrtx_group_clear(glrtx_group *g) {
+    if (!g) return GLRTX_EINVAL;
+    for (size_t i = 0; i < g->ctx.size(); i++)
+        if (int rc = gsub(g, (int)i, glrtx_clear(g->ctx[i]))) return rc;
+    return GLRTX_OK;
+}
+
+int glrtx_group_render(glrtx_group *g, const glrtx_params *p) {
+    if (!g) return GLRTX_EINVAL;
+    for (size_t i = 0; i < g->ctx.size(); i++)  // asynchronous launches: the GPUs run concurrently
+        if (int rc = gsub(g, (int)i, glrtx_render(g->ctx[i], p))) return rc;
+    return GLRTX_OK;
+}
+
+int glrtx_group_render_frames(glrtx_group *g, const glrtx_params *p, const float *seeds_xy, int n_frames) {
+    if (!g) return GLRTX_EINVAL;
+    for (size_t i = 0; i < g->ctx.size(); i++)
+        if (int rc = gsub(g, (int)i, glrtx_render_frames(g->ctx[i], p, seeds_xy, n_frames))) return rc;
+    return GLRTX_OK;
+}
+
+int glrtx_group_sync(glrtx_group *g) {
+    if (!g) return GLRTX_EINVAL;
+    for (size_t i = 0; i < g->ctx.size(); i++)
+        if (int rc = gsub(g, (int)i, glrtx_sync(g->ctx[i]))) return rc;
+    return GLRTX_OK;
+}
+
+int glrtx_group_read_accum(glrtx_group *g, float *dst, size_t dst_pitch_bytes) {
+    if (!g || !dst) return GLRTX_EINVAL;
+    if (dst_pitch_bytes < (size_t)g->width * sizeof(float4)) return gfail(g, GLRTX_EINVAL, "glrtx_group_read_accum: dst pitch too small");
+    if (int rc = group_gather(g)) return rc;
+    glrtx_ctx *r = g->ctx[0];
+    GHIP_TRY(g, hipStreamSynchronize(r->stream));
+    GHIP_TRY(g, hipMemcpy2D(dst, dst_pitch_bytes, g->full.p, r->pitch_bytes, (size_t)g->width * sizeof(float4), (size_t)g->height, hipMemcpyDeviceToHost));
+    return glrtx_group_sync(g);
+}
+
+int glrtx_group_resolve_rgba8(glrtx_group *g, uint8_t *dst, size_t dst_pitch_bytes, float gamma, int flip_y) {
+    if (!g || !dst) return GLRTX_EINVAL;
+    if (!(gamma > 0.f)) return gfail(g, GLRTX_EINVAL, "glrtx_group_resolve_rgba8: gamma must be positive");
+    if (dst_pitch_bytes < (size_t)g->width * 4) return gfail(g, GLRTX_EINVAL, "glrtx_group_resolve_rgba8: dst pitch too small");
+    if (int rc = group_gather(g)) return rc;
+    glrtx_ctx *r = g->ctx[0];
+    const size_t bytes = (size_t)g->width * 4 * (size_t)g->height;
+    if (g->full8.bytes < bytes) {
+        dev_free(g->full8);
+        GHIP_TRY(g, hipMalloc(&g->full8.p, bytes));
+        g->full8.bytes = bytes;
+    }
+    dim3 grid((g->width + 63) / 64, (g->height + 3) / 4);
+    hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, r->stream, (const float4 *)g->full.p, (int)(r->pitch_bytes / sizeof(float4)), g->width, g->height,
+                       (uchar4 *)g->full8.p, g->width, 1.0f / gamma, flip_y ? 1 : 0);
+    GHIP_TRY(g, hipGetLastError());
+    GHIP_TRY(g, hipStreamSynchronize(r->stream));
+    GHIP_TRY(g, hipMemcpy2D(dst, dst_pitch_bytes, g->full8.p, (size_t)g->width * 4, (size_t)g->width * 4, (size_t)g->height, hipMemcpyDeviceToHost));
+    return glrtx_group_sync(g);
+}
+
+int glrtx_group_get_stats(const glrtx_group *g, glrtx_stats *out) {
+    if (!g || !out || g->ctx.empty()) return GLRTX_EINVAL;
+    glrtx_stats s{};
+    for (size_t i = 0; i < g->ctx.size(); i++) {
+        glrtx_stats t{};
+        if (int rc = glrtx_get_stats(g->ctx[i], &t)) return rc;
+        if (i == 0) s = t;
+        else {
+            s.rays += t.rays; s.rays_untraced += t.rays_untraced; s.paths += t.paths; s.owned_rows += t.owned_rows;
+            s.kernel_ms_total = std::max(s.kernel_ms_total, t.kernel_ms_total);  // the GPUs run side by side
+            s.accumulate_ms_total = std::max(s.accumulate_ms_total, t.accumulate_ms_total);
+            s.kernel_ms_last = std::max(s.kernel_ms_last, t.kernel_ms_last);
+        }
+    }
+    *out = s;
+    return GLRTX_OK;
+}
+
 }  // extern "C"

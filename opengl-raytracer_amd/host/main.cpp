@@ -6,6 +6,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "scene.h"
 #include "window.h"
@@ -13,7 +14,7 @@
 using namespace glrt;
 
 static void usage(const char *exe) {
-    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--bvh sah|lbvh|lbvh-cpu] [--out file.png] [--device G]\n"
+    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--bvh sah|lbvh|lbvh-cpu] [--out file.png] [--save-every-frame] [--device G | --gpus N | --devices a,b,..]\n"
                 "  -i, --input             scene description (JSON; schema: SURVEY.md Appendix C)            [required]\n"
                 "  -s, --sample-per-cycle  accepted for compatibility; like the reference (main.cpp:13) it is not read\n"
                 "      --max-depth D       u_maxDepth (default 16, the reference shader's default)\n"
@@ -22,12 +23,17 @@ static void usage(const char *exe) {
                 "      --frames-in-flight B frames per launch of the render kernel (default 16; same pixels as 1)\n"
                 "      --bvh KIND          sah (CPU, default) | lbvh (linear BVH built on the GPU) | lbvh-cpu\n"
                 "      --out file.png      tonemapped output (default output.png, written after the last frame)\n"
-                "      --device G          HIP device ordinal (default: current)\n", exe);
+                "      --save-every-frame  write the image after every frame, one frame per launch (the reference's cadence, window.cpp:164)\n"
+                "      --device G          HIP device ordinal (default: current)\n"
+                "      --gpus N            render on HIP devices 0..N-1: interleaved 16-row stripes, gathered when the image is written\n"
+                "      --devices a,b,..    the same with an explicit device list (an ordinal may repeat)\n", exe);
 }
 
 int main(int argc, char **argv) {
     std::string input, out = "output.png";
     int depth = 16, spp = 1, frames = 16, device = -1, in_flight = 0;
+    bool every_frame = false;
+    std::vector<int> devices;
     std::string bvh;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -44,17 +50,24 @@ int main(int argc, char **argv) {
         else if (a == "--out") out = next("--out");
         else if (a == "--bvh") bvh = next("--bvh");
         else if (a == "--device") device = std::atoi(next("--device"));
+        else if (a == "--save-every-frame") every_frame = true;
+        else if (a == "--gpus") { const int n = std::atoi(next("--gpus")); devices.clear(); for (int k = 0; k < n; k++) devices.push_back(k); }
+        else if (a == "--devices") {
+            devices.clear();
+            for (const char *p = next("--devices"); *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
+        }
         else { usage(argv[0]); return 1; }
     }
     if (input.empty()) { usage(argv[0]); return 1; }
 
     auto window = std::make_unique<Window>();
-    window->setDevice(device);
+    if (devices.empty()) window->setDevice(device);
+    else window->setDevices(devices);
     window->setMaxDepth(depth);
     window->setSamplesPerFrame(spp);
     window->setFrameLimit(frames);
     if (in_flight > 0) window->setFramesInFlight(in_flight);
-    window->setOutput(out);
+    window->setOutput(out, every_frame);
 
     auto scene = std::make_shared<Scene>();
     if (!bvh.empty()) scene->setBvhBuilder(bvh);

@@ -17,32 +17,37 @@ namespace glrt {
 
 #define GLRTX_CHECK(call)                                                                        \
     do {                                                                                         \
-        if ((call) != GLRTX_OK) GLRT_FatalError("%s: %s", #call, glrtx_last_error(ctx_));        \
+        if ((call) != GLRTX_OK) GLRT_FatalError("%s: %s", #call, glrtx_group_last_error(grp_));  \
     } while (0)
 
 Window::Window() {
     if (const char *e = std::getenv("GLRT_FRAMES")) frameLimit_ = std::atoi(e);
     if (const char *e = std::getenv("GLRT_MAX_DEPTH")) maxDepth_ = std::atoi(e);
     if (const char *e = std::getenv("GLRT_FRAMES_IN_FLIGHT")) setFramesInFlight(std::atoi(e));
+    if (const char *e = std::getenv("GLRT_GPUS")) {
+        const int n = std::atoi(e);
+        if (n > 1) { devices_.clear(); for (int i = 0; i < n; i++) devices_.push_back(i); }
+    }
 }
 
 Window::~Window() {
-    if (ctx_) glrtx_destroy(ctx_);
+    if (grp_) glrtx_group_destroy(grp_);
 }
 
 unsigned long long Window::raysTraced() const {
     glrtx_stats st;
-    if (!ctx_ || glrtx_get_stats(ctx_, &st) != GLRTX_OK) return 0;
+    if (!grp_ || glrtx_group_get_stats(grp_, &st) != GLRTX_OK) return 0;
     return st.rays;
 }
 
 void Window::mainloop(const std::shared_ptr<Scene> &scene_, double fps) {
     (void)fps;  // the reference's default fps = -1 renders every iteration (window.cpp:126); so do we
     scene = scene_;
-    if (!ctx_ && glrtx_create(&ctx_, device_) != GLRTX_OK) GLRT_FatalError("glrtx_create: %s", glrtx_last_error(nullptr));
+    if (!grp_ && glrtx_group_create(&grp_, devices_.data(), (int)devices_.size()) != GLRTX_OK)
+        GLRT_FatalError("glrtx_group_create: %s", glrtx_group_last_error(nullptr));
     // scene upload: the five buffers Scene::parse handed to TextureBuffer::setData (scene.cpp:254-269)
-    GLRTX_CHECK(glrtx_upload_scene(
-        ctx_, scene->vertices.empty() ? nullptr : &scene->vertices[0].pos[0], scene->vertices.size(),
+    GLRTX_CHECK(glrtx_group_upload_scene(
+        grp_, scene->vertices.empty() ? nullptr : &scene->vertices[0].pos[0], scene->vertices.size(),
         scene->triangles.empty() ? nullptr : &scene->triangles[0].indices[0], scene->triangles.size(),
         scene->materials.empty() ? nullptr : &scene->materials[0].type[0], scene->materials.size(),
         scene->lights.empty() ? nullptr : &scene->lights[0].indices[0], scene->lights.size(),
@@ -57,14 +62,17 @@ void Window::mainloop(const std::shared_ptr<Scene> &scene_, double fps) {
         const auto t0 = std::chrono::steady_clock::now();
         if (n == 1) render();
         else renderFrames(n);
-        GLRTX_CHECK(glrtx_sync(ctx_));
+        GLRTX_CHECK(glrtx_group_sync(grp_));
         lastMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n;
         if (saveEveryFrame_ && !output_.empty()) saveCurrentFrame(output_, true);  // window.cpp:164
     }
     if (!saveEveryFrame_ && !output_.empty() && frameLimit_ > 0) saveCurrentFrame(output_, true);
 }
 
-void Window::initialize() { GLRTX_CHECK(glrtx_count_rays(ctx_, 1)); }
+void Window::initialize() {
+    for (int i = 0; i < glrtx_group_size(grp_); i++)
+        if (glrtx_count_rays(glrtx_group_ctx(grp_, i), 1) != GLRTX_OK) GLRT_FatalError("glrtx_count_rays failed");
+}
 
 void Window::frameParams(glrtx_params &p) const {
     // window.cpp:230-243: the per-frame uniforms (u_seed is filled in by the caller)
@@ -83,7 +91,7 @@ void Window::render() {
     glrtx_params p;
     frameParams(p);
     glrt_frame_seed(frame_++, p.seed);
-    GLRTX_CHECK(glrtx_render(ctx_, &p));  // window.cpp:290, the draw that runs the path tracer
+    GLRTX_CHECK(glrtx_group_render(grp_, &p));  // window.cpp:290, the draw that runs the path tracer
 }
 
 void Window::renderFrames(int n) {
@@ -91,7 +99,7 @@ void Window::renderFrames(int n) {
     frameParams(p);
     std::vector<float> seeds(2 * (size_t)n);
     for (int f = 0; f < n; f++) glrt_frame_seed(frame_++, &seeds[2 * (size_t)f]);
-    GLRTX_CHECK(glrtx_render_frames(ctx_, &p, seeds.data(), n));
+    GLRTX_CHECK(glrtx_group_render_frames(grp_, &p, seeds.data(), n));
 }
 
 void Window::resizeDefault(int w, int h) {
@@ -100,13 +108,14 @@ void Window::resizeDefault(int w, int h) {
     resetBuffer();
 }
 
-void Window::resetBuffer() { GLRTX_CHECK(glrtx_resize(ctx_, width_, height_)); }  // window.cpp:366-381
+void Window::resetBuffer() { GLRTX_CHECK(glrtx_group_resize(grp_, width_, height_)); }  // window.cpp:366-381
 
 void Window::saveCurrentFrame(const std::string &filename, bool overwrite) const {
     std::vector<unsigned char> bytes((size_t)width_ * height_ * 4);
     // resolve = screen.frag (rgb/count, clamp, gamma 2.2) + the vertical flip of window.cpp:391-398
-    if (glrtx_resolve_rgba8(ctx_, bytes.data(), (size_t)width_ * 4, 2.2f, 1) != GLRTX_OK)
-        GLRT_FatalError("glrtx_resolve_rgba8: %s", glrtx_last_error(ctx_));
+    // (with several GPUs the stripes are first gathered on the first one)
+    if (glrtx_group_resolve_rgba8(grp_, bytes.data(), (size_t)width_ * 4, 2.2f, 1) != GLRTX_OK)
+        GLRT_FatalError("glrtx_group_resolve_rgba8: %s", glrtx_group_last_error(grp_));
     std::string path = filename;
     if (!overwrite) {
         int count = 0;

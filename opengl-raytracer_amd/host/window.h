@@ -7,11 +7,12 @@
 #pragma once
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "common.h"
 #include "scene.h"
 
-struct glrtx_ctx;
+struct glrtx_group;
 struct glrtx_params;
 
 namespace glrt {
@@ -32,7 +33,11 @@ public:
     void setMaxDepth(int depth) { maxDepth_ = depth; }
     void setSamplesPerFrame(int spp) { samplesPerFrame_ = spp; }
     void setOutput(const std::string &file, bool everyFrame = false) { output_ = file; saveEveryFrame_ = everyFrame; }
-    void setDevice(int hipDevice) { device_ = hipDevice; }
+    void setDevice(int hipDevice) { devices_.assign(1, hipDevice); }
+    // Several GPUs of the node (no reference counterpart): the image rows are split into interleaved 16-row stripes, one share per
+    // listed HIP device, rendered concurrently and gathered on the first one when a frame is saved (glrtx_group, include/glrtx.h).
+    // The same ordinal may be listed more than once.  The image is bit-identical to the single-GPU one.  GLRT_GPUS=N = devices 0..N-1.
+    void setDevices(const std::vector<int> &hipDevices) { if (!hipDevices.empty()) devices_ = hipDevices; }
     void setFirstFrame(unsigned f) { frame_ = f; }
     // Frames issued per launch of the render kernel (glrtx_render_frames; bit-identical to one launch per frame).
     // Used when no image is written between frames and render() is not overridden per frame; GLRT_FRAMES_IN_FLIGHT.
@@ -54,8 +59,8 @@ private:
     void resetBuffer();
     void saveCurrentFrame(const std::string &filename, bool overwrite = true) const;
 
-    glrtx_ctx *ctx_ = nullptr;
-    int device_ = -1;
+    glrtx_group *grp_ = nullptr;
+    std::vector<int> devices_ = {-1};  // -1: the current HIP device
     int width_ = 0, height_ = 0;
     int frameLimit_ = 16, maxDepth_ = 16, samplesPerFrame_ = 1, framesInFlight_ = 16;
     unsigned frame_ = 0;

@@ -33,7 +33,10 @@ EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_err
            "glrtx_resize", "glrtx_clear", "glrtx_set_partition", "glrtx_local_row_to_y", "glrtx_bind_accum",
            "glrtx_set_stream", "glrtx_set_variant", "glrtx_count_rays", "glrtx_render", "glrtx_render_frames", "glrtx_sync", "glrtx_read_accum",
            "glrtx_accum_device_ptr", "glrtx_resolve_rgba8", "glrtx_get_stats", "glrtx_reset_stats",
-           "glrtx_timer_begin", "glrtx_timer_end"]
+           "glrtx_timer_begin", "glrtx_timer_end",
+           "glrtx_group_create", "glrtx_group_destroy", "glrtx_group_last_error", "glrtx_group_size", "glrtx_group_ctx",
+           "glrtx_group_upload_scene", "glrtx_group_resize", "glrtx_group_clear", "glrtx_group_render", "glrtx_group_render_frames",
+           "glrtx_group_sync", "glrtx_group_read_accum", "glrtx_group_resolve_rgba8", "glrtx_group_get_stats"]
 
 _lib = None
 
@@ -78,6 +81,23 @@ def lib():
         L.glrtx_reset_stats.argtypes = [vp]
         L.glrtx_timer_begin.argtypes = [vp]
         L.glrtx_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
+        L.glrtx_group_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+        L.glrtx_group_destroy.argtypes = [vp]
+        L.glrtx_group_destroy.restype = None
+        L.glrtx_group_last_error.argtypes = [vp]
+        L.glrtx_group_last_error.restype = C.c_char_p
+        L.glrtx_group_size.argtypes = [vp]
+        L.glrtx_group_ctx.argtypes = [vp, C.c_int]
+        L.glrtx_group_ctx.restype = vp
+        L.glrtx_group_upload_scene.argtypes = [vp, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t]
+        L.glrtx_group_resize.argtypes = [vp, C.c_int, C.c_int]
+        L.glrtx_group_clear.argtypes = [vp]
+        L.glrtx_group_render.argtypes = [vp, C.POINTER(Params)]
+        L.glrtx_group_render_frames.argtypes = [vp, C.POINTER(Params), fp, C.c_int]
+        L.glrtx_group_sync.argtypes = [vp]
+        L.glrtx_group_read_accum.argtypes = [vp, vp, C.c_size_t]
+        L.glrtx_group_resolve_rgba8.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_int]
+        L.glrtx_group_get_stats.argtypes = [vp, C.POINTER(Stats)]
         _lib = L
     return _lib
 
@@ -211,6 +231,84 @@ class Device:
         ms = C.c_float(0)
         self._ck(self.L.glrtx_timer_end(self.h, C.byref(ms)))
         return float(ms.value)
+
+
+class Group:
+    """glrtx_group: one context per listed HIP device (an ordinal may repeat), the image rows in interleaved 16-row stripes;
+    read_accum / resolve_rgba8 return the FULL image, gathered on the first device."""
+
+    def __init__(self, device_ids):
+        self.L = lib()
+        self.h = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        rc = self.L.glrtx_group_create(C.byref(self.h), ids, len(device_ids))
+        if rc != 0:
+            raise GlrtxError(rc, self.L.glrtx_group_last_error(None).decode())
+        self.w = self.hgt = 0
+
+    def close(self):
+        if self.h:
+            self.L.glrtx_group_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise GlrtxError(rc, self.L.glrtx_group_last_error(self.h).decode())
+
+    def size(self):
+        return int(self.L.glrtx_group_size(self.h))
+
+    def member_call(self, fn, *args):
+        """fn(ctx, *args) on every member (glrtx_count_rays, glrtx_set_variant, ...)."""
+        for i in range(self.size()):
+            rc = fn(self.L.glrtx_group_ctx(self.h, i), *args)
+            if rc != 0:
+                raise GlrtxError(rc, self.L.glrtx_last_error(self.L.glrtx_group_ctx(self.h, i)).decode())
+
+    def upload_scene(self, scene):
+        v, t, m, l, b = (_f32(scene[k]) for k in ("vert", "tri", "mat", "light", "bvh"))
+        self._ck(self.L.glrtx_group_upload_scene(self.h, _fp(v), v.size // 15, _fp(t), t.size // 4, _fp(m), m.size // 18,
+                                                 _fp(l), l.size // 4, _fp(b), b.size // 9))
+
+    def resize(self, w, h):
+        self._ck(self.L.glrtx_group_resize(self.h, w, h))
+        self.w, self.hgt = w, h
+
+    def clear(self):
+        self._ck(self.L.glrtx_group_clear(self.h))
+
+    def render(self, params):
+        p = params if isinstance(params, Params) else make_params(params)
+        self._ck(self.L.glrtx_group_render(self.h, C.byref(p)))
+
+    def render_frames(self, params, seeds):
+        p = params if isinstance(params, Params) else make_params(dict(params, seed=(0.0, 0.0)) if "seed" not in params else params)
+        sd = _f32(np.asarray(seeds, np.float32).reshape(-1, 2))
+        self._ck(self.L.glrtx_group_render_frames(self.h, C.byref(p), _fp(sd), sd.shape[0]))
+
+    def sync(self):
+        self._ck(self.L.glrtx_group_sync(self.h))
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._ck(self.L.glrtx_group_get_stats(self.h, C.byref(s)))
+        return s
+
+    def read_accum(self) -> np.ndarray:
+        out = np.zeros((self.hgt, self.w, 4), np.float32)
+        self._ck(self.L.glrtx_group_read_accum(self.h, out.ctypes.data, self.w * 16))
+        return out
+
+    def resolve_rgba8(self, gamma=2.2, flip_y=True) -> np.ndarray:
+        out = np.zeros((self.hgt, self.w, 4), np.uint8)
+        self._ck(self.L.glrtx_group_resolve_rgba8(self.h, out.ctypes.data, self.w * 4, gamma, int(flip_y)))
+        return out
 
 
 def render_image(scene, params, device_id=-1, count_rays=True):

@@ -78,6 +78,22 @@ def test_glrt_main_with_gpu_built_lbvh_gives_the_same_image(tmp_path, gpu_device
     assert (np.abs(imgs["lbvh"] - imgs["sah"]).max(-1) > 0).mean() < 0.01
 
 
+def test_glrt_main_on_several_partitions_writes_the_identical_png(tmp_path):
+    """glrt_main --devices 0,0 / 0,0,0 (glrt::Window on a glrtx_group; both shares on this GPU) and --save-every-frame
+    (the reference's cadence, window.cpp:164): the PNG is byte-identical to the single-context run's."""
+    b = _c1_builder()
+    js = scenes.export_json_obj(b, tmp_path, 96, 72, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0)
+    pngs = {}
+    for name, extra in (("one", []), ("two", ["--devices", "0,0"]), ("three", ["--devices", "0,0,0"]), ("every", ["--devices", "0,0", "--save-every-frame"])):
+        out = tmp_path / f"{name}.png"
+        r = subprocess.run([str(PKG / "lib" / "glrt_main"), "-i", str(js), "--max-depth", "4", "--frames", "5", "--frames-in-flight", "2",
+                            "--out", str(out)] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.count("Save:") == (5 if name == "every" else 1)
+        pngs[name] = out.read_bytes()
+    assert pngs["one"] == pngs["two"] == pngs["three"] == pngs["every"]
+
+
 def test_glrt_main_requires_input():
     r = subprocess.run([str(PKG / "lib" / "glrt_main")], capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stdout

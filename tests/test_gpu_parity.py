@@ -421,3 +421,49 @@ def test_more_materials_than_fit_in_lds(gpu_device):
             assert_bit_equal(acc, ref, f"340 materials, variant {variant}")
     finally:
         d.set_variant(2)
+
+
+# ---------------------------------------------------------------- groups (multi-GPU through the C ABI)
+@pytest.mark.parametrize("n_members", [1, 2, 3, 8])
+def test_group_renders_the_single_context_image(gpu_device, n_members):
+    """glrtx_group with n members (all on this GPU: the partition arithmetic, the concurrent streams, the stripe gather and the
+    full-frame resolve are what is under test) == one context, bit for bit: accumulator, ray count and RGBA8 bytes; with single
+    launches and with frames in flight; at a height that leaves ragged stripes."""
+    scene, params = scenes.config_c1(160, 104, max_depth=4, n_samples=1, subdiv=1)  # 104 rows = 6.5 stripes
+    seeds = [host.frame_seed(f) for f in range(5)]
+    d = gpu_device
+    ref, ref_st = gpu_render(d, scene, params, frames=seeds)
+    ref_rays = int(ref_st.rays)
+    ref8 = d.resolve_rgba8(2.2, True)
+    g = device.Group([0] * n_members)
+    try:
+        assert g.size() == n_members
+        g.upload_scene(scene)
+        g.resize(160, 104)
+        g.member_call(g.L.glrtx_count_rays, 1)
+        g.render(dict(params, seed=seeds[0]))
+        g.render_frames(params, seeds[1:4])
+        g.render(dict(params, seed=seeds[4]))
+        g.sync()
+        st = g.stats()
+        assert st.owned_rows == 104 and st.rays == ref_rays
+        assert_bit_equal(g.read_accum(), ref, f"group of {n_members}")
+        assert np.array_equal(g.resolve_rgba8(2.2, True), ref8)
+        g.clear()
+        g.render(dict(params, seed=seeds[0]))
+        one, _ = gpu_render(d, scene, params)
+        assert_bit_equal(g.read_accum(), one, "after clear")
+    finally:
+        g.close()
+
+
+def test_group_error_paths():
+    with pytest.raises(device.GlrtxError):
+        device.Group([0, 99])  # no such device
+    g = device.Group([0, 0])
+    try:
+        with pytest.raises(device.GlrtxError) as e:
+            g.render(scenes.config_c1(32, 32, subdiv=1)[1])
+        assert e.value.code == device.GLRTX_EINVAL and "context 0" in str(e.value) and "no scene" in str(e.value)
+    finally:
+        g.close()
