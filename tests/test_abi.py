@@ -52,3 +52,16 @@ def test_struct_layouts_match_header():
     from glrt_amd import device
     assert C.sizeof(device.Params) == 16 * 4 * 2 + 4 * 4 + 8
     assert C.sizeof(device.Stats) == 104
+
+
+def test_code_object_invariants():
+    """tools/isa_report.py --check on the built libglrtx.so: the render kernels spill nothing, and no instruction touches the
+    destination of trav_scan's s_load_dwordx16 between the load and its s_waitcnt (the load and the wait are separate asm statements)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_report.py"), "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("glrtx::pt_render_wgwf<false, false>")]
+    assert rows, r.stdout
+    vgpr, agpr, sgpr, vspill, sspill, scratch = (int(v) for v in rows[0][3:9])
+    assert vspill == 0 and scratch == 0 and sspill < 32 and vgpr <= 128

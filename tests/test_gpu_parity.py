@@ -467,3 +467,41 @@ def test_group_error_paths():
         assert e.value.code == device.GLRTX_EINVAL and "context 0" in str(e.value) and "no scene" in str(e.value)
     finally:
         g.close()
+
+
+def _closed_box(width, height, max_depth, n_samples):
+    """A closed room of albedo-0.98 walls with a small lamp: paths end almost only through Russian roulette (survival 0.95 per
+    bounce beyond depth 2), so path lengths have a long tail."""
+    b = scenes.SceneBuilder()
+    wall = b.add_material(scenes.diffuse((0.98, 0.98, 0.98)))
+    lamp = b.add_material(scenes.emitter((20.0, 20.0, 20.0)))
+    lo, hi = -2.0, 2.0
+    b.add_mesh(*scenes.quad((lo, lo, hi), (hi - lo, 0, 0), (0, 0, lo - hi)), wall)   # floor, normal +y
+    b.add_mesh(*scenes.quad((lo, hi, lo), (hi - lo, 0, 0), (0, 0, hi - lo)), wall)   # ceiling, normal -y
+    b.add_mesh(*scenes.quad((lo, lo, lo), (hi - lo, 0, 0), (0, hi - lo, 0)), wall)   # back, normal +z
+    b.add_mesh(*scenes.quad((hi, lo, hi), (lo - hi, 0, 0), (0, hi - lo, 0)), wall)   # front, normal -z
+    b.add_mesh(*scenes.quad((lo, lo, hi), (0, 0, lo - hi), (0, hi - lo, 0)), wall)   # left, normal +x
+    b.add_mesh(*scenes.quad((hi, lo, lo), (0, 0, hi - lo), (0, hi - lo, 0)), wall)   # right, normal -x
+    b.add_mesh(*scenes.quad((-0.5, hi - 0.01, -0.5), (1, 0, 0), (0, 0, 1)), lamp)                # lamp under the ceiling, facing down
+    sc = b.build()
+    c2w, s2c = scenes.camera((0.0, 0.0, 1.8), (0, 0, 0), (0, 1, 0), 70.0, width, height)
+    return sc, scenes.make_params(c2w, s2c, width, height, max_depth, n_samples)
+
+
+@pytest.mark.parametrize("max_depth", [255, 256, 300])
+def test_depth_beyond_the_packed_path_state_matches_the_oracle(gpu_device, max_depth):
+    """The wavefront kernel keeps depth in 8 bits of its packed path state; u_maxDepth > 255 is rendered by the persistent
+    megakernel instead (glrtx_render).  Both sides of that switch against the oracle, on a scene with long paths, single
+    launches and glrtx_render_frames."""
+    from oracle import pt_oracle
+    sc, pr = _closed_box(48, 48, max_depth, 4)
+    ref, ref_rays = pt_oracle.render(sc, pr)
+    acc, st = gpu_render(gpu_device, sc, pr)
+    assert int(st.rays) == ref_rays and ref_rays > 20 * 48 * 48 * 4  # long paths indeed
+    assert_bit_equal(acc, ref, f"depth {max_depth}")
+    d = gpu_device
+    d.clear(); d.reset_stats()
+    d.render_frames(pr, [pr["seed"], host.frame_seed(3)])
+    d.sync()
+    pt_oracle.render(sc, dict(pr, seed=host.frame_seed(3)), accum=ref)
+    assert_bit_equal(d.read_accum(), ref, f"depth {max_depth}, two frames in one call")
