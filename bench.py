@@ -182,7 +182,9 @@ def main(argv=None):
     ap.add_argument("--steps-per-launch", "--frames-in-flight", dest="steps_per_launch", type=int, default=STEPS_PER_LAUNCH,
                     help="steps per launch of the render kernel (at N ranks a step is N frames, so a launch covers N x this many frames: "
                          "this many full frames' worth of paths in flight on every GPU; 1 = one step per launch)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the CPU rehearsal in tests/)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals: tests/, or a 1-GPU box)")
+    ap.add_argument("--device-map", default="", help="rehearsal aid: comma-separated HIP ordinal per local rank (e.g. 0,0 runs two ranks on one GPU; "
+                                                     "RCCL needs distinct GPUs, so combine with --backend gloo --no-gather)")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -207,7 +209,8 @@ def main(argv=None):
     n_tri = int(scene["tri"].shape[0])
 
     factory = RENDERER_FACTORY or GpuRenderer
-    R = factory(rank, world, local_rank, scene, params, args.bvh)
+    dev_ord = int(args.device_map.split(",")[local_rank]) if args.device_map else local_rank
+    R = factory(rank, world, dev_ord, scene, params, args.bvh)
     scene = R.scene
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
