@@ -3,7 +3,7 @@
 # Outputs land in gpurun_out/prof_<tag>/; tools/summarize_profile.py turns them into profiles/<tag>_*.
 # Counters are collected in their own runs (never together with --sys-trace etc.), as the pool requires.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

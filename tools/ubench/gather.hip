@@ -3,7 +3,7 @@
 //   mode 1: each lane reads only 16 B of its record (lower bound: one line lookup per lane-step)
 //   mode 2: quad-cooperative: in instruction k the 4 lanes of a quad read the 4 chunks of lane k's record
 //           (one 64-B coalesced request per quad), then a DPP transpose hands every lane its own record
-// Build: hipcc -O3 --offload-arch=gfx950 tools/ubench/gather.hip -o /tmp/gather ; run: /tmp/gather
+// Build: hipcc -O3 --offload-arch=gfx950 tools/ubench/gather.hip -o tools/ubench/gather ; run: tools/ubench/gather [log2 records] [json-lines file]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -97,6 +97,10 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(rec, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<unsigned> r0(blocks * 256), r2(blocks * 256);
+    static const char *what[9] = {"4 x dwordx4 of the lane's own 64-B record (one 128-B line per lane)", "one dwordx4 of the record", "quad-cooperative 64-B loads + DPP transpose",
+                                  "one dwordx4, nt", "one dwordx4, sc0 sc1", "one dwordx4, lane pairs share a 128-B line", "one dword", "4 x dwordx4, nt",
+                                  "4 x dwordx4, the 4 lanes of a quad share one record (16 distinct lines per wave)"};
+    FILE *js = argc > 2 ? fopen(argv[2], "a") : nullptr;
     for (int mode = 0; mode < 9; mode++) {
         float best = 1e9f;
         for (int it = 0; it < 4; it++) {
@@ -117,9 +121,12 @@ int main(int argc, char **argv) {
         if (mode == 0) CK(hipMemcpy(r0.data(), out, r0.size() * 4, hipMemcpyDeviceToHost));
         if (mode == 2) CK(hipMemcpy(r2.data(), out, r2.size() * 4, hipMemcpyDeviceToHost));
         const double lane_steps = (double)blocks * 256 * steps;
-        printf("mode %d records 2^%d: %.3f ms, %.2f G lane-steps/s, %.1f lane-steps/clk/CU @2.4GHz\n", mode, log_n, best,
+        printf("mode %d records 2^%d: %.3f ms, %.2f G lane-steps/s, %.3f lane-steps/clk/CU @2.4GHz\n", mode, log_n, best,
                lane_steps / best * 1e-6, lane_steps / (best * 1e-3) / 256 / 2.4e9);
+        if (js) fprintf(js, "{\"mode\": %d, \"what\": \"%s\", \"table_bytes\": %zu, \"ms\": %.4f, \"g_lane_steps_per_s\": %.3f, \"clk_per_wave_step_per_cu\": %.2f}\n", mode, what[mode],
+                        (size_t)n * 64, best, lane_steps / best * 1e-6, 64.0 / (lane_steps / (best * 1e-3) / 256 / 2.4e9));
     }
     printf("mode2 == mode0: %s\n", r0 == r2 ? "yes" : "NO");
+    if (js) fclose(js);
     return 0;
 }
