@@ -320,6 +320,33 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
             if (is_vine && v.size() == 4 * n_tri) { P.vine.swap(v); P.vine_uniform = uniform ? 1 : 0; }
         }
     }
+    // Renumbering: the forks of the tree's top levels (breadth-first from the root, kTopForks of them) take the first indices, the
+    // others follow in the order the traversal meets them.  The top of the tree is then one contiguous, hot 8 KiB block; the
+    // -DGLRTX_LDS_TOP build of the wavefront kernel additionally keeps that block in LDS (measured: profiles/r02_lds_top.json).
+    if (root_ref >= 0 && forks.size() / 4 > 1) {
+        const int nf = (int)(forks.size() / 4);
+        std::vector<int> newid(nf, -1), order;
+        order.reserve(nf);
+        order.push_back(root_ref);
+        newid[root_ref] = 0;
+        for (size_t q = 0; q < order.size() && (int)order.size() < kTopForks; q++) {
+            const int f = order[q];
+            int refs[2]; std::memcpy(&refs[0], &forks[4 * f + 0].w, 4); std::memcpy(&refs[1], &forks[4 * f + 1].w, 4);
+            for (int k = 1; k >= 0; k--)  // children.y first, as the traversal
+                if (refs[k] >= 0 && refs[k] != REF_ABSENT && newid[refs[k]] < 0 && (int)order.size() < kTopForks) { newid[refs[k]] = (int)order.size(); order.push_back(refs[k]); }
+        }
+        for (int f = 0; f < nf; f++) if (newid[f] < 0) { newid[f] = (int)order.size(); order.push_back(f); }
+        std::vector<float4> re(forks.size());
+        for (int f = 0; f < nf; f++) {
+            for (int k = 0; k < 4; k++) re[4 * (size_t)newid[f] + k] = forks[4 * (size_t)f + k];
+            for (int k = 0; k < 2; k++) {
+                int r; std::memcpy(&r, &forks[4 * (size_t)f + k].w, 4);
+                if (r >= 0) { r = newid[r]; std::memcpy(&re[4 * (size_t)newid[f] + k].w, &r, 4); }
+            }
+        }
+        forks.swap(re);
+        root_ref = newid[root_ref];
+    }
     if (root_ref == REF_ABSENT) {  // empty scene: one childless fork, every ray misses
         forks.assign(4, make_float4(0.f, 0.f, 0.f, as_float(REF_ABSENT)));
         root_ref = 0;
@@ -350,7 +377,8 @@ int ensure(glrtx_ctx *c, DevBuf &b, size_t bytes) {
 // n_frames > 1 ("frames in flight"): the launch covers n_frames consecutive frames that differ only in u_seed (seeds_xy);
 // the per-sample planes are added to the accumulator in frame order afterwards, so the result is bit-identical to
 // n_frames separate launches.
-int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const float *seeds_xy, int n_frames) {
+int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, const float *seeds_xy, int n_frames) {
+    KernelArgs a = a_in;
     const int tiles8_x = (c->width + 7) / 8, tiles8_y = (c->owned_rows + 7) / 8;
     const size_t total = (size_t)tiles8_x * tiles8_y * 64;
     if (total * 2 >= (size_t)INT32_MAX) return fail(c, GLRTX_EINVAL, "image too large for the wgwf variant");
@@ -386,9 +414,18 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a, const glrtx_params *p, const 
         w.planes = (float4 *)c->wfPlanes.p;
     }
 
-    const int lds = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
-                    16 * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block
-                    (int)sizeof(ShadeSortLds);
+    const int lds_base = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
+                         16 * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block
+                         ((int)sizeof(ShadeSortLds) + 15) / 16 * 16;
+    // Top tree levels in LDS (trav_step): OFF by default -- measured on the headline config it is worth nothing (+1.6 % per frame at
+    // 128 forks, -0.7..-1.4 % on configs 2/4/5 with 16-128, all inside the run-to-run spread; profiles/r02_lds_top.json): the lanes at
+    // the top levels share their few cache lines with many other lanes of the wave already, so taking them off the vector-memory
+    // pipe removes almost no line fetches.  GLRTX_LDS_TOP=n stages the first n forks (as many as fit beside the traversal stacks
+    // without costing a resident workgroup are: the register budget allows GLRTX_WGWF_WAVES workgroups per CU, each 1/4 of 160 KiB).
+    int n_top = 0;
+    if (const char *v = std::getenv("GLRTX_LDS_TOP")) n_top = std::max(0, std::min(std::min(std::atoi(v), kTopForks), c->n_fork));
+    const int lds = lds_base + n_top * 64;
+    a.sc.n_top = n_top;
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
     // four instantiations: ray counting on/off x generic tree traversal / list scan of a vine (brute-force) tree
     using Kernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *);
@@ -540,6 +577,8 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     sc.root_lo = P.root_lo; sc.root_hi = P.root_hi;
     sc.n_light = (int)n_light;
     sc.n_mat = (int)n_mat;
+    sc.n_fork = (int)(forks.size() / 4);
+    sc.n_top = 0;  // chosen per launch by launch_wgwf
     sc.stack_entries = stack_need;
     sc.mats_in_lds = (n_mat > 0 && n_mat <= (size_t)kMaxLdsMaterials) ? 1 : 0;
     sc.vine = P.vine.empty() ? nullptr : (const float4 *)c->vine.p;

@@ -36,6 +36,7 @@ constexpr int kBlockThreads = 256;      // 4 wavefronts: a 16x16-pixel tile, one
 constexpr int kTile = 16;
 constexpr int REF_ABSENT = INT32_MIN;
 constexpr int kMaxLdsMaterials = 256;   // 12 KiB of LDS at most
+constexpr int kTopForks = 128;          // forks of the top tree levels, numbered first (pack_scene): one contiguous 8 KiB block
 
 constexpr float PT_EPS = 1.0e-4f;
 constexpr float PT_INFTY = 1.0e8f;
@@ -53,6 +54,8 @@ struct DevScene {
     int root_ref;
     int n_light;
     int n_mat;
+    int n_fork;
+    int n_top;          // wavefront kernel: forks [0, n_top) are also staged in LDS (0: none)
     int stack_entries;  // per-lane traversal stack entries in LDS
     int mats_in_lds;    // 1: materials staged into LDS at kernel start
     // "Vine" trees -- every fork has a leaf as children.y: the brute-force scan of BASELINE config 3 expressed in the
@@ -188,6 +191,12 @@ DEV float fmax_g(float a, float b) { return (b != b) ? a : (a > b ? a : b); }
 DEV float fmin_c(float x, float c) { return x < c ? x : c; }  // one operand constant
 DEV float fmax_c(float x, float c) { return x > c ? x : c; }
 
+// Explicit address spaces: left generic, the two arms are merged into one flat_load through a selected pointer, and a flat
+// access to LDS takes the vector-memory path instead of ds_read.
+typedef const __attribute__((address_space(3))) nfloat4 *lds_cf4;
+typedef const __attribute__((address_space(1))) nfloat4 *glb_cf4;
+typedef const __attribute__((address_space(1))) nfloat2 *glb_cf2;
+DEV float4 to_f4(nfloat4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 struct Hit {
     float t;    // INFTY on a miss
     int tri;    // closest triangle, -1 on a miss
@@ -301,8 +310,15 @@ DEV bool trav_init(const DevScene &sc, const float4 *root, Trav &T, float ox, fl
 
 // One trip of the traversal loop: process T.cur (fork or leaf), then pick the next node.
 // Returns true when the ray is finished (stack empty).
+// lds_top / n_top (wavefront kernel, GLRTX_LDS_TOP=n at run time, default 0): the first n_top forks -- the top levels of the tree,
+// numbered first by pack_scene -- are staged in LDS and read from there.  About half of a ray's fork visits are to those
+// levels, but it buys nothing measurable (profiles/r02_lds_top.json): the cost of a wave's node fetch is set by its number of
+// distinct cache lines (profiles/r02_ubench_gather.json), and the lanes at the top levels share theirs with many others.
+// What the experiment did find: written as below, every lane fetches its whole 56-byte record with FOUR load instructions
+// (dwordx4, dwordx4, dwordx3, dwordx3) issued together; the previous form -- three loads for all lanes, then one more and the
+// two refs as single dwords on the fork arm, six instructions -- was 8 % slower per frame for fewer bytes.
 template <bool CLOSEST>
-DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
+DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, const float4 *lds_top = nullptr, int n_top = 0) {
 #ifdef GLRTX_TRAV_STATS
     trav_stats_iter(T.cur, (const void *)(sc.forks + 4 * (ptrdiff_t)T.cur), T.stop_d == -__builtin_inff());
     T.iters++;
@@ -325,7 +341,13 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
     // (Left to the compiler these become dwordx3 loads plus, on the fork arm, one more dwordx3 and two dword loads of the
     // refs: 56 bytes per fork lane, 36 per triangle lane.  Forcing four dwordx4 loads issued together was measured 9 %
     // SLOWER -- the cost of a step grows with the bytes returned per lane, about 0.017 ms of frame time per byte.)
-    const float4 A = N[0], B = N[1], C = N[2], D = N[3];
+    float4 A, B, C, D;
+    if ((unsigned)cur < (unsigned)n_top) {  // a fork of the top levels: its record is in LDS
+        const lds_cf4 q = (lds_cf4)lds_top + 4 * cur;
+        A = to_f4(q[0]); B = to_f4(q[1]); C = to_f4(q[2]); D = to_f4(q[3]);
+    } else {
+        A = N[0]; B = N[1]; C = N[2]; D = N[3];
+    }
     // Two separate ifs, fork arm first: its extra loads (second box, refs) must go out BEFORE the triangle arithmetic of the
     // wave's leaf lanes.  (As one if / else the compiler may place the leaf arm first -- it did once the address select was
     // gone -- and the fork lanes then wait a second round trip behind it: 5 % of the frame.)
@@ -515,12 +537,6 @@ DEV float ggx(float hx, float hy, float hz, float ax, float ay) {
 struct Mat {
     float4 m0, m1, m2;  // {emission, type} {param0, alpha.x} {param1, alpha.y}
 };
-// Explicit address spaces: left generic, the two arms are merged into one flat_load through a selected pointer, and a flat
-// access to LDS takes the vector-memory path instead of ds_read.
-typedef const __attribute__((address_space(3))) nfloat4 *lds_cf4;
-typedef const __attribute__((address_space(1))) nfloat4 *glb_cf4;
-typedef const __attribute__((address_space(1))) nfloat2 *glb_cf2;
-DEV float4 to_f4(nfloat4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 DEV Mat load_mat(const DevScene &sc, const float4 *lds_mats, int m) {
     Mat r;
     if (sc.mats_in_lds) {
@@ -1304,7 +1320,7 @@ __device__ uint4 g_trip_log[16][64];
 // dependent round trips -- cost 14 % of the phase.  A second chunk fetched ahead of need was kept in round 1; measured
 // again after the kernel lost its spills it bought nothing (profiles/r02_ab_occupancy.txt) and its 8 registers were freed.)
 template <bool VINE>
-DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, int *stack, const float4 *rq, int n_rays,
+DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, const float4 *lds_top, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
     if (VINE) {  // list scan: every ray takes the same number of steps, so waves simply take 64 rays at a time
@@ -1328,6 +1344,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         return;
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int n_top = a.sc.n_top;
     const float4 none = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID));
     float4 cur_o = none, cur_d = none;  // this lane's record of the wave's current chunk
     int cur_pos = 0, cur_cnt = 0;       // wave-uniform
@@ -1406,10 +1423,10 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         // GLRTX_STEPS_PER_TRIP traversal steps per trip through the loop: cuts the refill bookkeeping (ballots, branches) on
         // the latency-critical instruction stream; a lane that finishes on the first step idles for one step
         if (active) {
-            bool fin = trav_step<true>(a.sc, stack, T);
+            bool fin = trav_step<true>(a.sc, stack, T, lds_top, n_top);
 #pragma unroll
             for (int k = 1; k < GLRTX_STEPS_PER_TRIP; k++)
-                if (!fin) fin = trav_step<true>(a.sc, stack, T);
+                if (!fin) fin = trav_step<true>(a.sc, stack, T, lds_top, n_top);
             if (fin) {
                 active = false;
                 unsaved = true;
@@ -1571,6 +1588,8 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));      // {root_lo, root_hi}
     float *lds_cam = reinterpret_cast<float *>(pl + 16 * sizeof(unsigned) + 32);     // {c2w, s2c, aperture, focal}
     [[maybe_unused]] ShadeSortLds *lds_sort = reinterpret_cast<ShadeSortLds *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
+    float4 *lds_top = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(lds_sort) + ((sizeof(ShadeSortLds) + 15) / 16) * 16);
+    for (int i = threadIdx.x; i < 4 * a.sc.n_top; i += kBlockThreads) lds_top[i] = a.sc.forks[i];  // top tree levels (trav_step)
     if (threadIdx.x < kCamFloats) lds_cam[threadIdx.x] = a.cam[threadIdx.x];
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
     if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
@@ -1645,7 +1664,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
         // their loads get going earlier (measured 1-2 %)
         __builtin_amdgcn_s_setprio(3);
-        wg_traverse_phase<VINE>(a, w, lds_root, stack, rq, n_rays, &ctl[1], rays);
+        wg_traverse_phase<VINE>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], rays);
         __builtin_amdgcn_s_setprio(0);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written
