@@ -56,7 +56,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_GINST = 1024 * 2.4 / 2  # wave64 VALU instructions/ns the chip can issue: 1024 SIMDs x 2.4 GHz / 2 cycles each
 STRIPE = 16
-STEPS_PER_LAUNCH = 16  # frames' worth of paths in flight on every GPU (frames in flight)
+STEPS_PER_LAUNCH = 24  # frames' worth of paths in flight on every GPU per launch (frames in flight; 8 / 16 / 32: 2.19 / 2.04 / 1.97 ms in round 1)
 
 # Test hook: tests/ replace this with a factory of CPU renderers (same interface as GpuRenderer) to rehearse the
 # N > 1 control flow under gloo.  The product path never sets it.

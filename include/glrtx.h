@@ -55,7 +55,7 @@ extern "C" {
 #define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
 #define GLRTX_ENOMEM (-5)
 
-#define GLRTX_ABI_VERSION 5
+#define GLRTX_ABI_VERSION 6
 
 typedef struct glrtx_ctx glrtx_ctx;
 
@@ -172,6 +172,22 @@ int glrtx_reset_stats(glrtx_ctx *ctx);
 /* HIP-event stopwatch on the stream launches go to: begin, N x render, end -> elapsed device ms. */
 int glrtx_timer_begin(glrtx_ctx *ctx);
 int glrtx_timer_end(glrtx_ctx *ctx, float *elapsed_ms_out);
+
+/* ---- Extensions beyond the reference.  PARITY UNPINNED: the reference has no analytic primitive
+ * (scenes are triangle meshes, raytrace.frag:226-257) and never branches on MTRL_DIELECTRIC (raytrace.frag:32), so there is no
+ * reference output for any of this; it is checked against this build's own CPU restatement (oracle/pt_oracle.c, *_ext) and
+ * against the tessellation limit of the pinned triangle path.  Off unless asked for; while active, launches run on the
+ * persistent megakernel (no frames in flight) and everything the reference does define keeps its pinned arithmetic.
+ *   glrtx_upload_spheres   n x {cx, cy, cz, radius, materialId}: analytic spheres next to the triangle BVH, tested one by
+ *                          one (at most 1024); call after glrtx_upload_scene (which drops them); n = 0 removes them.
+ *   glrtx_set_extensions   GLRTX_EXT_DIELECTRIC: materials of type 4 (MTRL_DIELECTRIC; param0 = tint, param1.x = index of
+ *                          refraction) reflect / refract with the Fresnel reflectance as probability instead of being black.
+ *                          GLRTX_EXT_WHITTED: Whitted-style transport -- a diffuse surface gathers its direct light and the
+ *                          path ends; only specular bounces continue. */
+#define GLRTX_EXT_DIELECTRIC 1
+#define GLRTX_EXT_WHITTED 2
+int glrtx_upload_spheres(glrtx_ctx *ctx, const float *spheres, size_t n_spheres);
+int glrtx_set_extensions(glrtx_ctx *ctx, int flags);
 
 /* ---- Groups: the same device layer on several GPUs of one node, behind one handle and one host thread.
  * No reference counterpart (the reference is single-GPU); SURVEY.md 8(b) sketches glrtx_create(ctx**, device_ids, n) with a

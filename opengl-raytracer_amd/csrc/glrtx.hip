@@ -42,6 +42,8 @@ struct glrtx_ctx {
     std::string err;
 
     DevBuf forks, nrms, mats, lights, vine, accum_own, counter, rgba8, work;
+    DevBuf spheres, sphereMat;  // extension kernel: analytic spheres
+    int n_spheres = 0, ext_flags = 0;
     DevBuf wfState, wfQ;      // wavefront path state (7 planes of float4 x ids) + per-workgroup queues (variant 2)
     DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
     DevBuf bvhVert, bvhTri, bvhNodes;  // glrtx_build_lbvh staging
@@ -533,7 +535,7 @@ void glrtx_destroy(glrtx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    dev_free(c->forks); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights); dev_free(c->vine);
+    dev_free(c->spheres); dev_free(c->sphereMat); dev_free(c->forks); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights); dev_free(c->vine);
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
     dev_free(c->wfState); dev_free(c->wfQ); dev_free(c->wfSeeds); dev_free(c->wfPlanes);
     dev_free(c->bvhVert); dev_free(c->bvhTri); dev_free(c->bvhNodes);
@@ -587,6 +589,7 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     if (std::getenv("GLRTX_NO_VINE_SCAN")) sc.n_vine = 0;  // A/B: force the generic tree traversal
     c->n_tri = (int)n_tri; c->n_fork = (int)(forks.size() / 4); c->n_mat = (int)n_mat; c->n_light = (int)n_light;
     c->have_scene = true;
+    c->n_spheres = 0;  // spheres reference this scene's materials: upload them again after a new scene
     c->st.stack_entries = stack_need;
     c->st.lds_bytes = lds_bytes_for(sc);
     c->st.n_tri = c->n_tri; c->st.n_fork = c->n_fork; c->st.n_mat = c->n_mat; c->st.n_light = c->n_light;
@@ -630,6 +633,37 @@ int glrtx_build_lbvh(glrtx_ctx *c, const float *vert, size_t n_vert, const float
     if (max_depth_out) *max_depth_out = depth;
     if (build_ms_out) *build_ms_out = ms;
     return depth < 63 ? GLRTX_OK : fail(c, GLRTX_EDEPTH, "glrtx_build_lbvh: tree depth %d exceeds the 64-entry traversal stack", depth);
+}
+
+int glrtx_upload_spheres(glrtx_ctx *c, const float *spheres, size_t n_spheres) {
+    if (!c) return GLRTX_EINVAL;
+    if (n_spheres && !spheres) return fail(c, GLRTX_EINVAL, "glrtx_upload_spheres: NULL buffer with non-zero count");
+    if (n_spheres > (size_t)kMaxSpheres) return fail(c, GLRTX_EINVAL, "glrtx_upload_spheres: at most %d spheres (they are tested one by one)", kMaxSpheres);
+    if (!c->have_scene) return fail(c, GLRTX_EINVAL, "glrtx_upload_spheres: upload the scene (materials) first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<float4> sp(n_spheres);
+    std::vector<int> mt(n_spheres);
+    for (size_t k = 0; k < n_spheres; k++) {
+        const float *r = spheres + 5 * k;
+        if (!(r[3] > 0.0f)) return fail(c, GLRTX_ESCENE, "sphere %zu: radius %g is not positive", k, r[3]);
+        if (!(r[4] >= 0.0f) || (size_t)r[4] >= (size_t)c->n_mat) return fail(c, GLRTX_ESCENE, "sphere %zu: material %g out of range", k, r[4]);
+        sp[k] = make_float4(r[0], r[1], r[2], r[3]);
+        mt[k] = (int)r[4];
+    }
+    int rc;
+    if ((rc = dev_upload(c, c->spheres, sp.data(), n_spheres * sizeof(float4)))) return rc;
+    if ((rc = dev_upload(c, c->sphereMat, mt.data(), n_spheres * sizeof(int)))) return rc;
+    c->n_spheres = (int)n_spheres;
+    return GLRTX_OK;
+}
+
+int glrtx_set_extensions(glrtx_ctx *c, int flags) {
+    if (!c) return GLRTX_EINVAL;
+    if (flags & ~(GLRTX_EXT_DIELECTRIC | GLRTX_EXT_WHITTED)) return fail(c, GLRTX_EINVAL, "glrtx_set_extensions: unknown flag bits 0x%x", flags);
+    static_assert(GLRTX_EXT_DIELECTRIC == EXT_DIELECTRIC && GLRTX_EXT_WHITTED == EXT_WHITTED, "extension flag values");
+    c->ext_flags = flags;
+    return GLRTX_OK;
 }
 
 int glrtx_set_partition(glrtx_ctx *c, int rank, int world, int stripe_rows) {
@@ -733,7 +767,7 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
     if (!c || !p) return GLRTX_EINVAL;
     if (n_frames < 0 || (n_frames > 0 && !seeds_xy)) return fail(c, GLRTX_EINVAL, "glrtx_render_frames: bad seeds/n_frames");
     if (n_frames == 0) return GLRTX_OK;
-    if (n_frames == 1 || c->variant != 2 || !wgwf_can_hold(p)) {  // the megakernel variants have no frames-in-flight form: one launch per frame
+    if (n_frames == 1 || c->variant != 2 || !wgwf_can_hold(p) || c->n_spheres > 0 || c->ext_flags != 0) {  // the megakernels have no frames-in-flight form: one launch per frame
         for (int f = 0; f < n_frames; f++) {
             glrtx_params q = *p;
             q.seed[0] = seeds_xy[2 * f]; q.seed[1] = seeds_xy[2 * f + 1];
@@ -813,30 +847,31 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
 
     // The wavefront variant packs depth and sample index into one word of the path state (kWfDepthMax, kWfSampleMax);
     // a launch beyond those ranges runs on the persistent megakernel instead (bit-identical, no packed state).
-    const int variant = (c->variant == 2 && !wgwf_can_hold(p)) ? 1 : c->variant;
+    // Extensions (analytic spheres, dielectric, Whitted termination) exist only in the persistent megakernel's EXT instantiation.
+    const bool ext = c->n_spheres > 0 || c->ext_flags != 0;
+    const int variant = (ext || (c->variant == 2 && !wgwf_can_hold(p))) ? 1 : c->variant;
     if (variant == 2) return launch_wgwf(c, a, p, c->frames_seeds, c->frames_n);
     if (variant == 1) {
         // persistent kernel: grid = what is resident at once (occupancy x CUs), capped by the work available
-        const int ci = c->count_rays ? 1 : 0;
-        if (lds > 64 * 1024) {
-            HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_persistent<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            HIP_TRY(c, hipFuncSetAttribute((const void *)pt_render_persistent<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        }
+        using PKernel = void (*)(const KernelArgs, unsigned *, const ExtArgs);
+        const PKernel pk = ext ? (c->count_rays ? (PKernel)pt_render_persistent<true, true> : (PKernel)pt_render_persistent<false, true>)
+                               : (c->count_rays ? (PKernel)pt_render_persistent<true, false> : (PKernel)pt_render_persistent<false, false>);
+        ExtArgs ex{};
+        ex.spheres = (const float4 *)c->spheres.p; ex.sphere_mat = (const int *)c->sphereMat.p;
+        ex.n_spheres = c->n_spheres; ex.flags = c->ext_flags;
+        if (lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         int per_cu = 0;
-        if (ci) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_persistent<true>, kBlockThreads, lds));
-        else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_persistent<false>, kBlockThreads, lds));
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pk, kBlockThreads, lds));
         if (per_cu < 1) per_cu = 1;
         const int tiles8 = ((c->width + 7) / 8) * ((c->owned_rows + 7) / 8);
         const int n_chunks = (tiles8 * 64 + kChunk - 1) / kChunk;
         const int waves_per_wg = kBlockThreads / 64;
         int grid = std::min(per_cu * c->n_cu, (n_chunks + waves_per_wg - 1) / waves_per_wg);
         if (grid < 1) grid = 1;
-        c->resident_wg[ci] = grid;
         HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        c->last_kernel = "pt_render_persistent";
-        if (ci) hipLaunchKernelGGL(pt_render_persistent<true>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, (unsigned *)c->work.p);
-        else hipLaunchKernelGGL(pt_render_persistent<false>, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, (unsigned *)c->work.p);
+        c->last_kernel = ext ? "pt_render_persistent (extensions)" : "pt_render_persistent";
+        hipLaunchKernelGGL(pk, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, (unsigned *)c->work.p, ex);
     } else {
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     c->last_kernel = "pt_render_kernel";

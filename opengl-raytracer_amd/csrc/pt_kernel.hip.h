@@ -558,6 +558,7 @@ struct Path {
     float bx, by, bz;              // beta (path throughput)
     float Lx, Ly, Lz;              // radiance gathered so far
     int depth;
+    bool spec;                     // extension kernel only: the previous bounce was a specular (dielectric) one
 };
 
 DEV void path_begin(Path &P, float ox, float oy, float oz, float dx, float dy, float dz) {
@@ -565,6 +566,7 @@ DEV void path_begin(Path &P, float ox, float oy, float oz, float dx, float dy, f
     P.bx = P.by = P.bz = 1.f;
     P.Lx = P.Ly = P.Lz = 0.f;
     P.depth = 0;
+    P.spec = false;
 }
 
 // Everything one iteration of the depth loop does EXCEPT its two BVH traversals: given the closest hit
@@ -586,7 +588,34 @@ struct Shade {
                           // contribution: a cosine <= 0, or one too small to register): counted as a ray, not traced
 };
 
-DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &P, const Hit &h, Shade &out) {
+// Surface at a hit: shading normal and material.  surf_tri() is the reference's (:254 and the triangle's material id);
+// the extension kernel also produces it for analytic spheres.
+struct Surf {
+    float nx, ny, nz;
+    int mtrl;
+};
+DEV Surf surf_tri(const DevScene &sc, const Hit &h) {
+    // normal of the closest hit (:254), computed once instead of per candidate
+    const float4 T0 = sc.forks[4 * (ptrdiff_t)(~h.tri)];
+    const float4 N0 = sc.nrms[3 * h.tri], N1 = sc.nrms[3 * h.tri + 1], N2 = sc.nrms[3 * h.tri + 2];
+    const float w0 = (1.0f - h.u) - h.v;
+    const float tx = (w0 * N0.x + h.u * N1.x) + h.v * N2.x;
+    const float ty = (w0 * N0.y + h.u * N1.y) + h.v * N2.y;
+    const float tz = (w0 * N0.z + h.u * N1.z) + h.v * N2.z;
+    const float r = rsq(dot3(tx, ty, tz, tx, ty, tz));
+    Surf S;
+    S.nx = tx * r; S.ny = ty * r; S.nz = tz * r;
+    S.mtrl = __float_as_int(T0.w);
+    return S;
+}
+
+// Extensions beyond the reference (PARITY UNPINNED -- the reference has neither, so there is nothing to
+// compare with; checked against this build's own CPU restatement and against the tessellation limit of the pinned path):
+constexpr int EXT_DIELECTRIC = 1;  // materials of type MTRL_DIELECTRIC (raytrace.frag:32, never branched on there: black) reflect / refract
+constexpr int EXT_WHITTED = 2;     // Whitted-style: a diffuse surface gathers its direct light and the path ends there; only specular bounces continue
+
+template <bool EXT>
+DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &P, float h_t, bool h_hit, const Surf &S, int ext_flags, Shade &out) {
     const DevScene &sc = a.sc;
     float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
     float bx = P.bx, by = P.by, bz = P.bz;
@@ -599,35 +628,60 @@ DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &
     float px_ = 0.f, py_ = 0.f, pz_ = 0.f;  // beta * candidate contribution
     float zx_ = 0.f, zy_ = 0.f, zz_ = 0.f;  // beta * 0
 
+    bool spec_out = false, stop_after = false;
     do {
-        if (h.tri < 0) break;  // miss: nothing is added and the loop ends (:497-499)
+        if (!h_hit) break;  // miss: nothing is added and the loop ends (:497-499)
 
-        // normal of the closest hit (:254), computed once instead of per candidate
-        const float4 T0 = sc.forks[4 * (ptrdiff_t)(~h.tri)];
-        float nx, ny, nz;
-        {
-            const float4 N0 = sc.nrms[3 * h.tri], N1 = sc.nrms[3 * h.tri + 1], N2 = sc.nrms[3 * h.tri + 2];
-            const float w0 = (1.0f - h.u) - h.v;
-            const float tx = (w0 * N0.x + h.u * N1.x) + h.v * N2.x;
-            const float ty = (w0 * N0.y + h.u * N1.y) + h.v * N2.y;
-            const float tz = (w0 * N0.z + h.u * N1.z) + h.v * N2.z;
-            const float r = rsq(dot3(tx, ty, tz, tx, ty, tz));
-            nx = tx * r; ny = ty * r; nz = tz * r;
-        }
-        const int mtrl = __float_as_int(T0.w);
-        const Mat M = load_mat(sc, lds_mats, mtrl);
+        const float nx = S.nx, ny = S.ny, nz = S.nz;
+        const Mat M = load_mat(sc, lds_mats, S.mtrl);
         const int type = __float_as_int(M.m0.w);
 
         // :420
-        const float tt = h.t + PT_EPS;
+        const float tt = h_t + PT_EPS;
         const float xx = ox + tt * dx, xy = oy + tt * dy, xz = oz + tt * dz;
         const float woz = (-(dz * nz) - (dy * ny)) - (dx * nx);  // dot(-d, n), also woLocal.z
 
         if (type == 5 && woz >= PT_EPS) {
             // MTRL_MEDIA from the front: the volume branch is compiled out in the reference
             // (ENABLE_VOLUME 0, :424-487); the ray is left unchanged.
+        } else if (EXT && type == 4 && (ext_flags & EXT_DIELECTRIC)) {
+            // ---- extension: smooth dielectric, param0 = tint, param1.x = index of refraction.  One rand() picks the reflected
+            // or the refracted direction with the unpolarised Fresnel reflectance as probability (weight = tint either way);
+            // delta BSDF: no light sampling; emission met on the next bounce counts (the "specularReflect" the reference
+            // declares at :490 and never sets).
+            if (depth == 0 || P.spec) { Lx = Lx + bx * M.m0.x; Ly = Ly + by * M.m0.y; Lz = Lz + bz * M.m0.z; }
+            const float rl = rsq(dot3(dx, dy, dz, dx, dy, dz));  // directions are not renormalised along a path (:542)
+            const float ux = dx * rl, uy = dy * rl, uz = dz * rl;
+            const float ci0 = (-(uz * nz) - (uy * ny)) - (ux * nx);  // cos(incident, n); negative: leaving the medium
+            const bool entering = ci0 > 0.0f;
+            const float fnx = entering ? nx : -nx, fny = entering ? ny : -ny, fnz = entering ? nz : -nz;
+            const float ci = __builtin_fabsf(ci0);
+            const float ior = M.m2.x;
+            const float eta = entering ? 1.0f / ior : ior;
+            const float k = 1.0f - (eta * eta) * (1.0f - ci * ci);
+            float F = 1.0f;  // total internal reflection
+            float ct = 0.0f;
+            if (k > 0.0f) {
+                ct = __builtin_sqrtf(k);
+                const float rs = (eta * ci - ct) / (eta * ci + ct);
+                const float rp = (ci - eta * ct) / (ci + eta * ct);
+                F = 0.5f * (rs * rs + rp * rp);
+            }
+            const float pick = pt_rand(rng);
+            const float hx = ox + h_t * dx, hy = oy + h_t * dy, hz = oz + h_t * dz;  // the hit point itself
+            if (pick < F) {  // reflect
+                const float two = 2.0f * ci;
+                dx = ux + two * fnx; dy = uy + two * fny; dz = uz + two * fnz;
+                ox = hx + fnx * (2.0f * PT_EPS); oy = hy + fny * (2.0f * PT_EPS); oz = hz + fnz * (2.0f * PT_EPS);
+            } else {  // refract
+                const float g = eta * ci - ct;
+                dx = eta * ux + g * fnx; dy = eta * uy + g * fny; dz = eta * uz + g * fnz;
+                ox = hx - fnx * (2.0f * PT_EPS); oy = hy - fny * (2.0f * PT_EPS); oz = hz - fnz * (2.0f * PT_EPS);
+            }
+            bx = bx * M.m1.x; by = by * M.m1.y; bz = bz * M.m1.z;
+            spec_out = true;
         } else {
-            if (depth == 0) {  // :490-494 (specularReflect / passedVolume are never set)
+            if (depth == 0 || (EXT && P.spec)) {  // :490-494 (specularReflect / passedVolume are never set by the reference)
                 Lx = Lx + bx * M.m0.x; Ly = Ly + by * M.m0.y; Lz = Lz + bz * M.m0.z;
             }
             // :502-506 local frame; cross() with the selected axis kept as 0/1 multipliers
@@ -807,7 +861,9 @@ DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &
             bx = bx * ((fx * cw) / pdf);
             by = by * ((fy * cw) / pdf);
             bz = bz * ((fz * cw) / pdf);
+            if (EXT && (ext_flags & EXT_WHITTED) && type == 2) stop_after = true;  // Whitted: direct light only at a diffuse surface
         }
+        if (EXT && stop_after) break;
 
         // Russian roulette :549-555
         if (2 < depth) {
@@ -824,6 +880,7 @@ DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &
     P.ox = ox; P.oy = oy; P.oz = oz; P.dx = dx; P.dy = dy; P.dz = dz;
     P.bx = bx; P.by = by; P.bz = bz;
     P.depth = depth + 1;
+    if (EXT) P.spec = spec_out;
     out.ended = done || P.depth >= a.max_depth;
     out.has_shadow = has_shadow;
     out.untraced = false;
@@ -839,6 +896,14 @@ DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &
     } else {
         out.Lpx = out.Lfx = Lx; out.Lpy = out.Lfy = Ly; out.Lpz = out.Lfz = Lz;
     }
+}
+
+// The reference's iteration: triangles only, no extensions.
+DEV void shade_hit(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path &P, const Hit &h, Shade &out) {
+    Surf S;
+    S.nx = S.ny = S.nz = 0.f; S.mtrl = 0;
+    if (h.tri >= 0) S = surf_tri(a.sc, h);
+    shade_core<false>(a, lds_mats, rng, P, h.t, h.tri >= 0, S, 0, out);
 }
 
 // The acceptance test of sampleDirect (:367): the shadow ray hit something at the light sample's distance.
@@ -858,6 +923,73 @@ DEV bool bounce(const KernelArgs &a, const float4 *lds_mats, int *stack, Rng &rn
         ok = nee_accepted(sh.dist, s.t, s.tri >= 0);
     } else if (sh.untraced) {
         rays += (1ull << 32) + 1ull;  // an execution of intersect() in the reference; its result cannot change L (Shade::untraced)
+    }
+    P.Lx = ok ? sh.Lpx : sh.Lfx; P.Ly = ok ? sh.Lpy : sh.Lfy; P.Lz = ok ? sh.Lpz : sh.Lfz;
+    return sh.ended;
+}
+
+// ------------------------------------------------------------------------------------------ extension kernel (f4)
+// Analytic spheres next to the triangle BVH, dielectric materials, Whitted-style termination.  PARITY UNPINNED: the reference
+// has none of this (its scenes are triangle meshes, raytrace.frag:226-257; MTRL_DIELECTRIC is a dead constant, :32), so there
+// is no reference output to compare with.  The arithmetic the reference does have -- everything in shade_core<false> -- is
+// shared, not copied.  Launched only when the caller asks for it (glrtx_upload_spheres / glrtx_set_extensions).
+struct ExtArgs {
+    const float4 *spheres;  // {centre.xyz, radius}; tested one by one after the BVH (BASELINE's sphere configs have 3-8 of them)
+    const int *sphere_mat;  // material id per sphere
+    int n_spheres;
+    int flags;              // EXT_*
+};
+constexpr int kMaxSpheres = 1024;
+
+// Closest intersection of a ray with sphere k beyond EPS: |o + t d - c|^2 = r^2 solved with the half-b form, IEEE ops only
+// (the CPU restatement in oracle/pt_oracle.c performs the same operations in the same order).
+DEV float sphere_t(float4 sp, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const float cx = ox - sp.x, cy = oy - sp.y, cz = oz - sp.z;
+    const float A = dot3(dx, dy, dz, dx, dy, dz);
+    const float B = dot3(cx, cy, cz, dx, dy, dz);
+    const float C = dot3(cx, cy, cz, cx, cy, cz) - sp.w * sp.w;
+    const float disc = B * B - A * C;
+    if (!(disc >= 0.0f)) return PT_INFTY;
+    const float sq = __builtin_sqrtf(disc);
+    const float t0 = (-B - sq) / A, t1 = (-B + sq) / A;
+    const float t = t0 > PT_EPS ? t0 : t1;
+    return t > PT_EPS ? t : PT_INFTY;
+}
+
+// Closest hit over triangles (the reference traversal) and spheres; Hit::tri >= 0 triangle, -2 - k sphere k, -1 miss.
+template <bool CLOSEST>
+DEV Hit traverse_ext(const DevScene &sc, const ExtArgs &ex, int *stack, float ox, float oy, float oz, float dx, float dy, float dz,
+                     float limit = PT_INFTY, float stop_d = -__builtin_inff()) {
+    Hit h = traverse<CLOSEST>(sc, stack, ox, oy, oz, dx, dy, dz, limit, stop_d);
+    for (int k = 0; k < ex.n_spheres; k++) {
+        const float t = sphere_t(ex.spheres[k], ox, oy, oz, dx, dy, dz);
+        if (t < h.t) { h.t = t; h.tri = -2 - k; }
+    }
+    return h;
+}
+
+DEV bool bounce_ext(const KernelArgs &a, const ExtArgs &ex, const float4 *lds_mats, int *stack, Rng &rng, Path &P, unsigned long long &rays) {
+    const Hit h = traverse_ext<true>(a.sc, ex, stack, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz);
+    rays++;
+    Surf S;
+    S.nx = S.ny = S.nz = 0.f; S.mtrl = 0;
+    if (h.tri >= 0) S = surf_tri(a.sc, h);
+    else if (h.tri < -1) {
+        const float4 sp = ex.spheres[-2 - h.tri];
+        const float qx = (P.ox + h.t * P.dx) - sp.x, qy = (P.oy + h.t * P.dy) - sp.y, qz = (P.oz + h.t * P.dz) - sp.z;
+        const float r = rsq(dot3(qx, qy, qz, qx, qy, qz));
+        S.nx = qx * r; S.ny = qy * r; S.nz = qz * r;
+        S.mtrl = ex.sphere_mat[-2 - h.tri];
+    }
+    Shade sh;
+    shade_core<true>(a, lds_mats, rng, P, h.t, h.tri != -1, S, ex.flags, sh);
+    bool ok = false;
+    if (sh.has_shadow) {
+        const Hit s = traverse_ext<false>(a.sc, ex, stack, P.ox, P.oy, P.oz, sh.sdx, sh.sdy, sh.sdz, shadow_limit(sh.dist), sh.dist);
+        rays++;
+        ok = nee_accepted(sh.dist, s.t, s.tri != -1);
+    } else if (sh.untraced) {
+        rays += (1ull << 32) + 1ull;
     }
     P.Lx = ok ? sh.Lpx : sh.Lfx; P.Ly = ok ? sh.Lpy : sh.Lfy; P.Lz = ok ? sh.Lpz : sh.Lfz;
     return sh.ended;
@@ -990,8 +1122,8 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_kernel(const KernelAr
 // Work order: pixel id -> 8x8 tile (row-major over the tile grid) -> pixel within the tile.
 constexpr int kChunk = 256;
 
-template <bool COUNT_RAYS>
-__global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const KernelArgs a, unsigned *work_counter) {
+template <bool COUNT_RAYS, bool EXT = false>
+__global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const KernelArgs a, unsigned *work_counter, const ExtArgs ex) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4 *lds_mats;
     int *stack;
@@ -1062,7 +1194,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
                 fresh = false;
             }
             bool finished = true;
-            if (a.max_depth > 0) finished = bounce(a, lds_mats, stack, rng, P, rays);
+            if (a.max_depth > 0) finished = EXT ? bounce_ext(a, ex, lds_mats, stack, rng, P, rays) : bounce(a, lds_mats, stack, rng, P, rays);
             if (finished) {
                 acc.x = acc.x + fmin_c(P.Lx, 100.0f);  // :558, :608
                 acc.y = acc.y + fmin_c(P.Ly, 100.0f);

@@ -14,6 +14,7 @@ from .host import LIB_DIR, PKG_ROOT
 
 GLRTX_OK = 0
 GLRTX_EINVAL, GLRTX_EDEVICE, GLRTX_ESCENE, GLRTX_EDEPTH, GLRTX_ENOMEM = -1, -2, -3, -4, -5
+EXT_DIELECTRIC, EXT_WHITTED = 1, 2
 
 
 class Params(C.Structure):
@@ -33,7 +34,7 @@ EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_err
            "glrtx_resize", "glrtx_clear", "glrtx_set_partition", "glrtx_local_row_to_y", "glrtx_bind_accum",
            "glrtx_set_stream", "glrtx_set_variant", "glrtx_count_rays", "glrtx_render", "glrtx_render_frames", "glrtx_sync", "glrtx_read_accum",
            "glrtx_accum_device_ptr", "glrtx_resolve_rgba8", "glrtx_get_stats", "glrtx_reset_stats",
-           "glrtx_timer_begin", "glrtx_timer_end",
+           "glrtx_timer_begin", "glrtx_timer_end", "glrtx_upload_spheres", "glrtx_set_extensions",
            "glrtx_group_create", "glrtx_group_destroy", "glrtx_group_last_error", "glrtx_group_size", "glrtx_group_ctx",
            "glrtx_group_upload_scene", "glrtx_group_resize", "glrtx_group_clear", "glrtx_group_render", "glrtx_group_render_frames",
            "glrtx_group_sync", "glrtx_group_read_accum", "glrtx_group_resolve_rgba8", "glrtx_group_get_stats"]
@@ -81,6 +82,8 @@ def lib():
         L.glrtx_reset_stats.argtypes = [vp]
         L.glrtx_timer_begin.argtypes = [vp]
         L.glrtx_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
+        L.glrtx_upload_spheres.argtypes = [vp, fp, C.c_size_t]
+        L.glrtx_set_extensions.argtypes = [vp, C.c_int]
         L.glrtx_group_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
         L.glrtx_group_destroy.argtypes = [vp]
         L.glrtx_group_destroy.restype = None
@@ -165,6 +168,15 @@ class Device:
         depth, ms = C.c_int(0), C.c_float(0)
         self._ck(self.L.glrtx_build_lbvh(self.h, _fp(v), v.shape[0], _fp(t), t.shape[0], _fp(nodes), C.byref(depth), C.byref(ms)))
         return nodes, int(depth.value), float(ms.value)
+
+    def upload_spheres(self, spheres):
+        """EXTENSION (parity unpinned): (n, 5) rows [cx, cy, cz, radius, material]; None or empty removes them."""
+        sp = _f32(np.zeros((0, 5)) if spheres is None else np.asarray(spheres, np.float32).reshape(-1, 5))
+        self._ck(self.L.glrtx_upload_spheres(self.h, _fp(sp), sp.shape[0]))
+
+    def set_extensions(self, flags: int):
+        """EXTENSION (parity unpinned): EXT_DIELECTRIC | EXT_WHITTED."""
+        self._ck(self.L.glrtx_set_extensions(self.h, int(flags)))
 
     def set_partition(self, rank, world, stripe_rows=16):
         self._ck(self.L.glrtx_set_partition(self.h, rank, world, stripe_rows))

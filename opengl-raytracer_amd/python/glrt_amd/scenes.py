@@ -181,6 +181,36 @@ def config_c1(width=256, height=256, max_depth=1, n_samples=1, bvh="sah", subdiv
     return scene, make_params(c2w, s2c, width, height, max_depth, n_samples)
 
 
+def dielectric(ior, tint=(1.0, 1.0, 1.0)):
+    """EXTENSION material (no reference counterpart: MTRL_DIELECTRIC = 4 is declared at raytrace.frag:32 and never branched on, so
+    without GLRTX_EXT_DIELECTRIC it renders black, like in the reference): param0 = tint, param1.x = index of refraction."""
+    return dict(type=4, param0=tint, param1=(float(ior), 0.0, 0.0))
+
+
+def config_spheres(width=256, height=256, max_depth=4, n_samples=1, subdiv=None, glass=False, bvh="sah"):
+    """BASELINE configs[0] read literally -- "3 spheres + 1 ground plane": the C1 layout with the three spheres ANALYTIC
+    (subdiv None; returned as a third value, (n, 5) rows [cx, cy, cz, radius, material] for glrtx_upload_spheres) or, for the
+    tessellation-limit comparison, as icospheres of the given subdivision on the pinned triangle path (third value None).
+    glass: the middle sphere is a dielectric (ior 1.5) instead of copper.  PARITY UNPINNED (no spheres in the reference)."""
+    b = SceneBuilder()
+    grey = b.add_material(diffuse((0.7, 0.7, 0.7)))
+    red = b.add_material(diffuse((0.8, 0.3, 0.3)))
+    mid = b.add_material(dielectric(1.5) if glass else conductor(COPPER["eta"], COPPER["kappa"], 0.2))
+    lamp = b.add_material(emitter((10.0, 10.0, 10.0)))
+    b.add_mesh(*quad((-10, 0, 10), (20, 0, 0), (0, 0, -20)), grey)
+    b.add_mesh(*quad((-1, 5, -1), (2, 0, 0), (0, 0, 2)), lamp)
+    balls = [((-2.2, 1.0, 0.0), red), ((0.0, 1.0, 0.0), mid), ((2.2, 1.0, 0.0), grey)]
+    spheres = None
+    if subdiv is None:
+        spheres = np.array([[c[0], c[1], c[2], 1.0, m] for c, m in balls], np.float32)
+    else:
+        for c, m in balls:
+            b.add_mesh(*icosphere(subdiv, 1.0, c), m)
+    scene = b.build(bvh)
+    c2w, s2c = camera((0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0, width, height)
+    return scene, make_params(c2w, s2c, width, height, max_depth, n_samples), spheres
+
+
 def _eight_spheres(b: SceneBuilder, subdiv: int):
     xs = (-3.3, -1.1, 1.1, 3.3)
     albedos = ((0.75, 0.75, 0.75), (0.8, 0.3, 0.3), (0.3, 0.7, 0.35), (0.3, 0.4, 0.8))

@@ -454,15 +454,60 @@ INL float pt_ggx(float hx, float hy, float hz, float ax, float ay) {
 #endif
 
 /* radiance() :409-559 with sampleDirect() :337-403 inlined */
+/* ------------------------------------------------------------------ extensions -- PARITY UNPINNED
+ * Analytic spheres, dielectric materials and Whitted-style termination do not exist in the reference (triangle meshes only,
+ * raytrace.frag:226-257; MTRL_DIELECTRIC declared at :32 and never branched on), so nothing below can be checked against it.
+ * This is the CPU statement of the device kernel's extension path (csrc/pt_kernel.hip.h: sphere_t, traverse_ext, the EXT
+ * branches of shade_core), operation for operation, so that tests can compare the two bit for bit; it is validated against
+ * the pinned triangle path through the tessellation limit (tests/test_ext.py).  Inactive unless pt_oracle_set_ext is called:
+ * the pinned restatement above and below is then exactly what it was. */
+#define PT_EXT_DIELECTRIC 1
+#define PT_EXT_WHITTED 2
+static struct { const float *spheres; int n_spheres; int flags; int active; } g_ext = {0, 0, 0, 0};
+void pt_oracle_set_ext(const float *spheres5, int n_spheres, int flags) {
+    g_ext.spheres = spheres5; g_ext.n_spheres = n_spheres; g_ext.flags = flags;
+    g_ext.active = (n_spheres > 0 || flags != 0);
+}
+INL float pt_sphere_t(const float *sp, v3 o, v3 d) {
+    float cx = o.x - sp[0], cy = o.y - sp[1], cz = o.z - sp[2];
+    float A = dot3(d.x, d.y, d.z, d.x, d.y, d.z);
+    float B = dot3(cx, cy, cz, d.x, d.y, d.z);
+    float C = dot3(cx, cy, cz, cx, cy, cz) - sp[3] * sp[3];
+    float disc = B * B - A * C;
+    if (!(disc >= 0.0f)) return PT_INFTY;
+    float sq = sqrtf(disc);
+    float t0 = (-B - sq) / A, t1 = (-B + sq) / A;
+    float t = t0 > PT_EPS ? t0 : t1;
+    return t > PT_EPS ? t : PT_INFTY;
+}
+/* closest hit over the BVH's triangles and the spheres */
+INL void pt_traverse_ext(const pt_scene *sc, v3 o, v3 d, int want_normal, pt_isect *is) {
+    pt_traverse(sc, o, d, want_normal, is);
+    for (int k = 0; k < g_ext.n_spheres; k++) {
+        const float *sp = g_ext.spheres + 5 * k;
+        float t = pt_sphere_t(sp, o, d);
+        if (t < is->tHit) {
+            is->tHit = t; is->hit = 1; is->tri = -2 - k; is->mtrl = (int)sp[4];
+            if (want_normal) {
+                float qx = (o.x + t * d.x) - sp[0], qy = (o.y + t * d.y) - sp[1], qz = (o.z + t * d.z) - sp[2];
+                float r = rsq(dot3(qx, qy, qz, qx, qy, qz));
+                is->norm.x = qx * r; is->norm.y = qy * r; is->norm.z = qz * r;
+            }
+        }
+    }
+}
+
 INL v3 pt_radiance(const pt_scene *sc, const pt_params *pr, pt_rng *rng, v3 o, v3 d, uint64_t *rays) {
     v3 L = {0.f, 0.f, 0.f}, beta = {1.f, 1.f, 1.f};
     const int n_mat_texels = sc->n_mat * 6, n_vert_texels = sc->n_vert * 5;
     const int nL = sc->n_light;
     const float nLf = (float)nL;
 
+    const int ext = g_ext.active;
+    int spec = 0; /* extension: the previous bounce was specular */
     for (int depth = 0; depth < pr->max_depth; depth++) {
         pt_isect is;
-        pt_traverse(sc, o, d, 1, &is);
+        if (ext) pt_traverse_ext(sc, o, d, 1, &is); else pt_traverse(sc, o, d, 1, &is);
         (*rays)++;
         EXP_CHECK(is, o, d);
         const v3 n = is.norm;
@@ -479,11 +524,45 @@ INL v3 pt_radiance(const pt_scene *sc, const pt_params *pr, pt_rng *rng, v3 o, v
         /* dot(-d, n); also woLocal.z */
         float woz = (-(d.z * n.z) - (d.y * n.y)) - (d.x * n.x);
 
-        if (type == 5 && woz >= PT_EPS) {
+        int spec_out = 0;
+        if (type == 5 && woz >= PT_EPS && (!ext || is.hit)) {
             /* :424-487 volume branch compiled out (ENABLE_VOLUME 0): ray unchanged */
+        } else if (ext && is.hit && type == 4 && (g_ext.flags & PT_EXT_DIELECTRIC)) {
+            /* extension: smooth dielectric (param0 = tint, param1.x = index of refraction), see shade_core<true> */
+            if (depth == 0 || spec) { L.x = L.x + beta.x * e.x; L.y = L.y + beta.y * e.y; L.z = L.z + beta.z * e.z; }
+            v3 tint = fetch3(sc->mat, n_mat_texels, m6 + 2);
+            float ior = fetch3(sc->mat, n_mat_texels, m6 + 3).x;
+            float rl = rsq(dot3(d.x, d.y, d.z, d.x, d.y, d.z));
+            float ux = d.x * rl, uy = d.y * rl, uz = d.z * rl;
+            float ci0 = (-(uz * n.z) - (uy * n.y)) - (ux * n.x);
+            int entering = ci0 > 0.0f;
+            float fnx = entering ? n.x : -n.x, fny = entering ? n.y : -n.y, fnz = entering ? n.z : -n.z;
+            float ci = fabsf(ci0);
+            float eta = entering ? 1.0f / ior : ior;
+            float k = 1.0f - (eta * eta) * (1.0f - ci * ci);
+            float F = 1.0f, ct = 0.0f;
+            if (k > 0.0f) {
+                ct = sqrtf(k);
+                float rs = (eta * ci - ct) / (eta * ci + ct);
+                float rp = (ci - eta * ct) / (ci + eta * ct);
+                F = 0.5f * (rs * rs + rp * rp);
+            }
+            float pick = pt_rand(rng);
+            float hx = o.x + is.tHit * d.x, hy = o.y + is.tHit * d.y, hz = o.z + is.tHit * d.z;
+            if (pick < F) {
+                float two = 2.0f * ci;
+                d.x = ux + two * fnx; d.y = uy + two * fny; d.z = uz + two * fnz;
+                o.x = hx + fnx * (2.0f * PT_EPS); o.y = hy + fny * (2.0f * PT_EPS); o.z = hz + fnz * (2.0f * PT_EPS);
+            } else {
+                float g = eta * ci - ct;
+                d.x = eta * ux + g * fnx; d.y = eta * uy + g * fny; d.z = eta * uz + g * fnz;
+                o.x = hx - fnx * (2.0f * PT_EPS); o.y = hy - fny * (2.0f * PT_EPS); o.z = hz - fnz * (2.0f * PT_EPS);
+            }
+            beta.x = beta.x * tint.x; beta.y = beta.y * tint.y; beta.z = beta.z * tint.z;
+            spec_out = 1;
         } else {
-            /* :490-499 (specularReflect / passedVolume are never true) */
-            if (depth == 0 && is.hit) {
+            /* :490-499 (specularReflect / passedVolume are never true in the reference; the extension sets the former) */
+            if ((depth == 0 || (ext && spec)) && is.hit) {
                 L.x = L.x + beta.x * e.x; L.y = L.y + beta.y * e.y; L.z = L.z + beta.z * e.z;
             }
             if (!is.hit) break;
@@ -612,7 +691,7 @@ INL v3 pt_radiance(const pt_scene *sc, const pt_params *pr, pt_rng *rng, v3 o, v
                 float rd = rsq(dd);
                 v3 dir = {dvx * rd, dvy * rd, dvz * rd};
                 pt_isect sh;
-                pt_traverse(sc, so, dir, 0, &sh);
+                if (ext) pt_traverse_ext(sc, so, dir, 0, &sh); else pt_traverse(sc, so, dir, 0, &sh);
                 (*rays)++;
                 EXP_CHECK(sh, so, dir);
                 float dist = sqrtf(dd);
@@ -678,7 +757,9 @@ INL v3 pt_radiance(const pt_scene *sc, const pt_params *pr, pt_rng *rng, v3 o, v
                 beta.y = beta.y * ((f.y * cw) / pdf);
                 beta.z = beta.z * ((f.z * cw) / pdf);
             }
+            if (ext && (g_ext.flags & PT_EXT_WHITTED) && type == 2) break; /* Whitted: direct light only at a diffuse surface */
         }
+        spec = spec_out;
 
         /* Russian roulette :549-555 */
         if (2 < depth) {

@@ -50,6 +50,8 @@ def lib():
                                             C.c_void_p]
         L.pt_oracle_sincos.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pt_oracle_max_threads.restype = C.c_int
+        L.pt_oracle_set_ext.restype = None
+        L.pt_oracle_set_ext.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.pt_oracle_resolve.restype = None
         L.pt_oracle_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
@@ -60,9 +62,23 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def render(scene, params, accum=None, rows=None, threads=0):
-    """Returns (accum (H, W, 4) float32 [L.rgb, count], n_rays).  Row 0 = bottom (gl_FragCoord.y = 0.5)."""
+EXT_DIELECTRIC, EXT_WHITTED = 1, 2
+
+
+def render(scene, params, accum=None, rows=None, threads=0, spheres=None, ext_flags=0):
+    """Returns (accum (H, W, 4) float32 [L.rgb, count], n_rays).  Row 0 = bottom (gl_FragCoord.y = 0.5).
+    spheres (n, 5) [cx, cy, cz, radius, material] / ext_flags: the PARITY-UNPINNED extensions (analytic spheres, EXT_DIELECTRIC,
+    EXT_WHITTED) -- the CPU statement of the device kernel's extension path, nothing of the reference's."""
     L = lib()
+    sph = None if spheres is None else _f32(np.asarray(spheres, np.float32).reshape(-1, 5))
+    L.pt_oracle_set_ext(None if sph is None else sph.ctypes.data, 0 if sph is None else sph.shape[0], int(ext_flags))
+    try:
+        return _render(L, scene, params, accum, rows, threads)
+    finally:
+        L.pt_oracle_set_ext(None, 0, 0)
+
+
+def _render(L, scene, params, accum, rows, threads):
     keep = {k: _f32(scene[k]) for k in ("vert", "tri", "mat", "light", "bvh")}
     sc = _Scene(keep["vert"].ctypes.data, keep["tri"].ctypes.data, keep["mat"].ctypes.data,
                 keep["light"].ctypes.data, keep["bvh"].ctypes.data, keep["vert"].size // 15,
