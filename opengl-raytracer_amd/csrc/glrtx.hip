@@ -17,8 +17,10 @@
 #include <string>
 #include <vector>
 
+#include "glrt_host.h"
 #include "pt_kernel.hip.h"
 #include "lbvh.hip.h"
+static_assert(glrtx::lbvh::kRotationPasses == GLRT_LBVH_ROTATION_PASSES, "device and CPU LBVH statements must run the same rotation sweeps");
 
 using namespace glrtx;
 

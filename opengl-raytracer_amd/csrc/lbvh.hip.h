@@ -5,7 +5,9 @@
 // node = {bboxMin, bboxMax, children}, fork children = (x, y, -1), leaf = (-1, -1, triangle).
 // Algorithm: Karras 2012 -- 30-bit Morton code of each triangle box centre, made unique by appending the
 // triangle index, radix-sorted (hipCUB); every internal node finds its key range and split from the
-// common-prefix lengths of neighbouring keys, independently; boxes are fitted bottom-up, one launch per tree level.  Layout: internal node i at index i (root = 0), the leaf of sorted
+// common-prefix lengths of neighbouring keys, independently; boxes are fitted bottom-up, one launch per tree level; three
+// sweeps of tree rotations (one launch per level and sweep) then improve the Morton tree's surface-area cost.
+// Layout: internal node i at index i (root = 0), the leaf of sorted
 // position k at index (n - 1) + k.  Every step is integer arithmetic or a single correctly rounded float
 // operation, so the result equals glrt_bvh_build_lbvh (host/bvh.cpp, the CPU statement) bit for bit.
 // Tree shape never changes what the path tracer computes (only exact ties).
@@ -192,6 +194,69 @@ __global__ __launch_bounds__(256) void k_fit_round(int n, int round, float *node
     stamp[i] = round;
 }
 
+// ---- tree rotations (the quality pass; CPU statement and rationale: host/bvh.cpp, lbvh::rotate_tree) ----
+// Original depth of every internal node (root 0), by walking up the parent links.
+__global__ __launch_bounds__(256) void k_levels(int n, const int *parent, int *level) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= n - 1) return;
+    int d = 0;
+    for (int c = parent[i]; c >= 0; c = parent[c]) d++;
+    level[i] = d;
+}
+__device__ __forceinline__ float half_area9(const float *lo, const float *hi) {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return (dx * dy + dy * dz) + dz * dx;
+}
+__device__ __forceinline__ float union_area9(const float *a, const float *b) {
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) { lo[k] = min_std(a[k], b[k]); hi[k] = max_std(a[3 + k], b[3 + k]); }
+    return half_area9(lo, hi);
+}
+// One sweep step: every internal node that was at depth `d` when the sweep started tries its four rotations.  Such nodes have
+// disjoint subtrees, a rotation rearranges only the subtree of its own node, and nothing above level d has moved yet in this
+// sweep, so the threads of one launch never touch the same record.
+__global__ __launch_bounds__(256) void k_rotate_level(int n, int d, const int *level, float *nodes, int *parent) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= n - 1 || level[i] != d) return;
+    float *N = nodes + 9 * (size_t)i;
+    const int c[2] = {(int)N[6], (int)N[7]};
+    float best = 0.0f;
+    int bx = -1, bside = 0, bwhich = 0;
+    for (int side = 0; side < 2; side++) {
+        const int x = c[side], y = c[side ^ 1];
+        if (x >= n - 1) continue;
+        const float *X = nodes + 9 * (size_t)x, *Y = nodes + 9 * (size_t)y;
+        const float old = half_area9(X, X + 3);
+        const float g0 = union_area9(Y, nodes + 9 * (size_t)(int)X[7]) - old;
+        const float g1 = union_area9(nodes + 9 * (size_t)(int)X[6], Y) - old;
+        if (g0 < best) { best = g0; bx = x; bside = side; bwhich = 0; }
+        if (g1 < best) { best = g1; bx = x; bside = side; bwhich = 1; }
+    }
+    if (bx < 0) return;
+    float *X = nodes + 9 * (size_t)bx;
+    const int y = c[bside ^ 1];
+    const int moved = (int)X[6 + bwhich];
+    X[6 + bwhich] = (float)y;
+    N[6 + (bside ^ 1)] = (float)moved;
+    parent[y] = bx;
+    parent[moved] = i;
+    const float *A = nodes + 9 * (size_t)(int)X[6], *B = nodes + 9 * (size_t)(int)X[7];
+    for (int k = 0; k < 3; k++) { X[k] = min_std(A[k], B[k]); X[3 + k] = max_std(A[3 + k], B[3 + k]); }
+}
+// Depth of the deepest leaf (after the rotations), one atomic per wave.
+__global__ __launch_bounds__(256) void k_max_depth(int n, const int *parent, int *max_depth) {
+    const int k = (int)(blockIdx.x * 256u + threadIdx.x);
+    int depth = 0;
+    if (k < n)
+        for (int c = parent[(n - 1) + k]; c >= 0; c = parent[c]) depth++;
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int o = __shfl_xor(depth, m);
+        depth = o > depth ? o : depth;
+    }
+    if ((threadIdx.x & 63u) == 0u) atomicMax(max_depth, depth);
+}
+constexpr int kRotationPasses = 3;  // == GLRT_LBVH_ROTATION_PASSES (glrt_host.h): the CPU statement must run the same sweeps
+
 struct Workspace {
     void *p = nullptr;
     size_t bytes = 0;
@@ -246,6 +311,22 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
     for (int round = 1; round <= out[1]; round++)
         hipLaunchKernelGGL(k_fit_round, grid, block, 0, stream, (int)n, round, d_nodes, (int *)arrived);
     LBVH_TRY(hipGetLastError());
+    if (n >= 3) {  // quality pass: tree rotations, bottom-up by original depth, kRotationPasses sweeps
+        int *level = (int *)arrived;  // the fit stamps are no longer needed
+        int depth = out[1];           // deepest leaf; internal nodes are at depths 0 .. depth - 1
+        for (int pass = 0; pass < kRotationPasses; pass++) {
+            // levels as they are when the sweep starts (a rotation at an ancestor moves whole subtrees between nodes of one depth)
+            hipLaunchKernelGGL(k_levels, grid, block, 0, stream, (int)n, parent, level);
+            for (int d = depth - 1; d >= 0; d--)
+                hipLaunchKernelGGL(k_rotate_level, grid, block, 0, stream, (int)n, d, level, d_nodes, parent);
+            LBVH_TRY(hipMemsetAsync(max_depth, 0, sizeof(int), stream));
+            hipLaunchKernelGGL(k_max_depth, grid, block, 0, stream, (int)n, parent, max_depth);
+            LBVH_TRY(hipGetLastError());
+            LBVH_TRY(hipMemcpyAsync(&depth, max_depth, sizeof(int), hipMemcpyDeviceToHost, stream));
+            LBVH_TRY(hipStreamSynchronize(stream));  // the next sweep's launch count depends on it
+        }
+        *max_depth_out = depth;
+    }
     LBVH_TRY(hipStreamSynchronize(stream));
     return hipSuccess;
 #undef LBVH_TRY
