@@ -5,7 +5,7 @@
 // node = {bboxMin, bboxMax, children}, fork children = (x, y, -1), leaf = (-1, -1, triangle).
 // Algorithm: Karras 2012 -- 30-bit Morton code of each triangle box centre, made unique by appending the
 // triangle index, radix-sorted (hipCUB); every internal node finds its key range and split from the
-// common-prefix lengths of neighbouring keys, independently; boxes are fitted bottom-up, one launch per tree level; three
+// common-prefix lengths of neighbouring keys, independently; boxes are fitted bottom-up, one launch per tree level; five
 // sweeps of tree rotations (one launch per level and sweep) then improve the Morton tree's surface-area cost.
 // Layout: internal node i at index i (root = 0), the leaf of sorted
 // position k at index (n - 1) + k.  Every step is integer arithmetic or a single correctly rounded float
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_rotate_level(int n, int d, const int *l
     float *N = nodes + 9 * (size_t)i;
     const int c[2] = {(int)N[6], (int)N[7]};
     float best = 0.0f;
-    int bx = -1, bside = 0, bwhich = 0;
+    int kind = -1, bside = 0, bwhich = 0;  // kind 0: child <-> grandchild, 1: grandchild <-> grandchild
     for (int side = 0; side < 2; side++) {
         const int x = c[side], y = c[side ^ 1];
         if (x >= n - 1) continue;
@@ -229,19 +229,43 @@ __global__ __launch_bounds__(256) void k_rotate_level(int n, int d, const int *l
         const float old = half_area9(X, X + 3);
         const float g0 = union_area9(Y, nodes + 9 * (size_t)(int)X[7]) - old;
         const float g1 = union_area9(nodes + 9 * (size_t)(int)X[6], Y) - old;
-        if (g0 < best) { best = g0; bx = x; bside = side; bwhich = 0; }
-        if (g1 < best) { best = g1; bx = x; bside = side; bwhich = 1; }
+        if (g0 < best) { best = g0; kind = 0; bside = side; bwhich = 0; }
+        if (g1 < best) { best = g1; kind = 0; bside = side; bwhich = 1; }
     }
-    if (bx < 0) return;
-    float *X = nodes + 9 * (size_t)bx;
-    const int y = c[bside ^ 1];
-    const int moved = (int)X[6 + bwhich];
-    X[6 + bwhich] = (float)y;
-    N[6 + (bside ^ 1)] = (float)moved;
-    parent[y] = bx;
-    parent[moved] = i;
-    const float *A = nodes + 9 * (size_t)(int)X[6], *B = nodes + 9 * (size_t)(int)X[7];
-    for (int k = 0; k < 3; k++) { X[k] = min_std(A[k], B[k]); X[3 + k] = max_std(A[3 + k], B[3 + k]); }
+    if (c[0] < n - 1 && c[1] < n - 1) {
+        const float *A = nodes + 9 * (size_t)c[0], *B = nodes + 9 * (size_t)c[1];
+        const float *A1 = nodes + 9 * (size_t)(int)A[6], *A2 = nodes + 9 * (size_t)(int)A[7];
+        const float *B1 = nodes + 9 * (size_t)(int)B[6], *B2 = nodes + 9 * (size_t)(int)B[7];
+        const float old = half_area9(A, A + 3) + half_area9(B, B + 3);
+        const float h0 = (union_area9(B1, A2) + union_area9(A1, B2)) - old;
+        const float h1 = (union_area9(B2, A2) + union_area9(B1, A1)) - old;
+        if (h0 < best) { best = h0; kind = 1; bwhich = 0; }
+        if (h1 < best) { best = h1; kind = 1; bwhich = 1; }
+    }
+    if (kind < 0) return;
+    auto refit = [&](float *X) {
+        const float *P = nodes + 9 * (size_t)(int)X[6], *Q = nodes + 9 * (size_t)(int)X[7];
+        for (int k = 0; k < 3; k++) { X[k] = min_std(P[k], Q[k]); X[3 + k] = max_std(P[3 + k], Q[3 + k]); }
+    };
+    if (kind == 0) {
+        float *X = nodes + 9 * (size_t)c[bside];
+        const int y = c[bside ^ 1];
+        const int moved = (int)X[6 + bwhich];
+        X[6 + bwhich] = (float)y;
+        N[6 + (bside ^ 1)] = (float)moved;
+        parent[y] = c[bside];
+        parent[moved] = i;
+        refit(X);
+    } else {
+        float *A = nodes + 9 * (size_t)c[0], *B = nodes + 9 * (size_t)c[1];
+        const float a1 = A[6];
+        A[6] = B[6 + bwhich];
+        B[6 + bwhich] = a1;
+        parent[(int)A[6]] = c[0];
+        parent[(int)B[6 + bwhich]] = c[1];
+        refit(A);
+        refit(B);
+    }
 }
 // Depth of the deepest leaf (after the rotations), one atomic per wave.
 __global__ __launch_bounds__(256) void k_max_depth(int n, const int *parent, int *max_depth) {
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(256) void k_max_depth(int n, const int *parent, int
     }
     if ((threadIdx.x & 63u) == 0u) atomicMax(max_depth, depth);
 }
-constexpr int kRotationPasses = 3;  // == GLRT_LBVH_ROTATION_PASSES (glrt_host.h): the CPU statement must run the same sweeps
+constexpr int kRotationPasses = 5;  // == GLRT_LBVH_ROTATION_PASSES (glrt_host.h): the CPU statement must run the same sweeps
 
 struct Workspace {
     void *p = nullptr;

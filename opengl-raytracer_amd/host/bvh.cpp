@@ -224,9 +224,9 @@ inline int delta(const std::vector<uint64_t> &k, int n, int i, int j) {
 
 // ---- Tree rotations (Kensler 2008), the quality pass that follows the Morton build.  A Morton tree splits at the spatial
 // median of a fixed axis cycle; its surface-area cost is 8-28 % above the binned-SAH tree's on the BASELINE scenes and it renders
-// 9-15 % slower.  One rotation at node i exchanges one child of i with a grandchild on the other side when that shrinks the
-// surface area of the child it is taken from or given to (four candidates, the best strictly negative change wins, the first
-// in the order below on ties); the box of i itself never changes.  A sweep goes bottom-up by the depth the nodes have when
+// 9-15 % slower.  One rotation at node i exchanges one child of i with a grandchild on the other side, or a grandchild of one
+// child with a grandchild of the other, when that shrinks the summed surface area of i's children (six candidates, the best
+// strictly negative change wins, the first in the order below on ties); the box of i itself never changes.  A sweep goes bottom-up by the depth the nodes have when
 // the sweep STARTS: nodes of equal depth have disjoint subtrees, a rotation only rearranges the subtree of its own node, and
 // within a sweep nothing above the current level has moved yet, so a level's nodes can be processed in any order -- or, on
 // the device, in parallel (csrc/lbvh.hip.h: k_rotate_level) -- with the same result.  Float arithmetic: differences, products and sums of box extents in one fixed association, exact min/max.
@@ -244,7 +244,7 @@ inline void rotate_node(float *nodes, int n, int i) {
     float *N = nodes + 9 * (size_t)i;
     const int c[2] = {(int)N[6], (int)N[7]};
     float best = 0.0f;
-    int bx = -1, bside = 0, bwhich = 0;
+    int kind = -1, bside = 0, bwhich = 0;  // kind 0: child <-> grandchild, 1: grandchild <-> grandchild
     for (int side = 0; side < 2; side++) {  // x = the child that is restructured, y = its sibling
         const int x = c[side], y = c[side ^ 1];
         if (x >= n - 1) continue;  // a leaf has no grandchildren to give
@@ -252,17 +252,39 @@ inline void rotate_node(float *nodes, int n, int i) {
         const float old = half_area9(X, X + 3);
         const float g0 = union_area9(Y, nodes + 9 * (size_t)(int)X[7]) - old;  // y <-> x.left : x' = (y, x.right)
         const float g1 = union_area9(nodes + 9 * (size_t)(int)X[6], Y) - old;  // y <-> x.right: x' = (x.left, y)
-        if (g0 < best) { best = g0; bx = x; bside = side; bwhich = 0; }
-        if (g1 < best) { best = g1; bx = x; bside = side; bwhich = 1; }
+        if (g0 < best) { best = g0; kind = 0; bside = side; bwhich = 0; }
+        if (g1 < best) { best = g1; kind = 0; bside = side; bwhich = 1; }
     }
-    if (bx < 0) return;
-    float *X = nodes + 9 * (size_t)bx;
-    const int y = c[bside ^ 1];
-    const int moved = (int)X[6 + bwhich];
-    X[6 + bwhich] = (float)y;
-    N[6 + (bside ^ 1)] = (float)moved;
-    const float *A = nodes + 9 * (size_t)(int)X[6], *B = nodes + 9 * (size_t)(int)X[7];
-    for (int k = 0; k < 3; k++) { X[k] = std::min(A[k], B[k]); X[3 + k] = std::max(A[3 + k], B[3 + k]); }
+    if (c[0] < n - 1 && c[1] < n - 1) {  // both children internal: exchange a grandchild of one with a grandchild of the other
+        const float *A = nodes + 9 * (size_t)c[0], *B = nodes + 9 * (size_t)c[1];
+        const float *A1 = nodes + 9 * (size_t)(int)A[6], *A2 = nodes + 9 * (size_t)(int)A[7];
+        const float *B1 = nodes + 9 * (size_t)(int)B[6], *B2 = nodes + 9 * (size_t)(int)B[7];
+        const float old = half_area9(A, A + 3) + half_area9(B, B + 3);
+        const float h0 = (union_area9(B1, A2) + union_area9(A1, B2)) - old;  // a.left <-> b.left : a' = (b1, a2), b' = (a1, b2)
+        const float h1 = (union_area9(B2, A2) + union_area9(B1, A1)) - old;  // a.left <-> b.right: a' = (b2, a2), b' = (b1, a1)
+        if (h0 < best) { best = h0; kind = 1; bwhich = 0; }
+        if (h1 < best) { best = h1; kind = 1; bwhich = 1; }
+    }
+    if (kind < 0) return;
+    auto refit = [&](float *X) {
+        const float *P = nodes + 9 * (size_t)(int)X[6], *Q = nodes + 9 * (size_t)(int)X[7];
+        for (int k = 0; k < 3; k++) { X[k] = std::min(P[k], Q[k]); X[3 + k] = std::max(P[3 + k], Q[3 + k]); }
+    };
+    if (kind == 0) {
+        float *X = nodes + 9 * (size_t)c[bside];
+        const int y = c[bside ^ 1];
+        const int moved = (int)X[6 + bwhich];
+        X[6 + bwhich] = (float)y;
+        N[6 + (bside ^ 1)] = (float)moved;
+        refit(X);
+    } else {
+        float *A = nodes + 9 * (size_t)c[0], *B = nodes + 9 * (size_t)c[1];
+        const float a1 = A[6];
+        A[6] = B[6 + bwhich];
+        B[6 + bwhich] = a1;
+        refit(A);
+        refit(B);
+    }
 }
 inline int rotate_tree(float *nodes, int n, int passes) {
     if (n < 3) return n - 1;  // 1 triangle: depth 0; 2: depth 1; nothing to rotate
