@@ -5,6 +5,7 @@
 set -e
 TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-single"   # every launch covers 16 frames
