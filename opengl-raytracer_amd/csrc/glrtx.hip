@@ -52,7 +52,6 @@ struct glrtx_ctx {
     lbvh::Workspace bvhWs;
     int variant = 2;          // 0 = tile megakernel, 1 = persistent megakernel with path regeneration, 2 = workgroup-local wavefront
     int n_cu = 256;
-    int resident_wg[2] = {0, 0};  // persistent grid size per COUNT_RAYS instantiation (0 = not yet queried)
     DevScene sc{};
     bool have_scene = false;
     int n_tri = 0, n_fork = 0, n_mat = 0, n_light = 0;

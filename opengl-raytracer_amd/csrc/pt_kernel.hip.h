@@ -338,9 +338,10 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, const float4 *lds_to
     // the two arms then cost one memory round trip, not two.
     const bool is_fork = cur >= 0;
     const float4 *N = sc.forks + 4 * (ptrdiff_t)cur;
-    // (Left to the compiler these become dwordx3 loads plus, on the fork arm, one more dwordx3 and two dword loads of the
-    // refs: 56 bytes per fork lane, 36 per triangle lane.  Forcing four dwordx4 loads issued together was measured 9 %
-    // SLOWER -- the cost of a step grows with the bytes returned per lane, about 0.017 ms of frame time per byte.)
+    // Every lane fetches its whole record here -- dwordx4, dwordx4, dwordx3, dwordx3: FOUR load instructions issued together (the
+    // compiler drops the unused C.w / D.w).  The vector-memory pipe charges per instruction and per distinct cache line, not per
+    // byte: fetching the fork arm's second box and refs separately (six instructions, 20 bytes less for a triangle lane) was 8 %
+    // slower per frame (profiles/r02_lds_top.json, r02_ubench_gather.json).
     float4 A, B, C, D;
     if ((unsigned)cur < (unsigned)n_top) {  // a fork of the top levels: its record is in LDS
         const lds_cf4 q = (lds_cf4)lds_top + 4 * cur;
