@@ -26,6 +26,8 @@ using namespace glrtx;
 
 namespace {
 
+constexpr int kFramesBudgetGiB = 32;  // device memory one glrtx_render_frames launch may use for path state and sample planes
+
 thread_local std::string g_create_error;
 
 struct DevBuf {
@@ -385,14 +387,9 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const int tiles8_x = (c->width + 7) / 8, tiles8_y = (c->owned_rows + 7) / 8;
     const size_t total = (size_t)tiles8_x * tiles8_y * 64;
     if (total * 2 >= (size_t)INT32_MAX) return fail(c, GLRTX_EINVAL, "image too large for the wgwf variant");
-    int shift = 31;
-    if (n_frames > 1) {
-        shift = 6;
-        while (((size_t)1 << shift) < total) shift++;
-        if (((size_t)n_frames << shift) * 2 >= (size_t)INT32_MAX)
-            return fail(c, GLRTX_EINVAL, "glrtx_render_frames: %d frames of %zu pixels exceed the 32-bit path id space", n_frames, total);
-    }
-    const size_t ids = n_frames > 1 ? ((size_t)n_frames << shift) : total;
+    const size_t ids = total * (size_t)n_frames;  // id = frame * total + pixel
+    if (2 * ids + 1 >= (size_t)UINT32_MAX)
+        return fail(c, GLRTX_EINVAL, "glrtx_render_frames: %d frames of %zu pixels exceed the 32-bit ray id space", n_frames, total);
     int rc;
     if ((rc = ensure(c, c->wfState, kWfStatePlanes * ids * sizeof(float4)))) return rc;
     WfArgs w;
@@ -404,8 +401,6 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     w.refill_min = kRefillMin;
     if (const char *v = std::getenv("GLRTX_REFILL_MIN")) w.refill_min = std::max(1, std::min(64, std::atoi(v)));
     w.n_frames = n_frames;
-    w.frame_shift = shift;
-    w.pid_mask = shift >= 31 ? INT32_MAX : (1 << shift) - 1;
     w.tiles_per_frame = (int)(total >> 6);
     const size_t plane_f4 = (size_t)a.pitch_f4 * (size_t)c->owned_rows;
     const int n_planes = n_frames * p->n_samples;
@@ -456,7 +451,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // every workgroup of the grid has its own queue slice; a slice holds both halves of the double-buffered ray queue
     // (2 rays per live path: the next ray and the shadow ray) and of the path-id queue; every (frame, sample) has its plane.
     {
-        const size_t max_id = (n_frames > 1 ? ((size_t)(n_frames - 1) << shift) : 0) | (total - 1);
+        const size_t max_id = ids - 1;
         const size_t slice_f4 = 2 * (size_t)2 * 2 * block_paths /* ray records */ + (3 * (size_t)block_paths * sizeof(unsigned) + 15) / 16 /* path ids [2] + shading order */;
         bool ok = max_id < ids && 2 * max_id + 1 < (size_t)WF_INVALID && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
                   block_paths <= kWgPathsMax && slice_f4 <= kWgQueueF4 && c->wfQ.bytes >= (size_t)grid * kWgQueueF4 * sizeof(float4) &&
@@ -776,19 +771,16 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
         }
         return GLRTX_OK;
     }
-    // Frames per launch are bounded by device memory: path state (104 B per id, id stride = next power of two of the
-    // owned pixels) plus one float4 plane per sample.  A longer request is issued as several launches, in order.
+    // Frames per launch are bounded by a FIXED memory budget (path state: kWfStatePlanes float4 per owned pixel and frame, plus one
+    // float4 plane per sample) -- not by what happens to be free on the device, so that the launch shapes, and with them the timing,
+    // do not depend on what else runs there.  A longer request is issued as several launches, in order.  GLRTX_FRAMES_BUDGET_MB
+    // overrides the default (tests).  An allocation that fails is reported, not worked around.
     HIP_TRY(c, hipSetDevice(c->device));
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
     const size_t px = (size_t)((c->width + 7) / 8) * (size_t)((c->owned_rows + 7) / 8) * 64;
-    size_t stride = 64;
-    while (stride < px) stride <<= 1;
-    const size_t held = c->wfPlanes.bytes + c->wfState.bytes;  // already ours, reusable
-    const size_t per_frame = stride * kWfStatePlanes * sizeof(float4) + (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
-    size_t budget = std::min<size_t>((size_t)48 << 30, (free_b + held) / 2);
-    if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;  // tests
-    const size_t id_cap = (((size_t)1 << 30) - 1) / stride;  // path ids are 31-bit, ray ids twice that
+    const size_t per_frame = px * kWfStatePlanes * sizeof(float4) + (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
+    size_t budget = (size_t)kFramesBudgetGiB << 30;
+    if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
+    const size_t id_cap = (((size_t)1 << 31) - 2) / std::max<size_t>(px, 1);  // ray ids are 2 id + shadow bit, below 0xFFFFFFFF
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, id_cap), budget / std::max<size_t>(per_frame, 1)));
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int n = std::min(chunk, n_frames - f0);

@@ -1250,16 +1250,19 @@ struct WfArgs {
     int block_paths;  // paths a workgroup keeps alive (power of two, 256 .. kWgPathsMax)
     int gss_div;      // top-up requests are capped at ceil(tiles left / gss_div); 0 = uncapped
     // Frames in flight (glrtx_render_frames): n_frames consecutive frames that differ only in u_seed run in ONE launch.
-    // Path ids are (frame << frame_shift) | tile-order pixel id; every finished sample is stored in its own plane
+    // Path ids are frame * total + tile-order pixel id; every finished sample is stored in its own plane
     // (frame * n_samples + sample) and accumulate_planes_kernel adds the planes to the accumulator in frame order, so
     // the sums are formed in exactly the order consecutive launches would form them.  n_frames == 1: samples are
     // added to the accumulator directly and seeds/planes are unused.
     const float2 *seeds;  // u_seed of every frame
     float4 *planes;       // [n_frames * n_samples][owned_rows][pitch_f4] of {min(L, 100), -}
     int n_frames;
-    int frame_shift;      // log2 of the id stride between frames (31 for a single frame)
-    int pid_mask;         // (1 << frame_shift) - 1
     int tiles_per_frame;  // total >> 6
+    // id = frame * total + tile-order pixel id (exact stride: no padding of the state arrays to a power of two)
+    DEV void split(int id, int &frame, int &pid) const {
+        if (n_frames > 1) { frame = (int)((unsigned)id / (unsigned)total); pid = id - frame * total; }
+        else { frame = 0; pid = id; }
+    }
 };
 // meta word of the path state: depth in bits 0-7 (it reaches max_depth before the path ends), sample index in bits 8-27.
 // The host sends launches beyond these ranges to the persistent megakernel (glrtx_render).
@@ -1272,7 +1275,8 @@ constexpr unsigned WF_INVALID = 0xFFFFFFFFu; // queue entry to skip
 constexpr int kRefillMin = 16;               // refill a traversal wave once this many lanes are idle
 
 DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lrow) {
-    const int pid = id & w.pid_mask;
+    int frame, pid;
+    w.split(id, frame, pid);
     const int t = pid >> 6, k = pid & 63;
     lx = (t % w.tiles8_x) * 8 + (k & 7);
     lrow = (t / w.tiles8_x) * 8 + (k >> 3);
@@ -1282,7 +1286,9 @@ DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lr
 // u_seed of the frame a path belongs to
 DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, int id) {
     if (w.n_frames > 1) {
-        const nfloat2 v = ((glb_cf2)w.seeds)[id >> w.frame_shift];
+        int frame, pid;
+        w.split(id, frame, pid);
+        const nfloat2 v = ((glb_cf2)w.seeds)[frame];
         return make_float2(v.x, v.y);
     }
     return make_float2(a.seed_x, a.seed_y);
@@ -1292,7 +1298,9 @@ DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, int id) {
 // Single frame: read-modify-write of the accumulator.  Frames in flight: the value goes to the sample's plane.
 DEV void wf_add_sample(const KernelArgs &a, const WfArgs &w, int id, int lx, int lrow, unsigned sample, float Lx, float Ly, float Lz) {
     if (w.n_frames > 1) {
-        const size_t slot = (size_t)(id >> w.frame_shift) * (size_t)a.n_samples + sample;
+        int frame, pid;
+        w.split(id, frame, pid);
+        const size_t slot = (size_t)frame * (size_t)a.n_samples + sample;
         st_stream(&w.planes[(slot * (size_t)a.owned_rows + (size_t)lrow) * (size_t)a.pitch_f4 + lx],
                   make_float4(fmin_c(Lx, 100.0f), fmin_c(Ly, 100.0f), fmin_c(Lz, 100.0f), 1.0f));
     } else {
@@ -1327,7 +1335,7 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam,
     Rng rng = {0.f, 0.f, sd.x, sd.y};
     Path P;
     unsigned sample = 0;
-    if ((id & w.pid_mask) < w.total && wf_pixel(a, w, id, lx, lrow)) {
+    if (wf_pixel(a, w, id, lx, lrow)) {  // (ids handed out by the top-up are < n_frames * total by construction)
         const int gy = local_row_to_y(a, lrow);
         const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;  // gl_FragCoord.xy
         rng.x = fcx / (float)a.width; rng.y = fcy / (float)a.height;  // :567
@@ -1773,8 +1781,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
             unsigned *pq_w = pathQ + cur * kWgPaths + np;
             const WgwfKernArgs *kt = wgwf_kernargs();
             for (int k = threadIdx.x; k < got; k += kBlockThreads) {
-                const int g = tile0 + (k >> 6), f = g / kt->w.tiles_per_frame;
-                const int id = (f << kt->w.frame_shift) | ((g - f * kt->w.tiles_per_frame) * 64 + (k & 63));
+                const int id = tile0 * 64 + k;  // tile g = tile0 + (k >> 6) of the frame-major tile order holds ids 64 g .. 64 g + 63
                 float4 ro = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID)), rd = ro;
                 const bool go = wf_generate_one(kt->a, kt->w, lds_cam, id, ro, rd);  // pixels outside the image leave skip markers
                 st_stream(&rq_w[2 * k], ro);
