@@ -418,10 +418,10 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // Top tree levels in LDS (trav_step): OFF by default -- measured on the headline config it is worth nothing (+1.6 % per frame at
     // 128 forks, -0.7..-1.4 % on configs 2/4/5 with 16-128, all inside the run-to-run spread; profiles/r02_lds_top.json): the lanes at
     // the top levels share their few cache lines with many other lanes of the wave already, so taking them off the vector-memory
-    // pipe removes almost no line fetches.  GLRTX_LDS_TOP=n stages the first n forks (as many as fit beside the traversal stacks
+    // pipe removes almost no line fetches.  In a -DGLRTX_LDS_TOP_MAX=128 build GLRTX_LDS_TOP=n stages the first n forks (as many as fit beside the traversal stacks
     // without costing a resident workgroup are: the register budget allows GLRTX_WGWF_WAVES workgroups per CU, each 1/4 of 160 KiB).
     int n_top = 0;
-    if (const char *v = std::getenv("GLRTX_LDS_TOP")) n_top = std::max(0, std::min(std::min(std::atoi(v), kTopForks), c->n_fork));
+    if (const char *v = std::getenv("GLRTX_LDS_TOP")) n_top = std::max(0, std::min(std::min(std::atoi(v), std::min(kTopForks, GLRTX_LDS_TOP_MAX)), c->n_fork));
     const int lds = lds_base + n_top * 64;
     a.sc.n_top = n_top;
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);

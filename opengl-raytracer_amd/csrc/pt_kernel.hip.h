@@ -310,15 +310,18 @@ DEV bool trav_init(const DevScene &sc, const float4 *root, Trav &T, float ox, fl
 
 // One trip of the traversal loop: process T.cur (fork or leaf), then pick the next node.
 // Returns true when the ray is finished (stack empty).
-// lds_top / n_top (wavefront kernel, GLRTX_LDS_TOP=n at run time, default 0): the first n_top forks -- the top levels of the tree,
-// numbered first by pack_scene -- are staged in LDS and read from there.  About half of a ray's fork visits are to those
+#ifndef GLRTX_LDS_TOP_MAX
+#define GLRTX_LDS_TOP_MAX 0  // experiment build: -DGLRTX_LDS_TOP_MAX=128 compiles the LDS path in, GLRTX_LDS_TOP=n selects n forks at run time
+#endif
+// lds_top / n_top (wavefront kernel; compiled in only with -DGLRTX_LDS_TOP_MAX=128, then GLRTX_LDS_TOP=n at run time): the first
+// n_top forks -- the top levels of the tree, numbered first by pack_scene -- are staged in LDS and read from there.  About half of a ray's fork visits are to those
 // levels, but it buys nothing measurable (profiles/r02_lds_top.json): the cost of a wave's node fetch is set by its number of
 // distinct cache lines (profiles/r02_ubench_gather.json), and the lanes at the top levels share theirs with many others.
 // What the experiment did find: written as below, every lane fetches its whole 56-byte record with FOUR load instructions
 // (dwordx4, dwordx4, dwordx3, dwordx3) issued together; the previous form -- three loads for all lanes, then one more and the
 // two refs as single dwords on the fork arm, six instructions -- was 8 % slower per frame for fewer bytes.
 template <bool CLOSEST>
-DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, const float4 *lds_top = nullptr, int n_top = 0) {
+DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] const float4 *lds_top = nullptr, [[maybe_unused]] int n_top = 0) {
 #ifdef GLRTX_TRAV_STATS
     trav_stats_iter(T.cur, (const void *)(sc.forks + 4 * (ptrdiff_t)T.cur), T.stop_d == -__builtin_inff());
     T.iters++;
@@ -343,12 +346,18 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, const float4 *lds_to
     // byte: fetching the fork arm's second box and refs separately (six instructions, 20 bytes less for a triangle lane) was 8 %
     // slower per frame (profiles/r02_lds_top.json, r02_ubench_gather.json).
     float4 A, B, C, D;
+#if GLRTX_LDS_TOP_MAX > 0
     if ((unsigned)cur < (unsigned)n_top) {  // a fork of the top levels: its record is in LDS
         const lds_cf4 q = (lds_cf4)lds_top + 4 * cur;
         A = to_f4(q[0]); B = to_f4(q[1]); C = to_f4(q[2]); D = to_f4(q[3]);
-    } else {
+    } else
+#endif
+    {
         A = N[0]; B = N[1]; C = N[2]; D = N[3];
     }
+    // Pin the fork-only words (the two refs, the second child's far corner) here, in front of the arms: without it the compiler
+    // sinks their loads into the fork arm and the fetch becomes six instructions instead of four (8 % slower per frame).
+    asm volatile("" : "+v"(A.w), "+v"(B.w), "+v"(D.x), "+v"(D.y), "+v"(D.z));
     // Two separate ifs, fork arm first: its extra loads (second box, refs) must go out BEFORE the triangle arithmetic of the
     // wave's leaf lanes.  (As one if / else the compiler may place the leaf arm first -- it did once the address select was
     // gone -- and the fork lanes then wait a second round trip behind it: 5 % of the frame.)
