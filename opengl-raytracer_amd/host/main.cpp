@@ -14,7 +14,7 @@
 using namespace glrt;
 
 static void usage(const char *exe) {
-    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--bvh sah|lbvh|lbvh-cpu] [--out file.png] [--save-every-frame] [--device G | --gpus N | --devices a,b,..]\n"
+    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--bvh sah|lbvh|lbvh-cpu] [--out file.png] [--save-every-frame] [--device G | --gpus N | --devices a,b,..] [--extensions] [--whitted]\n"
                 "  -i, --input             scene description (JSON; schema: SURVEY.md Appendix C)            [required]\n"
                 "  -s, --sample-per-cycle  accepted for compatibility; like the reference (main.cpp:13) it is not read\n"
                 "      --max-depth D       u_maxDepth (default 16, the reference shader's default)\n"
@@ -26,13 +26,16 @@ static void usage(const char *exe) {
                 "      --save-every-frame  write the image after every frame, one frame per launch (the reference's cadence, window.cpp:164)\n"
                 "      --device G          HIP device ordinal (default: current)\n"
                 "      --gpus N            render on HIP devices 0..N-1: interleaved 16-row stripes, gathered when the image is written\n"
-                "      --devices a,b,..    the same with an explicit device list (an ordinal may repeat)\n", exe);
+                "      --devices a,b,..    the same with an explicit device list (an ordinal may repeat)\n"
+                "      --extensions        accept what the reference does not have: shapes of type \"sphere\" (center, radius) and the material\n"
+                "                          \"dielectric\" (ior, tint); parity with the reference is not defined for such scenes\n"
+                "      --whitted           with --extensions: Whitted-style transport (direct light at diffuse surfaces, specular bounces only)\n", exe);
 }
 
 int main(int argc, char **argv) {
     std::string input, out = "output.png";
     int depth = 16, spp = 1, frames = 16, device = -1, in_flight = 0;
-    bool every_frame = false;
+    bool every_frame = false, extensions = false, whitted = false;
     std::vector<int> devices;
     std::string bvh;
     for (int i = 1; i < argc; i++) {
@@ -51,6 +54,8 @@ int main(int argc, char **argv) {
         else if (a == "--bvh") bvh = next("--bvh");
         else if (a == "--device") device = std::atoi(next("--device"));
         else if (a == "--save-every-frame") every_frame = true;
+        else if (a == "--extensions") extensions = true;
+        else if (a == "--whitted") { extensions = true; whitted = true; }
         else if (a == "--gpus") { const int n = std::atoi(next("--gpus")); devices.clear(); for (int k = 0; k < n; k++) devices.push_back(k); }
         else if (a == "--devices") {
             devices.clear();
@@ -71,6 +76,8 @@ int main(int argc, char **argv) {
 
     auto scene = std::make_shared<Scene>();
     if (!bvh.empty()) scene->setBvhBuilder(bvh);
+    scene->enableExtensions(extensions);
+    scene->setWhitted(whitted);
     scene->parse(input);
 
     window->mainloop(scene);

@@ -45,6 +45,9 @@ void Scene::parse(const std::string &filename) {
     const Json json = Json::parse(ss.str(), err);
     if (!err.empty()) GLRT_Warn("%s", err.c_str());
     const std::string baseDir = dirOf(filename);
+    if (const char *e = std::getenv("GLRT_EXTENSIONS")) extensions_ = extensions_ || std::atoi(e) != 0;
+    spheres.clear();
+    hasDielectric_ = false;
 
     // film (scene.cpp:57-60)
     width = json["film"]["width"].int_value();
@@ -99,6 +102,14 @@ void Scene::parse(const std::string &filename) {
             // The reference uploads two 3D textures here, but its shader's volume branch is compiled
             // out (raytrace.frag:4, :424-487): the material only marks the surface as pass-through.
             fill3(m.type, (float)MaterialType::Media);
+        } else if (material == "dielectric" && extensions_) {
+            // EXTENSION (no reference counterpart): MTRL_DIELECTRIC = 4 (raytrace.frag:32); param0 = tint, param1.x = index of refraction
+            fill3(m.type, 4.0f);
+            if (sh["tint"].is_null()) fill3(m.param0, 1.0f);
+            else vec3(sh["tint"], m.param0);
+            fill3(m.param1, 0.0f);
+            m.param1[0] = sh["ior"].is_null() ? 1.5f : (float)sh["ior"].number_value();
+            hasDielectric_ = true;
         } else {
             GLRT_FatalError("Unsupported material: %s", material.c_str());
         }
@@ -119,6 +130,12 @@ void Scene::parse(const std::string &filename) {
                 tri.indices[3] = (float)(materials.size() - 1);
                 triangles.push_back(tri);
             }
+        } else if (sh["type"].string_value() == "sphere" && extensions_) {  // EXTENSION: analytic sphere
+            float ctr[3] = {0.f, 0.f, 0.f};
+            if (!sh["center"].is_null()) vec3(sh["center"], ctr);
+            const float radius = sh["radius"].is_null() ? 1.0f : (float)sh["radius"].number_value();
+            if (!(radius > 0.0f)) GLRT_FatalError("sphere radius must be positive");
+            spheres.insert(spheres.end(), {ctr[0], ctr[1], ctr[2], radius, (float)(materials.size() - 1)});
         }
     }
     finalize();

@@ -41,6 +41,14 @@ public:
     int bvhDepth() const { return bvhDepth_; }
     // "sah" (default) | "lbvh" (built on the GPU) | "lbvh-cpu"; call before parse().  GLRT_BVH overrides.
     void setBvhBuilder(const std::string &kind) { bvhBuilder_ = kind; }
+    // EXTENSIONS beyond the reference (parity unpinned; include/glrtx.h).  Off, parse() is the reference's: "dielectric" is an
+    // unsupported material (FatalError, scene.cpp:216-218) and a shape that is not "obj" contributes no geometry (scene.cpp:222).
+    // On (call before parse(); GLRT_EXTENSIONS=1): material "dielectric" {"ior": n, "tint": [r,g,b]} and shape
+    // {"type": "sphere", "center": [x,y,z], "radius": r} are accepted; Window then uploads the spheres and enables
+    // GLRTX_EXT_DIELECTRIC (and GLRTX_EXT_WHITTED if setWhitted(true)).
+    void enableExtensions(bool on) { extensions_ = on; }
+    void setWhitted(bool on) { whitted_ = on; }
+    size_t numSpheres() const { return spheres.size() / 5; }
 
 private:
     void finalize();  // lights list + BVH (scene.cpp:246-256)
@@ -56,6 +64,8 @@ private:
     std::vector<BVHNode> nodes;
     int bvhDepth_ = 0;
     std::string bvhBuilder_ = "sah";
+    std::vector<float> spheres;  // extension: 5 floats per sphere {cx, cy, cz, radius, material}
+    bool extensions_ = false, whitted_ = false, hasDielectric_ = false;
 
     friend class Window;
     friend struct SceneProbe;

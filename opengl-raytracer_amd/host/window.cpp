@@ -52,6 +52,18 @@ void Window::mainloop(const std::shared_ptr<Scene> &scene_, double fps) {
         scene->materials.empty() ? nullptr : &scene->materials[0].type[0], scene->materials.size(),
         scene->lights.empty() ? nullptr : &scene->lights[0].indices[0], scene->lights.size(),
         scene->nodes.empty() ? nullptr : &scene->nodes[0].bboxMin[0], scene->nodes.size()));
+    // extensions the scene asked for (Scene::enableExtensions; none in a reference scene): analytic spheres, dielectric, Whitted
+    if (!scene->spheres.empty() || scene->hasDielectric_ || scene->whitted_) {
+        const int flags = (scene->hasDielectric_ ? GLRTX_EXT_DIELECTRIC : 0) | (scene->whitted_ ? GLRTX_EXT_WHITTED : 0);
+        for (int i = 0; i < glrtx_group_size(grp_); i++) {
+            glrtx_ctx *c = glrtx_group_ctx(grp_, i);
+            if (glrtx_upload_spheres(c, scene->spheres.empty() ? nullptr : scene->spheres.data(), scene->spheres.size() / 5) != GLRTX_OK ||
+                glrtx_set_extensions(c, flags) != GLRTX_OK)
+                GLRT_FatalError("extensions: %s", glrtx_last_error(c));
+        }
+        GLRT_Info("extensions: %zu analytic spheres%s%s (not part of the reference)", scene->spheres.size() / 5,
+                  scene->hasDielectric_ ? ", dielectric" : "", scene->whitted_ ? ", Whitted termination" : "");
+    }
     resize(scene->width, scene->height);
     initialize();
     // The reference presents (and saves) every frame; when only the final image is wanted the frames of a static

@@ -94,6 +94,64 @@ def test_glrt_main_on_several_partitions_writes_the_identical_png(tmp_path):
     assert pngs["one"] == pngs["two"] == pngs["three"] == pngs["every"]
 
 
+def _sphere_scene_json(tmp_path, w, h):
+    """BASELINE configs[0] read literally ("3 spheres + 1 ground plane") as a JSON scene for the facade's extension syntax, plus
+    the same scene as flat buffers + sphere rows for the C ABI."""
+    import json
+    b = scenes.SceneBuilder()
+    grey = b.add_material(scenes.diffuse((0.7, 0.7, 0.7)))
+    lamp = b.add_material(scenes.emitter((10.0, 10.0, 10.0)))
+    b.add_mesh(*scenes.quad((-10, 0, 10), (20, 0, 0), (0, 0, -20)), grey)
+    b.add_mesh(*scenes.quad((-1, 5, -1), (2, 0, 0), (0, 0, 2)), lamp)
+    js = scenes.export_json_obj(b, tmp_path, w, h, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0)
+    doc = json.loads(js.read_text())
+    doc["scene"] += [
+        {"type": "sphere", "center": [-2.2, 1.0, 0.0], "radius": 1.0, "material": "diffuse", "reflectance": [0.8, 0.3, 0.3]},
+        {"type": "sphere", "center": [0.0, 1.0, 0.0], "radius": 1.0, "material": "dielectric", "ior": 1.5},
+        {"type": "sphere", "center": [2.2, 1.0, 0.0], "radius": 1.0, "material": "diffuse", "reflectance": [0.7, 0.7, 0.7]},
+    ]
+    js.write_text(json.dumps(doc, indent=1))
+    red = b.add_material(scenes.diffuse((0.8, 0.3, 0.3)))
+    glass = b.add_material(scenes.dielectric(1.5))
+    grey2 = b.add_material(scenes.diffuse((0.7, 0.7, 0.7)))
+    spheres = np.array([[-2.2, 1.0, 0.0, 1.0, red], [0.0, 1.0, 0.0, 1.0, glass], [2.2, 1.0, 0.0, 1.0, grey2]], np.float32)
+    return js, b.build(), spheres
+
+
+def test_glrt_main_extension_scene_matches_the_c_abi(tmp_path, gpu_device):
+    """glrt_main --extensions on a JSON scene with "sphere" shapes and a "dielectric" material (syntax of this build, not of the
+    reference) == the same scene through glrtx_upload_spheres / glrtx_set_extensions; without --extensions the dielectric is
+    the reference's "Unsupported material" abort, and sphere shapes alone are ignored like any non-obj shape."""
+    from PIL import Image
+    from glrt_amd import device
+    w, h, depth, frames = 96, 64, 6, 3
+    js, scene, spheres = _sphere_scene_json(tmp_path, w, h)
+    out = tmp_path / "ext.png"
+    cmd = [str(PKG / "lib" / "glrt_main"), "-i", str(js), "--max-depth", str(depth), "--frames", str(frames), "--out", str(out)]
+    r = subprocess.run(cmd + ["--extensions"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "3 analytic spheres, dielectric" in r.stdout
+    img = np.asarray(Image.open(out))
+    c2w, s2c = scenes.camera((0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0, w, h)
+    params = scenes.make_params(c2w, s2c, w, h, depth, 1)
+    d = gpu_device
+    d.upload_scene(scene)
+    d.upload_spheres(spheres)
+    d.set_extensions(device.EXT_DIELECTRIC)
+    try:
+        d.set_partition(0, 1, 16)
+        d.resize(w, h)
+        for f in range(frames):
+            d.render(dict(params, seed=host.frame_seed(f), focal=0.0))
+        d.sync()
+        assert np.array_equal(img, d.resolve_rgba8(2.2, True))
+    finally:
+        d.set_extensions(0)
+        d.upload_spheres(None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "Unsupported material: dielectric" in (r.stdout + r.stderr)
+
+
 def test_glrt_main_requires_input():
     r = subprocess.run([str(PKG / "lib" / "glrt_main")], capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stdout
