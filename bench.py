@@ -10,7 +10,7 @@ frame with a fresh u_seed, window.cpp:121-169, :226-252) on the 1920x1080 image 
 per pixel and frame, every frame added to the resident float4 accumulator.
 
 One STEP = one pass of the hot path over one batch: with N ranks a step is N consecutive frames of that loop,
-the image rows sharded over the ranks in interleaved 16-row stripes (one process per GPU, global pixel
+the image rows sharded over the ranks in interleaved 8-row stripes (one process per GPU, global pixel
 coordinates, no data-path collective).  Every GPU therefore traces one full frame's worth of paths
 (2,073,600) per step whatever N is -- "scaling": "weak"; at N = 1 a step is exactly one frame.  The JSON line
 reports ms_per_step and config.ms_per_frame = ms_per_step / N.
@@ -55,7 +55,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_GINST = 1024 * 2.4 / 2  # wave64 VALU instructions/ns the chip can issue: 1024 SIMDs x 2.4 GHz / 2 cycles each
-STRIPE = 16
+STRIPE = 8  # rows per stripe: 1080 rows over 8 ranks = 136 / 128 rows per rank (16-row stripes: 144 / 128, 6.7 % off balance)
 STEPS_PER_LAUNCH = 24  # frames' worth of paths in flight on every GPU per launch (frames in flight; 8 / 16 / 32: 2.19 / 2.04 / 1.97 ms in round 1)
 
 # Test hook: tests/ replace this with a factory of CPU renderers (same interface as GpuRenderer) to rehearse the

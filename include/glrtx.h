@@ -125,7 +125,8 @@ int glrtx_clear(glrtx_ctx *ctx);
 
 /* Row-stripe partition for multi-GPU: this ctx owns stripes s (of stripe_rows rows) with
  * s % world == rank; its accumulator holds only those rows, in increasing y, pixel coordinates
- * stay global.  Default (rank 0, world 1) owns everything.  Must precede glrtx_resize. */
+ * stay global.  stripe_rows: a multiple of 8 (whole 8x8 work tiles).  Default (rank 0, world 1) owns everything.
+ * Must precede glrtx_resize. */
 int glrtx_set_partition(glrtx_ctx *ctx, int rank, int world, int stripe_rows);
 /* Global y of local accumulator row r (r in [0, owned_rows)), or -1. */
 int glrtx_local_row_to_y(const glrtx_ctx *ctx, int local_row);

@@ -26,6 +26,8 @@ using namespace glrtx;
 
 namespace {
 
+constexpr int kStripeQuantum = 8;   // stripe heights are multiples of the 8x8 work tile
+constexpr int kGroupStripe = 8;     // stripe height glrtx_group uses: 1080 rows over 8 members = 136 / 128 rows (16-row stripes: 144 / 128)
 constexpr int kFramesBudgetGiB = 32;  // device memory one glrtx_render_frames launch may use for path state and sample planes
 
 thread_local std::string g_create_error;
@@ -666,8 +668,8 @@ int glrtx_set_partition(glrtx_ctx *c, int rank, int world, int stripe_rows) {
     if (!c) return GLRTX_EINVAL;
     if (world < 1 || rank < 0 || rank >= world || stripe_rows < 1)
         return fail(c, GLRTX_EINVAL, "glrtx_set_partition: bad rank/world/stripe %d/%d/%d", rank, world, stripe_rows);
-    if (stripe_rows % kTile != 0)
-        return fail(c, GLRTX_EINVAL, "glrtx_set_partition: stripe_rows must be a multiple of %d", kTile);
+    if (stripe_rows % kStripeQuantum != 0)  // whole 8x8 work tiles per stripe (pixel -> row mapping itself works for any stripe height)
+        return fail(c, GLRTX_EINVAL, "glrtx_set_partition: stripe_rows must be a multiple of %d", kStripeQuantum);
     if (c->bound && c->width > 0 && owned_rows_of(c->height, rank, world, stripe_rows) > c->bound_rows)
         return fail(c, GLRTX_EINVAL, "glrtx_set_partition: the new partition does not fit the bound accumulator (%d rows); unbind it first", c->bound_rows);
     c->rank = rank; c->world = world; c->stripe = stripe_rows;
@@ -1131,7 +1133,7 @@ int glrtx_group_resize(glrtx_group *g, int width, int height) {
     const int n = (int)g->ctx.size();
     for (int i = 0; i < n; i++) {
         glrtx_ctx *c = g->ctx[i];
-        c->rank = i; c->world = n; c->stripe = kTile;  // == glrtx_set_partition(c, i, n, 16) without the intermediate resize
+        c->rank = i; c->world = n; c->stripe = kGroupStripe;  // == glrtx_set_partition(c, i, n, 8) without the intermediate resize
         if (int rc = gsub(g, i, glrtx_resize(c, width, height))) return rc;
     }
     g->width = width; g->height = height;

@@ -246,7 +246,7 @@ class Device:
 
 
 class Group:
-    """glrtx_group: one context per listed HIP device (an ordinal may repeat), the image rows in interleaved 16-row stripes;
+    """glrtx_group: one context per listed HIP device (an ordinal may repeat), the image rows in interleaved 8-row stripes;
     read_accum / resolve_rgba8 return the FULL image, gathered on the first device."""
 
     def __init__(self, device_ids):

@@ -82,21 +82,21 @@ def test_full_size_determinism_and_partition_invariance(gpu_device):
     assert st.rays > 2 * 1920 * 1080 and np.all(full[..., 3] == 1.0)
     assert np.isfinite(full).all() and full[..., :3].max() <= 100.0 and full[..., :3].min() >= 0.0
     h = params["height"]
-    for world in (2, 8):
+    for world, stripe in ((2, 16), (8, 8), (8, 24)):  # 8 rows = what bench.py and glrtx_group use
         stitched = np.zeros_like(full)
         total_rays = 0
         for rank in range(world):
-            d.set_partition(rank, world, 16)
+            d.set_partition(rank, world, stripe)
             d.resize(params["width"], h)
             d.reset_stats()
             d.count_rays(True)
             d.render(params)
             d.sync()
-            ys = dist.owned_rows(rank, world, 16, h)
+            ys = dist.owned_rows(rank, world, stripe, h)
             assert np.array_equal(d.local_rows_y(), ys)
             stitched[ys] = d.read_accum()
             total_rays += d.stats().rays
-        assert_bit_equal(stitched, full, f"world {world}")
+        assert_bit_equal(stitched, full, f"world {world}, {stripe}-row stripes")
         assert total_rays == st.rays
     d.set_partition(0, 1, 16)
 
@@ -287,7 +287,7 @@ def test_frames_in_flight_full_size_partitions_and_accumulate_on_top(gpu_device)
     try:
         stitched = np.zeros_like(seq)
         for rank in range(3):
-            d.set_partition(rank, 3, 16); d.resize(params["width"], params["height"])
+            d.set_partition(rank, 3, 8); d.resize(params["width"], params["height"])
             d.render_frames(params, seeds); d.sync()
             stitched[d.local_rows_y()] = d.read_accum()
         assert_bit_equal(stitched, seq, "frames in flight, 3-rank partition")
