@@ -192,7 +192,7 @@ int glrtx_set_extensions(glrtx_ctx *ctx, int flags);
 
 /* ---- Groups: the same device layer on several GPUs of one node, behind one handle and one host thread.
  * No reference counterpart (the reference is single-GPU); SURVEY.md 8(b) sketches glrtx_create(ctx**, device_ids, n) with a
- * gathering read_accum -- this is that, kept apart from the single-context calls.  Member i owns the 16-row stripes s with
+ * gathering read_accum -- this is that, kept apart from the single-context calls.  Member i owns the 8-row stripes s with
  * s % n == i (global pixel coordinates, resident accumulator rows, its own stream); rendering exchanges nothing; read_accum
  * and resolve_rgba8 first copy the stripes device-to-device into a full frame on member 0's GPU (xGMI peer copies), i.e. they
  * return the FULL image.  device_ids may name the same GPU more than once (partition emulation, used by the tests).

@@ -1008,7 +1008,7 @@ int glrtx_timer_end(glrtx_ctx *c, float *ms) {
 
 // ---------------------------------------------------------------------------------------------------------------- groups
 // Several contexts -- one per GPU of the node -- behind one handle, driven by one host thread: the multi-GPU form of the
-// same entry points.  Context i owns the 16-row stripes s with s % n == i (glrtx_set_partition), renders
+// same entry points.  Context i owns the 8-row stripes s with s % n == i (glrtx_set_partition), renders
 // them on its own stream with global pixel coordinates, and keeps its accumulator rows resident.  Nothing is exchanged while
 // rendering.  Only when an image is wanted (read_accum / resolve) are the stripes copied, device to device, into a full-frame
 // buffer on the first context's GPU (peer copies over xGMI; hipMemcpyPeerAsync also serves the same-device case the tests use).

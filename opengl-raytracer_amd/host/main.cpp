@@ -25,7 +25,7 @@ static void usage(const char *exe) {
                 "      --out file.png      tonemapped output (default output.png, written after the last frame)\n"
                 "      --save-every-frame  write the image after every frame, one frame per launch (the reference's cadence, window.cpp:164)\n"
                 "      --device G          HIP device ordinal (default: current)\n"
-                "      --gpus N            render on HIP devices 0..N-1: interleaved 16-row stripes, gathered when the image is written\n"
+                "      --gpus N            render on HIP devices 0..N-1: interleaved 8-row stripes, gathered when the image is written\n"
                 "      --devices a,b,..    the same with an explicit device list (an ordinal may repeat)\n"
                 "      --extensions        accept what the reference does not have: shapes of type \"sphere\" (center, radius) and the material\n"
                 "                          \"dielectric\" (ior, tint); parity with the reference is not defined for such scenes\n"

@@ -34,7 +34,7 @@ public:
     void setSamplesPerFrame(int spp) { samplesPerFrame_ = spp; }
     void setOutput(const std::string &file, bool everyFrame = false) { output_ = file; saveEveryFrame_ = everyFrame; }
     void setDevice(int hipDevice) { devices_.assign(1, hipDevice); }
-    // Several GPUs of the node (no reference counterpart): the image rows are split into interleaved 16-row stripes, one share per
+    // Several GPUs of the node (no reference counterpart): the image rows are split into interleaved 8-row stripes, one share per
     // listed HIP device, rendered concurrently and gathered on the first one when a frame is saved (glrtx_group, include/glrtx.h).
     // The same ordinal may be listed more than once.  The image is bit-identical to the single-GPU one.  GLRT_GPUS=N = devices 0..N-1.
     void setDevices(const std::vector<int> &hipDevices) { if (!hipDevices.empty()) devices_ = hipDevices; }
