@@ -415,8 +415,8 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     }
 
     const int lds_base = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
-                         16 * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block
-                         ((int)sizeof(ShadeSortLds) + 15) / 16 * 16;
+                         16 * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block |
+                         kWgPathsMax / 8;  // light-test bits, one per path-queue position
     // Top tree levels in LDS (trav_step): OFF by default -- measured on the headline config it is worth nothing (+1.6 % per frame at
     // 128 forks, -0.7..-1.4 % on configs 2/4/5 with 16-128, all inside the run-to-run spread; profiles/r02_lds_top.json): the lanes at
     // the top levels share their few cache lines with many other lanes of the wave already, so taking them off the vector-memory
@@ -454,7 +454,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // (2 rays per live path: the next ray and the shadow ray) and of the path-id queue; every (frame, sample) has its plane.
     {
         const size_t max_id = ids - 1;
-        const size_t slice_f4 = 2 * (size_t)2 * 2 * block_paths /* ray records */ + (3 * (size_t)block_paths * sizeof(unsigned) + 15) / 16 /* path ids [2] + shading order */;
+        const size_t slice_f4 = 2 * (size_t)2 * 2 * block_paths /* ray records */ + (2 * (size_t)block_paths * sizeof(unsigned) + 15) / 16 /* path ids [2] */;
         bool ok = max_id < ids && 2 * max_id + 1 < (size_t)WF_INVALID && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
                   block_paths <= kWgPathsMax && slice_f4 <= kWgQueueF4 && c->wfQ.bytes >= (size_t)grid * kWgQueueF4 * sizeof(float4) &&
                   c->wfState.bytes >= kWfStatePlanes * ids * sizeof(float4) && w.ids == ids && grid >= 1 && grid <= resident &&

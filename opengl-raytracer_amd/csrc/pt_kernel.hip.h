@@ -1237,12 +1237,13 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
 // queues -- was built and measured first: 5.3 ms per headline frame, of which ~3.4 ms was nine
 // device-wide waits for each trip's longest ray.  The workgroup-local form below replaced it.)
 struct WfArgs {
-    // Path state: seven float4-wide planes of `ids` entries each in ONE allocation (one base pointer and one stride in scalar
-    // registers instead of seven pointers), plane k of path id at state[k * ids + id]:
+    // Path state: six float4-wide planes of `ids` entries each in ONE allocation (one base pointer and one stride in scalar
+    // registers instead of six pointers), plane k of path id at state[k * ids + id]:
     //   0: {next ray origin (= shadow ray origin), rng.x}      1: {next ray direction, rng.y}
     //   2: {beta, meta}   meta = depth | sample << 8 | flags   3: {L if the pending light sample is accepted (or L), dist}
     //   4: {L if it is rejected, -}                             5: closest hit of the path's ray {t, tri, u, v}
-    //   6: closest hit of the shadow ray {t, tri} (first 8 bytes of the entry)
+    // (a shadow ray leaves no record in memory: the traversal lane evaluates the light test of :367 itself and sets one bit,
+    //  indexed by the owning path's position in the workgroup's path queue, in LDS)
     // (ray origins/directions for the traversal travel in the workgroup's ray queue: 32-byte records
     //  {origin, ray id} {direction, -} in queue order, read with unit stride)
     float4 *state;
@@ -1252,7 +1253,6 @@ struct WfArgs {
     DEV size_t plane(int k) const { size_t n = ids; asm volatile("" : "+s"(n)); return (size_t)k * n; }
     DEV float4 *A(int k, unsigned id) const { return state + plane(k) + id; }
     DEV float4 *H(unsigned id) const { return state + plane(5) + id; }
-    DEV float2 *HS(unsigned id) const { return reinterpret_cast<float2 *>(state + plane(6) + id); }
     int total;        // tile-order ids: tiles8_x * tiles8_y * 64
     int tiles8_x;
     int refill_min;   // refill a traversal wave once this many lanes are idle
@@ -1275,7 +1275,7 @@ struct WfArgs {
 };
 // meta word of the path state: depth in bits 0-7 (it reaches max_depth before the path ends), sample index in bits 8-27.
 // The host sends launches beyond these ranges to the persistent megakernel (glrtx_render).
-constexpr int kWfStatePlanes = 7;  // float4-wide planes of WfArgs::state
+constexpr int kWfStatePlanes = 6;  // float4-wide planes of WfArgs::state
 constexpr int kWfDepthMax = 255;
 constexpr int kWfSampleMax = (1 << 20) - 1;
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
@@ -1364,7 +1364,7 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam,
 // One path of the shade stage: resolve the light sample of the previous bounce, then either close the
 // sample (and start the pixel's next one) or run shade_hit() on the new hit.  Outputs which rays to
 // queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray.
-DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, unsigned id, bool &push_ext, bool &push_sh,
+DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, unsigned id, bool light_accepted, bool &push_ext, bool &push_sh,
                        float4 &ray_o, float4 &ray_d, float4 &ray_sd, unsigned long long &rays) {
     int lx, lrow;
     wf_pixel(a, w, (int)id, lx, lrow);
@@ -1382,8 +1382,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     // resolve the light sample of the previous bounce (:367, :539)
     P.Lx = s3.x; P.Ly = s3.y; P.Lz = s3.z;
     if (meta & WF_PENDING) {
-        const float2 hs = ld_stream(w.HS(id));
-        if (!nee_accepted(s3.w, hs.x, __float_as_int(hs.y) >= 0)) {
+        if (!light_accepted) {  // the traversal lane's verdict on the shadow ray (nee_accepted), one bit per path
             const float4 s4 = ld_stream(w.A(4, id));
             P.Lx = s4.x; P.Ly = s4.y; P.Lz = s4.z;
         }
@@ -1442,7 +1441,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 #endif
 constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes its queues); the host picks block_paths <= this so
                                    // that the launch has that many pixels for every resident workgroup
-constexpr size_t kWgQueueF4 = 8 * (size_t)kWgPathsMax + 3 * (size_t)kWgPathsMax / 4;  // float4 units per workgroup: ray records + path ids [2] + shading order
+constexpr size_t kWgQueueF4 = 8 * (size_t)kWgPathsMax + (size_t)kWgPathsMax / 2;  // float4 units per workgroup: ray records + path ids [2]
 #ifndef GLRTX_WGWF_WAVES
 #define GLRTX_WGWF_WAVES 4
 #endif
@@ -1462,7 +1461,7 @@ __device__ uint4 g_trip_log[16][64];
 #endif
 
 // Traverse phase of one trip, run by a whole workgroup: lanes pull the workgroup's queued rays and a lane whose ray
-// is finished takes the next one once refill_min lanes of its wave are idle.  Hit records go to w.H / w.HS.
+// is finished takes the next one once refill_min lanes of its wave are idle.  Path-ray hits go to w.H, shadow-ray verdicts to light_bits.
 // The queue holds the rays themselves (32-byte records {origin, ray id} {direction, -}); every wave keeps one chunk of 64
 // records in registers -- lane l holds record l -- fetched with unit stride (64 at a time through *ray_head, an LDS
 // counter).  A refill therefore touches no memory: the idle lane with rank r takes the record held by lane
@@ -1471,7 +1470,7 @@ __device__ uint4 g_trip_log[16][64];
 // again after the kernel lost its spills it bought nothing (profiles/r02_ab_occupancy.txt) and its 8 registers were freed.)
 template <bool VINE>
 DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, const float4 *lds_top, int *stack, const float4 *rq, int n_rays,
-                           unsigned *ray_head, unsigned long long &rays) {
+                           unsigned *ray_head, unsigned *light_bits, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
     if (VINE) {  // list scan: every ray takes the same number of steps, so waves simply take 64 rays at a time
         for (;;) {
@@ -1487,7 +1486,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
                                           shadow ? d.w : -__builtin_inff());
             if (r != WF_INVALID) {
                 rays++;
-                if (r & 1u) st_stream(w.HS(r >> 1), make_float2(h.t, __int_as_float(h.tri)));
+                if (r & 1u) { if (nee_accepted(d.w, h.t, h.tri >= 0)) atomicOr(&light_bits[r >> 6], 1u << ((r >> 1) & 31u)); }
                 else st_stream(w.H(r >> 1), make_float4(h.t, __int_as_float(h.tri), h.u, h.v));
             }
         }
@@ -1522,9 +1521,10 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
     T.cur = 0; T.sp = 0;
     T.h.t = PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
     auto save_hit = [&]() {
-        const unsigned id = rid >> 1;
-        if (rid & 1u) st_stream(w.HS(id), make_float2(T.h.t, __int_as_float(T.h.tri)));
-        else st_stream(w.H(id), make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v));
+        const unsigned id = rid >> 1;  // path id (path ray) or the path's position in the workgroup's path queue (shadow ray)
+        if (rid & 1u) {  // the light test of :367, decided here (T.stop_d is the light sample's distance): one bit for the shade phase
+            if (nee_accepted(T.stop_d, T.h.t, T.h.tri >= 0)) atomicOr(&light_bits[id >> 5], 1u << (id & 31u));
+        } else st_stream(w.H(id), make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v));
         unsaved = false;
     };
     for (;;) {
@@ -1590,85 +1590,11 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
 // goes through wf_shade_path(); the rays and paths of the next trip are appended to rq_next / pq_next
 // (wave-aggregated, one LDS atomic per wave and queue on *n_rays_next / *n_paths_next).
 //
-// The paths are shaded in the order of a stable 3-way partition by the KIND of work their iteration of the depth loop
-// is (GLRTX_SHADE_SORT): 0 = nearly none (the ray missed, the path only awaits its last shadow ray, a material with
-// neither BSDF branch), 1 = diffuse (:511-519), 2 = conductor (:520-532).  shade_hit() is ~1800 vector instructions
-// when a wave holds all kinds -- every lane waits through every branch -- of which a diffuse wave needs ~1000 and a
-// wave of misses ~100; left in pixel order 26 of 64 lanes were active per instruction.  A path's arithmetic does not
-// depend on its neighbours in the wave, so results are unchanged.  The partition is stable: inside each class the
-// paths stay in pixel order.
-// MEASURED AND SWITCHED OFF (profiles/r02_shade_sort.txt): bit-identical, but 9 % SLOWER per frame.  The shade phase is
-// bound by its chains of dependent loads (state, triangle, normals, light, materials), not by vector-instruction issue
-// (the co-resident traversal waves run at raised priority and the SIMDs' VALU is 39 % busy overall), so removing
-// instructions from it buys nothing, while the partition costs three more barriers per trip and turns the unit-stride
-// state loads of a wave into three (then nine, ...) runs.  Kept behind the macro for the record.
-#ifndef GLRTX_SHADE_SORT
-#define GLRTX_SHADE_SORT 0
-#endif
-constexpr int kSortChunks = kWgPathsMax / 64;  // 64-path wave chunks of a full path queue
-struct ShadeSortLds {                          // LDS scratch of the partition (1.75 KiB)
-    unsigned long long key_lo[kSortChunks], key_hi[kSortChunks];  // per wave chunk: bit l = key bit of the chunk's l-th path
-    unsigned offs[3][kSortChunks];                                // per class and wave chunk: count, then first output position
-    unsigned total;
-};
-
-// Class of path `id` (see above); WF_INVALID queue entries (pixels outside the image) get 3 = dropped.
-DEV int wf_shade_class(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, unsigned id) {
-    if (id == WF_INVALID) return 3;
-    const unsigned meta = __float_as_uint(ld_stream(w.A(2, id)).w);
-    if (meta & WF_FINISHING) return 0;
-    const int tri = __float_as_int(ld_stream(w.H(id)).y);
-    if (tri < 0) return 0;
-    const int m = __float_as_int(a.sc.forks[4 * (ptrdiff_t)(~tri)].w);
-    const int type = __float_as_int(load_mat(a.sc, lds_mats, m).m0.w);
-    return type == 2 ? 1 : (type == 3 ? 2 : 0);
-}
-
-// pq[0..n_paths) -> sorted[0..n_sorted): stable partition by class; returns n_sorted.  Called by the whole workgroup.
-DEV int wg_shade_sort(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const unsigned *pq, int n_paths, unsigned *sorted,
-                      ShadeSortLds *L) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int n_chunks = (n_paths + 63) >> 6;
-    for (int c = wave; c < n_chunks; c += kBlockThreads / 64) {  // classify
-        const int i = c * 64 + lane;
-        const int key = wf_shade_class(a, w, lds_mats, i < n_paths ? pq[i] : WF_INVALID);
-        const unsigned long long lo = __ballot(key & 1), hi = __ballot(key & 2);
-        if (lane == 0) {
-            L->key_lo[c] = lo; L->key_hi[c] = hi;
-            L->offs[0][c] = (unsigned)__popcll(~lo & ~hi); L->offs[1][c] = (unsigned)__popcll(lo & ~hi); L->offs[2][c] = (unsigned)__popcll(~lo & hi);
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {  // exclusive prefix over (class, chunk): one 64-lane scan per class
-        unsigned base = 0;
-        for (int k = 0; k < 3; k++) {
-            const unsigned v = lane < n_chunks ? L->offs[k][lane] : 0u;
-            unsigned incl = v;
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned t = (unsigned)__shfl_up((int)incl, d);
-                if (lane >= d) incl += t;
-            }
-            if (lane < n_chunks) L->offs[k][lane] = base + incl - v;
-            base += (unsigned)__shfl((int)incl, 63);
-        }
-        if (lane == 0) L->total = base;
-    }
-    __syncthreads();
-    for (int c = wave; c < n_chunks; c += kBlockThreads / 64) {  // scatter
-        const int i = c * 64 + lane;
-        const unsigned long long lo = L->key_lo[c], hi = L->key_hi[c];
-        const int key = (int)((lo >> lane) & 1ull) | ((int)((hi >> lane) & 1ull) << 1);
-        if (key < 3) {
-            const unsigned long long mine = (key & 1 ? lo : ~lo) & (key & 2 ? hi : ~hi);
-            sorted[L->offs[key][c] + (unsigned)__popcll(mine & lt_mask)] = pq[i];
-        }
-    }
-    __syncthreads();  // `sorted` complete (same CU: its stores are visible to the workgroup's other waves)
-    return (int)L->total;
-}
-
-DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, const unsigned *pq, int n_paths,
+// (Shading the paths in a stable partition by material class -- diffuse / conductor / nothing to do -- was built and measured in
+// round 2: bit-identical, 9 % slower per frame; profiles/r02_shade_sort.txt, removed.)
+// Shadow rays: the light test's verdict for the path at queue position i is bit i of `light_bits` (LDS), set by the traversal
+// lane that finished the path's shadow ray; the shadow ray pushed here carries the position its path will have in pq_next.
+DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, const unsigned *light_bits, const unsigned *pq, int n_paths,
                         float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1678,10 +1604,8 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         unsigned id = WF_INVALID;
         float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro, rsd = ro;
         if (i < n_paths) id = pq[i];
-        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, cam, id, push_ext, push_sh, ro, rd, rsd, rays);
-#ifdef GLRTX_PHASE_STATS
-        if (lane == 0) { atomicAdd(&g_phase_cycles[7], 1ull); }  // wave chunks shaded
-#endif
+        const bool light_accepted = i < n_paths && ((light_bits[i >> 5] >> (i & 31)) & 1u) != 0u;
+        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, cam, id, light_accepted, push_ext, push_sh, ro, rd, rsd, rays);
         const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
         unsigned br = 0, bp = 0;
         if (lane == 0) {
@@ -1697,12 +1621,13 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
             st_stream(&r[0], make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u)));
             st_stream(&r[1], rd);
         }
+        const unsigned pos_next = bp + (unsigned)__popcll(mp & lt_mask);  // this path's position in the next trip's path queue
         if (push_sh) {
             float4 *r = rq_next + 2 * (size_t)(br + __popcll(me) + __popcll(ms & lt_mask));
-            st_stream(&r[0], make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u + 1u)));
+            st_stream(&r[0], make_float4(ro.x, ro.y, ro.z, __uint_as_float(pos_next * 2u + 1u)));  // shadow ray id: queue position, odd
             st_stream(&r[1], rsd);
         }
-        if (push_ext || push_sh) pq_next[bp + __popcll(mp & lt_mask)] = id;
+        if (push_ext || push_sh) pq_next[pos_next] = id;
     }
 }
 
@@ -1737,8 +1662,8 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     // would occupy ~100 of the 102 SGPRs and spill into VGPR lanes inside the traversal loop)
     float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));      // {root_lo, root_hi}
     float *lds_cam = reinterpret_cast<float *>(pl + 16 * sizeof(unsigned) + 32);     // {c2w, s2c, aperture, focal}
-    [[maybe_unused]] ShadeSortLds *lds_sort = reinterpret_cast<ShadeSortLds *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
-    float4 *lds_top = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(lds_sort) + ((sizeof(ShadeSortLds) + 15) / 16) * 16);
+    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);  // kWgPathsMax bits
+    float4 *lds_top = reinterpret_cast<float4 *>(light_bits + kWgPathsMax / 32);
     for (int i = threadIdx.x; i < 4 * a.sc.n_top; i += kBlockThreads) lds_top[i] = a.sc.forks[i];  // top tree levels (trav_step)
     if (threadIdx.x < kCamFloats) lds_cam[threadIdx.x] = a.cam[threadIdx.x];
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
@@ -1746,7 +1671,6 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     // per-workgroup slice of the queue buffer: ray records float4[2][2 * block_paths][2], then path ids unsigned[2][block_paths]
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
     unsigned *pathQ = reinterpret_cast<unsigned *>(rayQ + 8 * (size_t)w.block_paths);
-    [[maybe_unused]] unsigned *sortQ = pathQ + 2 * (size_t)w.block_paths;  // this trip's shading order (GLRTX_SHADE_SORT)
     if (a.sc.mats_in_lds)
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
 
@@ -1785,6 +1709,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         __syncthreads();
         {
             const int got = (int)ctl[6] * 64, tile0 = (int)ctl[0];
+            if (threadIdx.x < kWgPathsMax / 32) light_bits[threadIdx.x] = 0u;  // last read by the previous shade phase (a barrier ago)
             const int nr = (int)ctl[2 + cur], np = (int)ctl[4 + cur];
             float4 *rq_w = rayQ + 2 * ((size_t)cur * 2 * kWgPaths + nr);
             unsigned *pq_w = pathQ + cur * kWgPaths + np;
@@ -1813,7 +1738,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
         // their loads get going earlier (measured 1-2 %)
         __builtin_amdgcn_s_setprio(3);
-        wg_traverse_phase<VINE>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], rays);
+        wg_traverse_phase<VINE>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], light_bits, rays);
         __builtin_amdgcn_s_setprio(0);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written
@@ -1823,14 +1748,8 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 
         // ---- shade phase: the live paths; appends go to the other queue pair
         const WgwfKernArgs *ks = wgwf_kernargs();
-#if GLRTX_SHADE_SORT
-        const int n_shade = wg_shade_sort(ks->a, ks->w, lds_mats, pq, n_paths, sortQ, lds_sort);
-        wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, sortQ, n_shade, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
+        wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, light_bits, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
                        &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], rays);
-#else
-        wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
-                       &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], rays);
-#endif
         PH_STAMP(ps1);
         __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
         PH_STAMP(ps2);
