@@ -1391,7 +1391,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     Shade sh;
     sh.has_shadow = false;
     if (!ended) {
-        const float4 hh = ld_stream(w.H(id));
+        const float4 hh = *w.H(id);  // (plain load and store for the hit records: -1.6 % against the non-temporal forms, profiles/r02_ab_flags.txt)
         Hit h;
         h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
         shade_hit(a, lds_mats, rng, P, h, sh);
@@ -1524,7 +1524,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         const unsigned id = rid >> 1;  // path id (path ray) or the path's position in the workgroup's path queue (shadow ray)
         if (rid & 1u) {  // the light test of :367, decided here (T.stop_d is the light sample's distance): one bit for the shade phase
             if (nee_accepted(T.stop_d, T.h.t, T.h.tri >= 0)) atomicOr(&light_bits[id >> 5], 1u << (id & 31u));
-        } else st_stream(w.H(id), make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v));
+        } else *w.H(id) = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);  // plain store: scattered 16-byte writes merge in L2 now and then, non-temporal ones never do (-1.2 %)
         unsaved = false;
     };
     for (;;) {
