@@ -81,8 +81,11 @@ struct KernelArgs {
 
 #define DEV __device__ __forceinline__
 
-// Streamed data (path state, ray records, hit records, sample planes): written once and read once per trip, never
-// reused from cache.  GLRTX_STREAM_NT marks those accesses non-temporal so that they do not displace the BVH from L2.
+// Streamed data (path state, sample planes, the reads of ray records): written once and read once per trip, never reused from
+// cache.  GLRTX_STREAM_NT marks those accesses non-temporal so that they do not displace the BVH from L2 (-2.3 % per frame).
+// Two streams are deliberately NOT marked (per-stream A/B, profiles/r02_ab_flags.txt): the ray records' stores -- the same
+// workgroup reads them back within a phase, and written plainly they are still cached then (-4 %) -- and the hit records
+// (scattered 16-byte stores that a plain store lets merge in L2 now and then, -1.6 %).
 #ifndef GLRTX_STREAM_NT
 #define GLRTX_STREAM_NT 3
 #endif
@@ -1618,14 +1621,14 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         bp = __builtin_amdgcn_readfirstlane(bp);
         if (push_ext) {
             float4 *r = rq_next + 2 * (size_t)(br + __popcll(me & lt_mask));
-            st_stream(&r[0], make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u)));
-            st_stream(&r[1], rd);
+            r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u));
+            r[1] = rd;
         }
         const unsigned pos_next = bp + (unsigned)__popcll(mp & lt_mask);  // this path's position in the next trip's path queue
         if (push_sh) {
             float4 *r = rq_next + 2 * (size_t)(br + __popcll(me) + __popcll(ms & lt_mask));
-            st_stream(&r[0], make_float4(ro.x, ro.y, ro.z, __uint_as_float(pos_next * 2u + 1u)));  // shadow ray id: queue position, odd
-            st_stream(&r[1], rsd);
+            r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pos_next * 2u + 1u));  // shadow ray id: queue position, odd
+            r[1] = rsd;
         }
         if (push_ext || push_sh) pq_next[pos_next] = id;
     }
@@ -1718,8 +1721,8 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
                 const int id = tile0 * 64 + k;  // tile g = tile0 + (k >> 6) of the frame-major tile order holds ids 64 g .. 64 g + 63
                 float4 ro = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID)), rd = ro;
                 const bool go = wf_generate_one(kt->a, kt->w, lds_cam, id, ro, rd);  // pixels outside the image leave skip markers
-                st_stream(&rq_w[2 * k], ro);
-                st_stream(&rq_w[2 * k + 1], rd);
+                rq_w[2 * k] = ro;  // (plain stores, like every ray record: see st_stream)
+                rq_w[2 * k + 1] = rd;
                 pq_w[k] = go ? (unsigned)id : WF_INVALID;
             }
             __syncthreads();  // everyone has read the counts
