@@ -49,9 +49,13 @@ int glrt_bvh_build_sah(const float *vert, size_t n_vert, const float *tri, size_
                        int *max_depth_out);
 int glrt_bvh_build_chain(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out);
 /* Linear BVH (30-bit Morton order + Karras hierarchy), improved by GLRT_LBVH_ROTATION_PASSES bottom-up sweeps of tree
- * rotations (child <-> grandchild and grandchild <-> grandchild exchanges).  Same output, bit for bit, as the GPU builder glrtx_build_lbvh (include/glrtx.h); internal node i at index i,
+ * rotations (child <-> grandchild and grandchild <-> grandchild exchanges) and by rebuilding every maximal subtree of at most
+ * GLRT_LBVH_REBUILD_LEAVES leaves with the exact sweep SAH.  Same output, bit for bit, as the GPU builder glrtx_build_lbvh (include/glrtx.h); internal node i at index i,
  * leaves after them in Morton order. */
-#define GLRT_LBVH_ROTATION_PASSES 5
+#ifndef GLRT_LBVH_ROTATION_PASSES
+#define GLRT_LBVH_ROTATION_PASSES 4
+#endif
+#define GLRT_LBVH_REBUILD_LEAVES 64
 int glrt_bvh_build_lbvh(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
                         int *max_depth_out);
 

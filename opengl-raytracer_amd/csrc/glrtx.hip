@@ -21,6 +21,7 @@
 #include "pt_kernel.hip.h"
 #include "lbvh.hip.h"
 static_assert(glrtx::lbvh::kRotationPasses == GLRT_LBVH_ROTATION_PASSES, "device and CPU LBVH statements must run the same rotation sweeps");
+static_assert(glrtx::lbvh::kRebuildLeaves == GLRT_LBVH_REBUILD_LEAVES, "device and CPU LBVH statements must rebuild the same subtrees");
 
 using namespace glrtx;
 

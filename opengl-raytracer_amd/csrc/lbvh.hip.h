@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void k_rotate_level(int n, int d, const int *l
         refit(B);
     }
 }
-// Depth of the deepest leaf (after the rotations), one atomic per wave.
+// Depth of the deepest leaf (after the rotations), one atomic per workgroup (1,500 per-wave atomics on one word took 15 of the
+// kernel's 22 microseconds).
 __global__ __launch_bounds__(256) void k_max_depth(int n, const int *parent, int *max_depth) {
     const int k = (int)(blockIdx.x * 256u + threadIdx.x);
     int depth = 0;
@@ -277,9 +278,204 @@ __global__ __launch_bounds__(256) void k_max_depth(int n, const int *parent, int
         const int o = __shfl_xor(depth, m);
         depth = o > depth ? o : depth;
     }
-    if ((threadIdx.x & 63u) == 0u) atomicMax(max_depth, depth);
+    __shared__ int red[4];
+    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = depth;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+        atomicMax(max_depth, a > b ? a : b);
+    }
 }
-constexpr int kRotationPasses = 5;  // == GLRT_LBVH_ROTATION_PASSES (glrt_host.h): the CPU statement must run the same sweeps
+// ---- subtree rebuild (the second quality pass; CPU statement and rationale: host/bvh.cpp, lbvh::rebuild_subtrees) ----
+constexpr int kRebuildLeaves = 64;  // == GLRT_LBVH_REBUILD_LEAVES (glrt_host.h)
+constexpr int kRebuildSahLevels = 20;  // as in host/bvh.cpp: deeper segments are halved
+// The rebuild forms unions of many boxes in an order of its own (scans across lanes; the CPU statement: sequential sweeps).  min and
+// max give the same result in any order once no operand is a negative zero, so the leaf boxes are read as x + 0.0f (-0 -> +0,
+// everything else unchanged) and the unions use the plain instructions.
+// Leaves below every internal node, capped at kRebuildLeaves + 1: one thread per node, a depth-first walk that stops at the cap.
+__global__ __launch_bounds__(256) void k_subtree_count(int n, const float *nodes, int *count) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= n - 1) return;
+    int stack[64];
+    int sp = 0, cnt = 0;
+    stack[sp++] = i;
+    while (sp > 0 && cnt <= kRebuildLeaves) {
+        const int v = stack[--sp];
+        if (v >= n - 1) { cnt++; continue; }
+        if (sp + 2 > 64) { cnt = kRebuildLeaves + 1; break; }  // deeper than any tree the traversal accepts
+        stack[sp++] = (int)nodes[9 * (size_t)v + 6];
+        stack[sp++] = (int)nodes[9 * (size_t)v + 7];
+    }
+    count[i] = cnt < kRebuildLeaves + 1 ? cnt : kRebuildLeaves + 1;
+}
+// The roots of the MAXIMAL subtrees with at most kRebuildLeaves leaves, as a list (in no particular order: the subtrees are disjoint).
+__global__ __launch_bounds__(256) void k_subtree_roots(int n, const int *parent, const int *count, int *roots, int *n_roots) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    bool is_root = false;
+    if (i < n - 1 && count[i] <= kRebuildLeaves) {
+        const int pr = parent[i];
+        is_root = pr < 0 || count[pr] > kRebuildLeaves;
+    }
+    const unsigned long long mask = __ballot(is_root);
+    if (mask == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    int base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(n_roots, __popcll(mask));
+    base = __shfl(base, __ffsll((long long)mask) - 1);
+    if (is_root) roots[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+}
+// One wave per listed subtree (a fixed grid walks the list: a launch with a block per internal node spent 0.25 ms dispatching blocks that left at once).
+// Lane p is position p of the subtree's leaf order.  The tree is built level by level; the nodes of a level are the SEGMENTS of the
+// order, all of them processed at once: per axis the lanes rank themselves inside their segment (a count over the segment),
+// segmented prefix / suffix unions by shuffles, one cost per lane, the segment's minimum by a loop over the segment.
+__global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, int *parent, const int *roots, const int *n_roots) {
+    const int n_int = n - 1, lane = (int)threadIdx.x;
+    __shared__ int q[2 * kRebuildLeaves], qn, slots[kRebuildLeaves], leaves[kRebuildLeaves], sorted_item[kRebuildLeaves], ord[kRebuildLeaves];
+    __shared__ int ref_l[kRebuildLeaves], ref_r[kRebuildLeaves], split_k[kRebuildLeaves];
+    __shared__ float box[kRebuildLeaves][6], cen[kRebuildLeaves][3], cost_l[kRebuildLeaves], key_l[kRebuildLeaves];
+  for (int ri = (int)blockIdx.x; ri < *n_roots; ri += (int)gridDim.x) {
+    const int r = roots[ri];
+    __syncthreads();  // the previous subtree's last reads of the shared arrays are done
+    // ---- gather the subtree's nodes (breadth-first), then its internal slots (without r) and leaves in ascending index order
+    if (lane == 0) { q[0] = r; qn = 1; }
+    __syncthreads();
+    for (int head = 0;;) {
+        const int end = qn;
+        __syncthreads();  // everyone has read the count before anyone appends
+        if (head >= end) break;
+        for (int i = head + lane; i < end; i += 64) {
+            const int v = q[i];
+            if (v < n_int) {
+                const int at = atomicAdd(&qn, 2);
+                q[at] = (int)nodes[9 * (size_t)v + 6];
+                q[at + 1] = (int)nodes[9 * (size_t)v + 7];
+            }
+        }
+        head = end;
+        __syncthreads();
+    }
+    const int total = qn, m = (total + 1) / 2;  // m leaves, m - 1 internal nodes
+    for (int i = lane; i < total; i += 64) {
+        const int v = q[i];
+        if (v == r) continue;
+        const bool is_leaf = v >= n_int;
+        int rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < total; j++) {
+            const int w = q[j];
+            if (w != r && (w >= n_int) == is_leaf && w < v) rank++;
+        }
+        if (is_leaf) leaves[rank] = v; else slots[rank] = v;
+    }
+    __syncthreads();
+    int item = lane;  // the leaf (rank in `leaves`) at this lane's position
+    if (lane < m) {
+        const float *L = nodes + 9 * (size_t)leaves[lane];
+        for (int k = 0; k < 6; k++) box[lane][k] = L[k] + 0.0f;
+        for (int k = 0; k < 3; k++) cen[lane][k] = 0.5f * (L[k] + L[3 + k]);
+        ord[lane] = lane;
+    }
+    __syncthreads();
+    int a = 0, b = lane < m ? m : 0, slot = r;  // this lane's segment [a, b) and the node slot it is building; b - a < 2: nothing to do
+    if (lane >= m) { a = lane; b = lane; }
+    int next_slot = 0;
+    for (int level = 0;; level++) {
+        const bool busy = b - a >= 2;
+        if (!__any(busy)) break;
+        int longest = busy ? b - a : 0;
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(longest, d); longest = o > longest ? o : longest; }
+        float best = __builtin_inff();
+        int best_k = 1, best_item = item, best_imb = b - a;
+        float all_lo[3] = {0.f, 0.f, 0.f}, all_hi[3] = {0.f, 0.f, 0.f};
+        for (int axis = 0; axis < 3; axis++) {
+            // rank inside the segment by (centre, leaf rank); keys by POSITION, so that the loop's reads do not depend on one another
+            const float key = lane < m ? cen[item][axis] : 0.f;
+            key_l[lane] = key;
+            __syncthreads();
+            int rank = a;
+            if (busy) {
+#pragma unroll 4
+                for (int j = 0; j < longest; j++) {
+                    const int qq = a + j < b ? a + j : lane;  // (own entry: adds nothing)
+                    const float c = key_l[qq];
+                    const int it = ord[qq];
+                    rank += (c < key || (c == key && it < item)) ? 1 : 0;
+                }
+                sorted_item[rank] = item;
+            }
+            __syncthreads();
+            const int s_item = busy ? sorted_item[lane] : item;
+            // segmented inclusive prefix and suffix unions of the boxes in sorted order
+            float plo[3], phi[3], slo[3], shi[3];
+            for (int k = 0; k < 3; k++) { plo[k] = slo[k] = busy ? box[s_item][k] : 0.f; phi[k] = shi[k] = busy ? box[s_item][3 + k] : 0.f; }
+            for (int d = 1; d < 64; d <<= 1) {
+                for (int k = 0; k < 3; k++) {
+                    const float ul = __shfl_up(plo[k], d), uh = __shfl_up(phi[k], d), dl = __shfl_down(slo[k], d), dh = __shfl_down(shi[k], d);
+                    if (busy && lane - d >= a) { plo[k] = __builtin_fminf(plo[k], ul); phi[k] = __builtin_fmaxf(phi[k], uh); }
+                    if (busy && lane + d < b) { slo[k] = __builtin_fminf(slo[k], dl); shi[k] = __builtin_fmaxf(shi[k], dh); }
+                }
+            }
+            // the split in front of this lane: [a, lane) | [lane, b)
+            float cost = __builtin_inff();
+            {
+                float ql[3], qh[3];
+                for (int k = 0; k < 3; k++) { ql[k] = __shfl_up(plo[k], 1); qh[k] = __shfl_up(phi[k], 1); }
+                if (busy && lane > a) cost = half_area9(ql, qh) * (float)(lane - a) + half_area9(slo, shi) * (float)(b - lane);
+            }
+            if (axis == 0 && lane == a) for (int k = 0; k < 3; k++) { all_lo[k] = slo[k]; all_hi[k] = shi[k]; }
+            cost_l[lane] = cost;
+            __syncthreads();
+            if (busy) {  // the segment's best split on this axis: lowest cost, then most balanced, then first
+                float bc = __builtin_inff();
+                int bk = 1, bi = b - a;
+                bool found = false;
+#pragma unroll 4
+                for (int j = 1; j < longest; j++)
+                    if (a + j < b) {
+                        const float c = cost_l[a + j];
+                        const int imb = abs(2 * j - (b - a));
+                        if (level < kRebuildSahLevels && (c < bc || (c == bc && imb < bi))) { bc = c; bk = j; bi = imb; found = true; }
+                    }
+                // (the first axis' order is taken even if no split qualifies: non-finite boxes, or past the SAH levels; as the CPU statement does)
+                if (found && (bc < best || (bc == best && bi < best_imb))) { best = bc; best_k = bk; best_imb = bi; best_item = s_item; }
+                else if (axis == 0) best_item = s_item;
+            }
+            __syncthreads();
+        }
+        // the winning axis' order becomes the order; children, slots, node record
+        item = best_item;
+        if (level >= kRebuildSahLevels) best_k = (b - a) / 2;
+        if (lane < m) ord[lane] = item;
+        const bool leader = busy && lane == a;
+        const int n_l = best_k, n_r = (b - a) - best_k;
+        const int need = leader ? (n_l >= 2 ? 1 : 0) + (n_r >= 2 ? 1 : 0) : 0;
+        int incl = need;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        const int level_total = __shfl(incl, 63);
+        __syncthreads();  // ord complete
+        if (leader) {
+            const int at = next_slot + incl - need;
+            const int rl = n_l >= 2 ? slots[at] : leaves[ord[a]];
+            const int rr = n_r >= 2 ? slots[at + (n_l >= 2 ? 1 : 0)] : leaves[ord[b - 1]];
+            ref_l[a] = rl; ref_r[a] = rr; split_k[a] = best_k;
+            float *N = nodes + 9 * (size_t)slot;
+            for (int k = 0; k < 3; k++) { N[k] = all_lo[k]; N[3 + k] = all_hi[k]; }
+            N[6] = (float)rl; N[7] = (float)rr; N[8] = -1.0f;
+            parent[rl] = slot;
+            parent[rr] = slot;
+        }
+        next_slot += level_total;
+        __syncthreads();
+        if (busy) {
+            const int k = split_k[a];
+            if (lane < a + k) { slot = ref_l[a]; b = a + k; }
+            else { slot = ref_r[a]; a = a + k; }
+        }
+        __syncthreads();
+    }
+  }
+}
+constexpr int kRotationPasses = GLRT_LBVH_ROTATION_PASSES;  // == GLRT_LBVH_ROTATION_PASSES (glrt_host.h): the CPU statement must run the same sweeps
 
 struct Workspace {
     void *p = nullptr;
@@ -349,6 +545,18 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
             LBVH_TRY(hipMemcpyAsync(&depth, max_depth, sizeof(int), hipMemcpyDeviceToHost, stream));
             LBVH_TRY(hipStreamSynchronize(stream));  // the next sweep's launch count depends on it
         }
+        // second quality pass: every maximal subtree of at most kRebuildLeaves leaves rebuilt with the exact sweep SAH
+        int *count = (int *)arrived;  // the rotation levels are no longer needed
+        int *roots = (int *)keys0, *n_roots = (int *)(bounds + 194);  // the unsorted keys are no longer needed
+        LBVH_TRY(hipMemsetAsync(n_roots, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_subtree_count, grid, block, 0, stream, (int)n, d_nodes, count);
+        hipLaunchKernelGGL(k_subtree_roots, grid, block, 0, stream, (int)n, parent, count, roots, n_roots);
+        hipLaunchKernelGGL(k_rebuild_subtrees, dim3(std::min<unsigned>(n - 1, 8192u)), dim3(64), 0, stream, (int)n, d_nodes, parent, roots, n_roots);
+        LBVH_TRY(hipMemsetAsync(max_depth, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_max_depth, grid, block, 0, stream, (int)n, parent, max_depth);
+        LBVH_TRY(hipGetLastError());
+        LBVH_TRY(hipMemcpyAsync(&depth, max_depth, sizeof(int), hipMemcpyDeviceToHost, stream));
+        LBVH_TRY(hipStreamSynchronize(stream));
         *max_depth_out = depth;
     }
     LBVH_TRY(hipStreamSynchronize(stream));
