@@ -87,6 +87,57 @@ def test_lbvh_layout_and_image_equals_sah_image():
     assert depth40 <= 8  # index tie-break splits equal codes evenly
 
 
+def _tree_stats(nodes):
+    """(leaf count, forks' summed half-area / root's, summed half-area of the leaves' parents / root's, depth); asserts a proper tree with tight boxes."""
+    n_nodes = nodes.shape[0]
+    seen = np.zeros(n_nodes, bool)
+    area = lambda b: (lambda d: d[0] * d[1] + d[1] * d[2] + d[2] * d[0])(np.maximum(b[3:6] - b[0:3], 0).astype(np.float64))
+    forks = tests = 0.0
+    leaves = depth = 0
+    st = [(0, 0)]
+    while st:
+        i, d = st.pop()
+        assert not seen[i]
+        seen[i] = True
+        if nodes[i, 8] >= 0:
+            leaves += 1; depth = max(depth, d)
+            continue
+        l, r = int(nodes[i, 6]), int(nodes[i, 7])
+        assert np.array_equal(nodes[i, 0:3], np.minimum(nodes[l, 0:3], nodes[r, 0:3]))  # the union of the children, exactly
+        assert np.array_equal(nodes[i, 3:6], np.maximum(nodes[l, 3:6], nodes[r, 3:6]))
+        forks += area(nodes[i])
+        tests += sum(area(nodes[i]) for c in (l, r) if nodes[c, 8] >= 0)
+        st += [(l, d + 1), (r, d + 1)]
+    assert seen.all()
+    return leaves, forks / area(nodes[0]), tests / area(nodes[0]), depth
+
+
+def test_lbvh_quality_passes_keep_a_valid_tree_and_reach_the_sah_trees_cost():
+    """Rotation sweeps + SAH rebuild of the subtrees of <= GLRT_LBVH_REBUILD_LEAVES leaves (host/bvh.cpp): every triangle once, every
+    fork's box the exact union of its children's, and on random triangles the surface-area cost lands within 3 % of the
+    binned-SAH tree's (Morton tree + rotations alone: 6 % more expected triangle tests)."""
+    sc_l, _ = scenes.config_c3(16, 16, n=20_000, bvh="lbvh")
+    sc_s, _ = scenes.config_c3(16, 16, n=20_000, bvh="sah")
+    n_l, forks_l, tests_l, depth_l = _tree_stats(_nodes(sc_l))
+    n_s, forks_s, tests_s, _ = _tree_stats(_nodes(sc_s))
+    assert n_l == n_s == 20_000 and depth_l == sc_l["bvh_depth"] < 40
+    assert forks_l < 1.03 * forks_s and tests_l < 1.03 * tests_s
+    # equal boxes: every split costs the same; the tie goes to the balanced one, not to a chain
+    v = np.tile(sc_l["vert"].reshape(-1, 5, 3)[:3], (64, 1, 1)).reshape(-1, 3)
+    t = np.array([[3 * i, 3 * i + 1, 3 * i + 2, 0] for i in range(64)], np.float32)
+    nodes, depth = host.build_bvh(v, t, "lbvh")
+    assert _tree_stats(nodes.reshape(-1, 9))[0] == 64 and depth == 6
+    # a box coordinate of -0.0 next to +0.0: unions are formed without negative zeros
+    sc, _ = scenes.config_c3(8, 8, n=50, bvh="sah")
+    vert = sc["vert"].reshape(-1, 5, 3).copy()
+    vert[::7, 0, 1] = -0.0
+    vert[3::7, 0, 1] = 0.0
+    nodes, _ = host.build_bvh(vert.reshape(-1, 3), sc["tri"], "lbvh")
+    nodes = nodes.reshape(-1, 9)
+    forks = nodes[nodes[:, 8] < 0]
+    assert not np.any((forks[:, :6] == 0) & np.signbit(forks[:, :6]))
+
+
 def test_sah_depth_bounded():
     sc, _ = scenes.config_c2(32, 32, subdiv=2)
     assert sc["bvh_depth"] < 40
