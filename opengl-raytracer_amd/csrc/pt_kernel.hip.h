@@ -338,7 +338,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
     // Evaluating a test's later terms when an earlier one already failed cannot change the outcome
     // (pure IEEE arithmetic; a NaN/inf produced behind a failed test is masked by the predicate).
     const int cur = T.cur;
-    bool need_pop = true;
+    bool need_pop = true, done = false;
     // Fork and triangle records have the same 64-byte shape and are fetched by the SAME four loads, issued
     // before the wave splits into its fork lanes and its triangle lanes: in a mixed wave (3 of 4 iterations)
     // the two arms then cost one memory round trip, not two.
@@ -416,22 +416,45 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
         T.h.tri = closer ? t : T.h.tri;
         if (CLOSEST) { T.h.u = closer ? u : T.h.u; T.h.v = closer ? v : T.h.v; }
         T.h.t = hit ? __builtin_fminf(T.h.t, tt) : T.h.t;
-        if (T.stop_d - T.h.t >= PT_EPS) { TS_DONE; return true; }  // shadow ray: an occluder is known, the light test has failed
+        done = T.stop_d - T.h.t >= PT_EPS;  // shadow ray: an occluder is known, the light test has failed
     }
-    if (!need_pop) return false;
-    // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298
-    for (;;) {
-        if (T.sp == 0) { TS_DONE; return true; }
-        T.sp--;
-        // ONE ds_read_b64 for {ref, t0}: left to itself the compiler reads t0, waits, and only then reads the
-        // ref of entries that survive -- two dependent LDS round trips per pop.  (The low 32 bits of a generic
-        // pointer into LDS are the LDS byte address; the wait is inside the statement, cdna guide section 5.7.)
-        unsigned long long e;
-        const unsigned lds_addr = (unsigned)(uintptr_t)stack + (unsigned)T.sp * (kBlockThreads * 8u);
-        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(lds_addr) : "memory");
-        T.cur = (int)(unsigned)e;
-        if (T.h.t >= __uint_as_float((unsigned)(e >> 32))) return false;
+    // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298.  Hand-written: as C++ the
+    // compiler's structurizer spends ~30 instructions of exec-mask bookkeeping per trip on this loop-with-two-exits, the loop
+    // itself is 9.  Lanes drop out of the loop when their stack is empty or when the entry they read survives; {ref, t0} comes in
+    // ONE ds_read_b64.  t0 starts as +inf ("nothing found"), so a lane that leaves with an empty stack has found = false.
+    if (need_pop && !done) {
+        float t0 = __builtin_inff();
+        int sp = T.sp, ref = 0;
+        unsigned long long save;
+        unsigned addr;
+        const unsigned lds_base = (unsigned)(uintptr_t)stack;
+        asm volatile(
+            "s_mov_b64 %[save], exec\n"
+            "1:\n\t"
+            "v_cmp_ne_u32 vcc, 0, %[sp]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execz 2f\n\t"
+            "v_add_u32 %[sp], -1, %[sp]\n\t"
+            "v_lshl_add_u32 %[addr], %[sp], 11, %[base]\n\t"
+            "ds_read_b32 %[ref], %[addr]\n\t"
+            "ds_read_b32 %[t0], %[addr] offset:4\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_gt_f32 vcc, %[t0], %[th]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execnz 1b\n"
+            "2:\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [t0] "+v"(t0), [ref] "+v"(ref), [sp] "+v"(sp), [save] "=&s"(save), [addr] "=&v"(addr)
+            : [base] "v"(lds_base), [th] "v"(T.h.t)
+            : "vcc", "memory");
+        T.sp = sp;
+        T.cur = ref;
+        done = t0 > T.h.t;  // nothing survived: the stack is empty
     }
+#ifdef GLRTX_TRAV_STATS
+    if (done) { TS_DONE; }
+#endif
+    return done;
 }
 
 // intersect(Ray, Triangle) :226-257 against the running closest hit; v0 / e1 = v1-v0 / e2 = v2-v0
