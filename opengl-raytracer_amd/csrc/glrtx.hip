@@ -260,7 +260,7 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
                     continue;
                 }
                 ref_of[n] = (int)(forks.size() / 4);
-                for (int k = 0; k < 4; k++) forks.push_back(make_float4(0.f, 0.f, 0.f, as_float(REF_ABSENT)));
+                for (int k = 0; k < 4; k++) forks.push_back(make_float4(0.f, 0.f, 0.f, as_float(~(int)n_tri)));  // absent child: the never-hit record
                 // forks are numbered in the order the traversal meets them (children.y first, raytrace.frag:299-307):
                 // the first-visited child's record directly follows its parent's
                 f.stage = 1;
@@ -356,7 +356,7 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         root_ref = newid[root_ref];
     }
     if (root_ref == REF_ABSENT) {  // empty scene: one childless fork, every ray misses
-        forks.assign(4, make_float4(0.f, 0.f, 0.f, as_float(REF_ABSENT)));
+        forks.assign(4, make_float4(0.f, 0.f, 0.f, as_float(~(int)n_tri)));
         root_ref = 0;
         P.root_lo = make_float4(0.f, 0.f, 0.f, 0.f);
         P.root_hi = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -559,10 +559,13 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     const int root_ref = P.root_ref, stack_need = P.stack_need;
 
     int rc;
-    // one node array: triangle records in reverse order, then the forks (DevScene::forks points at fork 0)
-    std::vector<float4> nodes(tris.size() + forks.size());
-    for (size_t t = 0; t < n_tri; t++) std::memcpy(&nodes[4 * (n_tri - 1 - t)], &tris[4 * t], 4 * sizeof(float4));
-    std::memcpy(nodes.data() + tris.size(), forks.data(), forks.size() * sizeof(float4));
+    // one node array: the all-zero record ~n_tri (what an absent child refers to: never hit), the triangle records in reverse order,
+    // then the forks (DevScene::forks points at fork 0)
+    const size_t tri_f4 = 4 * (n_tri + 1);
+    if ((tri_f4 + forks.size()) * sizeof(float4) >= ((size_t)1 << 32)) return fail(c, GLRTX_EINVAL, "glrtx_upload_scene: node array exceeds 4 GiB");
+    std::vector<float4> nodes(tri_f4 + forks.size(), make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t t = 0; t < n_tri; t++) std::memcpy(&nodes[4 * (n_tri - t)], &tris[4 * t], 4 * sizeof(float4));
+    std::memcpy(nodes.data() + tri_f4, forks.data(), forks.size() * sizeof(float4));
     if ((rc = dev_upload(c, c->forks, nodes.data(), nodes.size() * sizeof(float4)))) return rc;
     if ((rc = dev_upload(c, c->nrms, nrms.data(), nrms.size() * sizeof(float4)))) return rc;
     if ((rc = dev_upload(c, c->mats, mats.data(), mats.size() * sizeof(float4)))) return rc;
@@ -570,7 +573,9 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     if (!P.vine.empty() && (rc = dev_upload(c, c->vine, P.vine.data(), P.vine.size() * sizeof(float4)))) return rc;
 
     DevScene &sc = c->sc;
-    sc.forks = (const float4 *)c->forks.p + tris.size();
+    sc.forks = (const float4 *)c->forks.p + tri_f4;
+    sc.nodes0 = (const float4 *)c->forks.p;
+    sc.node_bias = (unsigned)(tri_f4 * sizeof(float4));
     sc.nrms = (const float4 *)c->nrms.p;
     sc.mats = (const float4 *)c->mats.p;
     sc.lights = (const float4 *)c->lights.p;

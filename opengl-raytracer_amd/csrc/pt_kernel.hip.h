@@ -19,8 +19,10 @@
 //   forks  : 4 x float4 (64 B) per interior BVH node, holding its CHILDREN's boxes:
 //            {minL.xyz, refL} {maxL.xyz, refR} {minR.xyz, -} {maxR.xyz, -}
 //            ref >= 0 -> fork index, ref < 0 -> ~triangle (leaf nodes are folded into their
-//            parent's ref: the reference never tests a leaf's own box, raytrace.frag:310-331),
-//            ref == REF_ABSENT -> no child.  The root's own box is in DevScene.
+//            parent's ref: the reference never tests a leaf's own box, raytrace.frag:310-331).
+//            A child the wire format leaves out (children.x/y < 0; no builder of this repository does) is ~n_tri: a record of
+//            zeros in front of the triangles, "tested" like a leaf and never hit (det = 0), so that the step carries no test
+//            for absent children.  The root's own box is in DevScene.
 //   tris   : 4 x float4 (64 B, the shape of a fork record) per triangle {v0.xyz, materialId} {v1-v0, -} {v2-v0, -} {-},
 //            in the same array as the forks, triangle t at record index ~t (DevScene::forks)
 //   nrms   : 3 x float4 per triangle {n0} {n1} {n2}   (read once per ray, for the closest hit only)
@@ -47,6 +49,8 @@ struct DevScene {
     const float4 *forks;  // fork f at forks[4 f]; triangle t at forks[4 ~t] = forks[-4 (t + 1)]: ONE array with the triangle records
                           // stored (in reverse) in front of fork 0, so that a ref -- fork index or ~triangle -- is itself the
                           // signed record index and the traversal step needs no base-pointer select
+    const float4 *nodes0; // first byte of that array (the all-zero record ~n_tri); record ref lies at byte ref * 64 + node_bias from
+    unsigned node_bias;   // here: an unsigned 32-bit offset from a uniform base, which the load instructions take as they are
     const float4 *nrms;
     const float4 *mats;
     const float4 *lights;
@@ -343,7 +347,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
     // before the wave splits into its fork lanes and its triangle lanes: in a mixed wave (3 of 4 iterations)
     // the two arms then cost one memory round trip, not two.
     const bool is_fork = cur >= 0;
-    const float4 *N = sc.forks + 4 * (ptrdiff_t)cur;
+    const float4 *N = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.nodes0) + ((unsigned)cur * 64u + sc.node_bias));
     // Every lane fetches its whole record here -- dwordx4, dwordx4, dwordx3, dwordx3: FOUR load instructions issued together (the
     // compiler drops the unused C.w / D.w).  The vector-memory pipe charges per instruction and per distinct cache line, not per
     // byte: fetching the fork arm's second box and refs separately (six instructions, 20 bytes less for a triangle lane) was 8 %
@@ -369,9 +373,9 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
         float t0l, t0r;
         const bool bl = box_pass(A, B, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0l);
         const bool br = box_pass(C, D, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0r);
-        // leaf children are never box-tested (:310-331); an absent child never passes
-        const bool pl = l != REF_ABSENT && (l < 0 || bl);
-        const bool pr = r != REF_ABSENT && (r < 0 || br);
+        // leaf children are never box-tested (:310-331); (an absent child is the never-hit record ~n_tri)
+        const bool pl = l < 0 || bl;
+        const bool pr = r < 0 || br;
 #ifdef GLRTX_NEAR_FIRST_EXPERIMENT
         // MEASUREMENT ONLY (never shipped: ties may resolve differently from the reference): a path ray visits the nearer child first
         const float kl = l < 0 ? -PT_INFTY : t0l, kr = r < 0 ? -PT_INFTY : t0r;
