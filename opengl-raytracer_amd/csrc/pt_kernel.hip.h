@@ -419,7 +419,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
         const bool closer = hit && tt < T.h.t;  // strict: among equal distances the first one visited wins (:325)
         T.h.tri = closer ? t : T.h.tri;
         if (CLOSEST) { T.h.u = closer ? u : T.h.u; T.h.v = closer ? v : T.h.v; }
-        T.h.t = hit ? __builtin_fminf(T.h.t, tt) : T.h.t;
+        T.h.t = closer ? tt : T.h.t;  // == hit ? min(tHit, tt) : tHit (a NaN tt is never closer)
         done = T.stop_d - T.h.t >= PT_EPS;  // shadow ray: an occluder is known, the light test has failed
     }
     // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298.  Hand-written: as C++ the
@@ -450,7 +450,8 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
             "s_mov_b64 exec, %[save]"
             : [t0] "+v"(t0), [ref] "+v"(ref), [sp] "+v"(sp), [save] "=&s"(save), [addr] "=&v"(addr)
             : [base] "v"(lds_base), [th] "v"(T.h.t)
-            : "vcc", "memory");
+            : "vcc", "scc", "memory");  // (exec is restored; s_and_b64 writes scc)
+        static_assert(kBlockThreads * 8 == 1 << 11, "the pop loop shifts the stack index by 11: entry e of lane l at byte (e * kBlockThreads + l) * 8");
         T.sp = sp;
         T.cur = ref;
         done = t0 > T.h.t;  // nothing survived: the stack is empty
