@@ -37,6 +37,7 @@ namespace glrtx {
 constexpr int kBlockThreads = 256;      // 4 wavefronts: a 16x16-pixel tile, one 8x8 sub-tile per wave
 constexpr int kTile = 16;
 constexpr int REF_ABSENT = INT32_MIN;
+constexpr int REF_FIN = INT32_MIN;      // Trav::cur of a finished ray (nothing left on the stack)
 constexpr int kMaxLdsMaterials = 256;   // 12 KiB of LDS at most
 constexpr int kTopForks = 128;          // forks of the top tree levels, numbered first (pack_scene): one contiguous 8 KiB block
 
@@ -342,7 +343,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
     // Evaluating a test's later terms when an earlier one already failed cannot change the outcome
     // (pure IEEE arithmetic; a NaN/inf produced behind a failed test is masked by the predicate).
     const int cur = T.cur;
-    bool need_pop = true, done = false;
+    bool need_pop = true;
     // Fork and triangle records have the same 64-byte shape and are fetched by the SAME four loads, issued
     // before the wave splits into its fork lanes and its triangle lanes: in a mixed wave (3 of 4 iterations)
     // the two arms then cost one memory round trip, not two.
@@ -420,15 +421,17 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
         T.h.tri = closer ? t : T.h.tri;
         if (CLOSEST) { T.h.u = closer ? u : T.h.u; T.h.v = closer ? v : T.h.v; }
         T.h.t = closer ? tt : T.h.t;  // == hit ? min(tHit, tt) : tHit (a NaN tt is never closer)
-        done = T.stop_d - T.h.t >= PT_EPS;  // shadow ray: an occluder is known, the light test has failed
+        // shadow ray: once an occluder is known the light test has failed and the traversal ends; otherwise on to the stack
+        need_pop = !(T.stop_d - T.h.t >= PT_EPS);
+        T.cur = REF_FIN;
     }
     // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298.  Hand-written: as C++ the
     // compiler's structurizer spends ~30 instructions of exec-mask bookkeeping per trip on this loop-with-two-exits, the loop
-    // itself is 9.  Lanes drop out of the loop when their stack is empty or when the entry they read survives; {ref, t0} comes in
-    // ONE ds_read_b64.  t0 starts as +inf ("nothing found"), so a lane that leaves with an empty stack has found = false.
-    if (need_pop && !done) {
-        float t0 = __builtin_inff();
-        int sp = T.sp, ref = 0;
+    // itself is 10.  Lanes drop out of the loop when their stack is empty -- their ref becomes REF_FIN: the ray is finished -- or
+    // when the entry they read survives.
+    if (need_pop) {
+        float t0;
+        int sp = T.sp, ref = REF_FIN;
         unsigned long long save;
         unsigned addr;
         const unsigned lds_base = (unsigned)(uintptr_t)stack;
@@ -436,6 +439,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
             "s_mov_b64 %[save], exec\n"
             "1:\n\t"
             "v_cmp_ne_u32 vcc, 0, %[sp]\n\t"
+            "v_cndmask_b32 %[ref], %[fin], %[ref], vcc\n\t"
             "s_and_b64 exec, exec, vcc\n\t"
             "s_cbranch_execz 2f\n\t"
             "v_add_u32 %[sp], -1, %[sp]\n\t"
@@ -448,18 +452,17 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
             "s_cbranch_execnz 1b\n"
             "2:\n\t"
             "s_mov_b64 exec, %[save]"
-            : [t0] "+v"(t0), [ref] "+v"(ref), [sp] "+v"(sp), [save] "=&s"(save), [addr] "=&v"(addr)
-            : [base] "v"(lds_base), [th] "v"(T.h.t)
+            : [t0] "=&v"(t0), [ref] "+&v"(ref), [sp] "+&v"(sp), [save] "=&s"(save), [addr] "=&v"(addr)  // (early-clobber: ref starts as
+            : [base] "v"(lds_base), [th] "v"(T.h.t), [fin] "v"(REF_FIN)                                   //  REF_FIN and must not share fin's register)
             : "vcc", "scc", "memory");  // (exec is restored; s_and_b64 writes scc)
         static_assert(kBlockThreads * 8 == 1 << 11, "the pop loop shifts the stack index by 11: entry e of lane l at byte (e * kBlockThreads + l) * 8");
         T.sp = sp;
         T.cur = ref;
-        done = t0 > T.h.t;  // nothing survived: the stack is empty
     }
 #ifdef GLRTX_TRAV_STATS
-    if (done) { TS_DONE; }
+    if (T.cur == REF_FIN) { TS_DONE; }
 #endif
-    return done;
+    return T.cur == REF_FIN;
 }
 
 // intersect(Ray, Triangle) :226-257 against the running closest hit; v0 / e1 = v1-v0 / e2 = v2-v0
