@@ -1530,7 +1530,11 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
     const int n_top = a.sc.n_top;
     const float4 none = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID));
     float4 cur_o = none, cur_d = none;  // this lane's record of the wave's current chunk
+    float cur_ix = 0.f, cur_iy = 0.f, cur_iz = 0.f;  // ... and 1 / direction (:260), computed when the chunk arrives
     int cur_pos = 0, cur_cnt = 0;       // wave-uniform
+    // What a ray needs before its first step -- the three IEEE reciprocals and the test of the root's own box -- is done HERE, once per
+    // record with all 64 lanes busy, not at refill time in the few lanes that take a ray: a refill is then seven instructions of setup
+    // behind its cross-lane reads.  A ray that misses the root box is marked in the sign of d.w (the light sample's distance: never negative).
     auto fetch = [&](float4 &o, float4 &d) -> int {                    // returns the number of records in the chunk (0: queue exhausted)
         int base = 0;
         if (lane == 0) base = (int)atomicAdd(ray_head, 64u);
@@ -1540,6 +1544,11 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         if (lane < cnt) {
             o = ld_stream(&rq[2 * (size_t)(base + lane)]);
             d = ld_stream(&rq[2 * (size_t)(base + lane) + 1]);
+            cur_ix = 1.0f / d.x; cur_iy = 1.0f / d.y; cur_iz = 1.0f / d.z;
+            const bool shadow = (__float_as_uint(o.w) & 1u) != 0u;
+            float t0;
+            if (a.sc.root_ref >= 0 && !box_pass(root[0], root[1], o.x, o.y, o.z, cur_ix, cur_iy, cur_iz, shadow ? shadow_limit(d.w) : PT_INFTY, t0))
+                d.w = __uint_as_float(__float_as_uint(d.w) | 0x80000000u);
         }
         return cnt;
     };
@@ -1581,15 +1590,24 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
                 const float ox = __shfl(cur_o.x, src), oy = __shfl(cur_o.y, src), oz = __shfl(cur_o.z, src);
                 const unsigned new_rid = (unsigned)__shfl((int)__float_as_uint(cur_o.w), src);
                 const float dx = __shfl(cur_d.x, src), dy = __shfl(cur_d.y, src), dz = __shfl(cur_d.z, src);
-                const float dist = __shfl(cur_d.w, src);  // shadow rays: distance of the light sample
+                const float dist_m = __shfl(cur_d.w, src);  // shadow rays: distance of the light sample; sign bit: the root box is missed
+                const float ix = __shfl(cur_ix, src), iy = __shfl(cur_iy, src), iz = __shfl(cur_iz, src);
                 if (!active && rank < take) {
                     if (unsaved) save_hit();
                     rid = new_rid;
                     if (rid != WF_INVALID) {
                         rays++;
                         const bool shadow = (rid & 1u) != 0u;
-                        active = trav_init(a.sc, root, T, ox, oy, oz, dx, dy, dz, shadow ? shadow_limit(dist) : PT_INFTY,
-                                           shadow ? dist : -__builtin_inff());
+                        const float dist = __builtin_fabsf(dist_m);
+                        T.ox = ox; T.oy = oy; T.oz = oz; T.dx = dx; T.dy = dy; T.dz = dz; T.ix = ix; T.iy = iy; T.iz = iz;
+                        T.h.t = shadow ? shadow_limit(dist) : PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
+                        T.stop_d = shadow ? dist : -__builtin_inff();
+                        T.sp = 0;
+                        T.cur = a.sc.root_ref;
+#ifdef GLRTX_TRAV_STATS
+                        T.iters = 0;
+#endif
+                        active = (__float_as_uint(dist_m) & 0x80000000u) == 0u;
                         unsaved = !active;  // root box missed: the (miss) record is already final
                     }
                 }
