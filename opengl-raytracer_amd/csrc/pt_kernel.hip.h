@@ -193,6 +193,16 @@ DEV float pt_rand(Rng &s) {
 // ------------------------------------------------------------------------------------------ helpers
 DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (az * bz + ay * by) + ax * bx; }
 DEV float rsq(float x) { return 1.0f / __builtin_sqrtf(x); }  // IEEE sqrt then IEEE divide
+// The correctly rounded 1.0f / x in three instructions where that is provably the same value: v_rcp_f32 and ONE Newton step with
+// fused multiply-adds equal the IEEE quotient for EVERY float with FLT_MIN <= |x| <= 2^126 (tools/ubench/rcp_exact.hip runs all 2^32
+// bit patterns on the device: 0 mismatches there, and a NaN stays a NaN); beyond 2^126 (a denormal quotient) and for infinities the
+// compiler's ten-instruction expansion runs.  For the caller's purposes |x| below FLT_MIN need not be exact: the triangle test
+// rejects |det| < EPS whatever the reciprocal is.
+DEV float rcp_exact(float x) {
+    if (__builtin_fabsf(x) > 0x1p126f) return 1.0f / x;
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
 // GLSL min/max as the reference's GL implementation lowers them (other operand on NaN):
 DEV float fmin_g(float a, float b) { return (b != b) ? a : (a < b ? a : b); }
 DEV float fmax_g(float a, float b) { return (b != b) ? a : (a > b ? a : b); }
@@ -404,7 +414,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
         const float pz = T.dx * C.y - T.dy * C.x;
         const float det = dot3(B.x, B.y, B.z, px, py, pz);
         const float U = dot3(tx, ty, tz, px, py, pz);
-        const float inv = 1.0f / det;
+        const float inv = rcp_exact(det);
         const float u = U * inv;
         const float qx = ty * B.z - tz * B.y;
         const float qy = tz * B.x - tx * B.z;
