@@ -6,7 +6,7 @@ Bar: bit-exact float32 (stricter than north_star's 1e-4; the tolerance is assert
 import numpy as np
 import pytest
 
-from conftest import screen_cases, assert_bit_equal, golden_names, load_golden
+from conftest import PKG, screen_cases, assert_bit_equal, golden_names, load_golden
 from glrt_amd import device, dist, host, scenes
 
 pytestmark = pytest.mark.gpu
@@ -505,3 +505,22 @@ def test_depth_beyond_the_packed_path_state_matches_the_oracle(gpu_device, max_d
     d.sync()
     pt_oracle.render(sc, dict(pr, seed=host.frame_seed(3)), accum=ref)
     assert_bit_equal(d.read_accum(), ref, f"depth {max_depth}, two frames in one call")
+
+
+def test_short_reciprocal_equals_the_ieee_quotient_on_every_float():
+    """pt_kernel.hip.h: rcp_exact computes 1 / det of the triangle test as v_rcp_f32 + one Newton step wherever FLT_MIN <= |x| <= 2^126.
+    tools/ubench/rcp_exact.hip (built by __graft_entry__.build()) compares that sequence with the compiler's correctly rounded division
+    for every float bit pattern on the device: no mismatch inside the range the kernel uses it in."""
+    import re
+    import subprocess
+    exe = PKG / "lib" / "rcp_exact"
+    assert exe.exists(), f"{exe} not built: run __graft_entry__.build()"
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = re.findall(r"\|x\| in \[([^,]+), ([^\]]+)\]: (\d+) values; rcp \+ 1 Newton step: (\d+) mismatches", r.stdout)
+    assert len(rows) == 3, r.stdout
+    by_range = {(float(a), float(b)): (int(n), int(m)) for a, b, n, m in rows}
+    assert by_range[(1e-30, 1e30)][1] == 0 and by_range[(1e-30, 1e30)][0] > 3_000_000_000
+    assert by_range[(1e-4, 1e30)][1] == 0
+    n_all, m_all = [v for k, v in by_range.items() if k[0] < 1e-37][0]
+    assert m_all == 1 << 24, "the only mismatches in the normal range are the 2^24 patterns above 2^126 (denormal quotients)"
