@@ -222,6 +222,37 @@ def test_empty_and_edge_scenes(gpu_device):
     assert st.rays == 0 and np.all(acc[..., 3] == 1) and np.all(acc[..., :3] == 0)
 
 
+def test_forks_with_an_absent_child_match_the_oracle(gpu_device):
+    """The wire format lets a fork leave out children.x or children.y (raytrace.frag:299-307 pushes only indices >= 0); no builder here
+    produces that.  The kernel refers such a child to a never-hit record instead of testing for its absence: same image, same ray count,
+    in every kernel variant."""
+    from oracle import pt_oracle
+    scene, params = scenes.config_c1(96, 64, max_depth=5, n_samples=2, subdiv=1)
+    nodes = scene["bvh"].reshape(-1, 9).copy()
+    rng = np.random.default_rng(5)
+    forks = np.flatnonzero(nodes[:, 8] < 0)
+    extra = []
+    for k, f in enumerate(rng.choice(forks, 40, replace=False)):
+        side = 6 + (k & 1)                       # the child that gets a one-child fork put in front of it
+        child = int(nodes[f, side])
+        unary = nodes[child].copy()              # same box as the child it leads to
+        unary[6:9] = (-1.0, -1.0, -1.0)
+        unary[6 + ((k >> 1) & 1)] = float(child)  # ... hanging off children.x for some, children.y for others
+        nodes[f, side] = float(nodes.shape[0] + len(extra))
+        extra.append(unary)
+    sc = dict(scene, bvh=np.concatenate([nodes, np.array(extra, np.float32)], 0).reshape(-1, 3))
+    ref, ref_rays = pt_oracle.render(sc, params)
+    d = gpu_device
+    try:
+        for v in (2, 1, 0):
+            d.set_variant(v)
+            acc, st = gpu_render(d, sc, params)
+            assert st.rays == ref_rays
+            assert_bit_equal(acc, ref, f"absent children, variant {v}")
+    finally:
+        d.set_variant(2)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_all_kernel_variants_bit_identical(gpu_device, variant):
     """The tile megakernel (0), the persistent megakernel with path regeneration (1) and the
