@@ -55,8 +55,9 @@ def test_struct_layouts_match_header():
 
 
 def test_code_object_invariants():
-    """tools/isa_report.py --check on the built libglrtx.so: the render kernels spill nothing, and no instruction touches the
-    destination of trav_scan's s_load_dwordx16 between the load and its s_waitcnt (the load and the wait are separate asm statements)."""
+    """tools/isa_report.py --check on the built libglrtx.so: the render kernels spill nothing, no instruction touches the
+    destination of trav_scan's s_load_dwordx16 between the load and its s_waitcnt (the load and the wait are separate asm statements),
+    and the hand-written pop loop of trav_step keeps its sentinel and the ref it overwrites in different registers."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_report.py"), "--check"], capture_output=True, text=True, timeout=300)

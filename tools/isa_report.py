@@ -9,6 +9,8 @@ Invariants checked (they protect hand-written inline asm from register-allocatio
   * the list-scan kernels (pt_render_wgwf<*, true>) issue `s_load_dwordx16` from one asm statement and wait for it in
     another (trav_scan: the record is fetched one step ahead of its use).  Between the load and the `s_waitcnt
     lgkmcnt(0)` that follows it no instruction may read or copy the destination registers.
+  * the traversal step's pop loop (trav_step, inline asm) keeps the sentinel REF_FIN and the ref it overwrites in DIFFERENT registers
+    (both start out with the same value; sharing them made the loop write back the last culled ref instead of the sentinel).
 Works without a GPU (llvm-objcopy / clang-offload-bundler / llvm-readelf / llvm-objdump from /opt/rocm).
 """
 from __future__ import annotations
@@ -116,6 +118,37 @@ def check_scalar_prefetch(co: pathlib.Path, ks) -> list:
     return problems
 
 
+def check_pop_loop(co: pathlib.Path, ks) -> list:
+    """Every `v_cmp_ne_u32 vcc, 0, vSP ; v_cndmask_b32 vREF, vFIN, vREF, vcc` pair of the render kernels: vFIN != vREF, and the loop is there."""
+    problems = []
+    dis = subprocess.run([str(LLVM / "llvm-objdump"), "-d", "--no-show-raw-insn", str(co)], check=True, capture_output=True, text=True).stdout
+    body, name = {}, None
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+        if m:
+            name = m.group(1)
+            body[name] = []
+        elif name and ln.strip():
+            body[name].append(ln.split("//")[0].strip())
+    for k in ks:
+        if not any(t in k["pretty"] for t in ("pt_render_wgwf", "pt_render_persistent", "pt_render_kernel")):
+            continue
+        if "pt_render_wgwf" in k["pretty"] and k["pretty"].rstrip(">").endswith("true"):
+            continue  # list-scan instantiations never pop
+        ins = body.get(k["name"], [])
+        n = 0
+        for a, b in zip(ins, ins[1:]):
+            if re.fullmatch(r"v_cmp_ne_u32_e32 vcc, 0, v\d+", a):
+                m = re.fullmatch(r"v_cndmask_b32_e32 (v\d+), (v\d+), (v\d+), vcc", b)
+                if m and m.group(1) == m.group(3):
+                    n += 1
+                    if m.group(2) == m.group(1):
+                        problems.append(f"{k['pretty']}: pop loop: `{b}` -- the sentinel shares the ref's register")
+        if n == 0:
+            problems.append(f"{k['pretty']}: no pop loop found (v_cmp_ne_u32 vcc, 0, sp / v_cndmask ref, fin, ref)")
+    return problems
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=str(LIB))
@@ -130,7 +163,7 @@ def main():
         if a.out:
             pathlib.Path(a.out).write_text("llvm-readelf --notes of the gfx950 code object in libglrtx.so (tools/isa_report.py)\n\n" + t + "\n")
         if a.check:
-            bad = check_scalar_prefetch(co, ks)
+            bad = check_scalar_prefetch(co, ks) + check_pop_loop(co, ks)
             for b in bad:
                 print("ISA CHECK FAILED:", b)
             sys.exit(1 if bad else 0)
