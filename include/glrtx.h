@@ -112,7 +112,15 @@ int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t
                       const float *light, size_t n_light, const float *bvh, size_t n_nodes, int *n_fork_out,
                       int *stack_entries_out);
 
-/* Full image size; (re)allocates and clears this ctx's accumulator rows. */
+/* Host-only test hook (no device, no ctx): the repacked fork records as the kernels read them -- 16 floats per fork
+ * {child L box min, ref L} {child L box max, ref R} {child R box min, -} {child R box max, -}, refs as int bit patterns
+ * (>= 0 fork index, < 0 ~triangle; ~n_tri = the never-hit record that stands for an absent child) -- so that a test can replay
+ * the traversal step's push/pop rules on the packed tree and check stack_entries against the deepest stack it reaches.
+ * forks_out may be NULL (counts only).  No reference counterpart (the reference's stack is a fixed int[64], raytrace.frag:284). */
+int glrtx_debug_pack_forks(const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat, size_t n_mat,
+                           const float *light, size_t n_light, const float *bvh, size_t n_nodes, float *forks_out,
+                           size_t capacity_forks, int *n_fork_out, int *root_ref_out, int *stack_entries_out);
+
 /* Linear BVH built on the device (30-bit Morton order, Karras hierarchy, bottom-up fit), returned in the wire format
  * glrtx_upload_scene takes: nodes_out = (2*n_tri-1)*9 floats, root = node 0.  Takes the place of the reference's CPU
  * builder BVH::construct (src/core/bvh.cpp:59-160) for large scenes; identical, bit for bit, to glrt_bvh_build_lbvh
@@ -120,6 +128,7 @@ int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t
 int glrtx_build_lbvh(glrtx_ctx *ctx, const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
                      int *max_depth_out, float *build_ms_out);
 
+/* Full image size; (re)allocates and clears this ctx's accumulator rows. */
 int glrtx_resize(glrtx_ctx *ctx, int width, int height);
 int glrtx_clear(glrtx_ctx *ctx);
 

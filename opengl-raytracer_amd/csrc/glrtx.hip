@@ -30,6 +30,7 @@ namespace {
 constexpr int kStripeQuantum = 8;   // stripe heights are multiples of the 8x8 work tile
 constexpr int kGroupStripe = 8;     // stripe height glrtx_group uses: 1080 rows over 8 members = 136 / 128 rows (16-row stripes: 144 / 128)
 constexpr int kFramesBudgetGiB = 32;  // device memory one glrtx_render_frames launch may use for path state and sample planes
+constexpr unsigned kLaunchRing = 16;  // launches that may be outstanding per context before a new one waits for the oldest
 
 thread_local std::string g_create_error;
 
@@ -44,7 +45,16 @@ struct glrtx_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, evm = nullptr, ev1 = nullptr;  // per launch: start, render kernel done, all done
+    // Per launch: start, render kernel done, all done.  A RING of triples: a launch takes the next free one and never waits for an
+    // earlier launch; finished launches are folded into the stats lazily (glrtx_sync, glrtx_get_stats, or -- without blocking -- at the
+    // next launch).  Only with kLaunchRing launches outstanding does a new launch wait, for the oldest one.
+    struct LaunchRec {
+        hipEvent_t ev0 = nullptr, evm = nullptr, ev1 = nullptr;
+        const char *kernel = "";
+        int frames = 0;
+    };
+    LaunchRec ring[kLaunchRing];
+    unsigned ring_head = 0, ring_tail = 0;  // launches [tail, head) are recorded and not yet folded
     hipEvent_t tm0 = nullptr, tm1 = nullptr;      // glrtx_timer_*
     std::string err;
 
@@ -72,7 +82,6 @@ struct glrtx_ctx {
     int bound_rows = 0;       // rows the caller's buffer holds (glrtx_bind_accum)
 
     bool count_rays = false;
-    bool launch_pending = false;  // ev1 recorded, kernel time not yet folded into stats
     const char *last_kernel = "";  // name of the last render kernel launched (error reports)
     mutable bool counters_stale = false;          // a counting launch was issued since the device counters were last read
     mutable unsigned long long counters_host[2] = {0, 0};
@@ -121,23 +130,35 @@ int owned_rows_of(int height, int rank, int world, int stripe) {
 
 inline float as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
 
-// Fold the last launch's event pair into the stats (needs the stream to have passed ev1).
-int fold_launch_time(glrtx_ctx *c) {
-    if (!c->launch_pending) return GLRTX_OK;
-    if (hipError_t e = hipEventSynchronize(c->ev1); e != hipSuccess) {
-        // a fault inside the kernel surfaces here, not at the launch call: say which launch it was
-        c->launch_pending = false;
-        return fail(c, GLRTX_EDEVICE, "render launch failed on the device (%s): %s, %dx%d (%d owned rows), %d frame(s), device %d", hipGetErrorString(e),
-                    c->last_kernel, c->width, c->height, c->owned_rows, c->st.frames_last, c->device);
+// Fold finished launches' event triples into the stats, oldest first.  block = false: only those whose events have already
+// completed (hipEventQuery; nothing on the launch path ever waits for the device); block = true: all of them (the caller has
+// synchronised the stream, or wants to).  A fault inside a kernel surfaces here, not at the launch call: say which launch it was.
+int fold_launches(glrtx_ctx *c, bool block, unsigned keep = 0) {
+    while (c->ring_head - c->ring_tail > keep) {
+        glrtx_ctx::LaunchRec &r = c->ring[c->ring_tail % kLaunchRing];
+        hipError_t e = block ? hipEventSynchronize(r.ev1) : hipEventQuery(r.ev1);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); return GLRTX_OK; }
+        c->ring_tail++;
+        if (e != hipSuccess)
+            return fail(c, GLRTX_EDEVICE, "render launch failed on the device (%s): %s, %dx%d (%d owned rows), %d frame(s), device %d", hipGetErrorString(e),
+                        r.kernel, c->width, c->height, c->owned_rows, r.frames, c->device);
+        float ms = 0.f, ms2 = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, r.ev0, r.evm));   // render kernel
+        HIP_TRY(c, hipEventElapsedTime(&ms2, r.evm, r.ev1));  // plane accumulation (frames in flight), else ~0
+        c->st.kernel_ms_last = ms;
+        c->st.kernel_ms_total += ms;
+        c->st.accumulate_ms_total += ms2;
+        c->st.kernel_launches++;
     }
-    float ms = 0.f, ms2 = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->evm));   // render kernel
-    HIP_TRY(c, hipEventElapsedTime(&ms2, c->evm, c->ev1));  // plane accumulation (frames in flight), else ~0
-    c->st.kernel_ms_last = ms;
-    c->st.kernel_ms_total += ms;
-    c->st.accumulate_ms_total += ms2;
-    c->st.kernel_launches++;
-    c->launch_pending = false;
+    return GLRTX_OK;
+}
+
+// The event triple of the launch being issued.  Never blocks unless kLaunchRing launches are outstanding.
+int next_launch_rec(glrtx_ctx *c, glrtx_ctx::LaunchRec *&out) {
+    if (int rc = fold_launches(c, false)) return rc;
+    if (c->ring_head - c->ring_tail >= kLaunchRing)
+        if (int rc = fold_launches(c, true, kLaunchRing - 1)) return rc;
+    out = &c->ring[c->ring_head % kLaunchRing];
     return GLRTX_OK;
 }
 
@@ -285,13 +306,20 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
                 forks[4 * fi + slot].x = b[0]; forks[4 * fi + slot].y = b[1]; forks[4 * fi + slot].z = b[2];
                 forks[4 * fi + slot + 1].x = b[3]; forks[4 * fi + slot + 1].y = b[4]; forks[4 * fi + slot + 1].z = b[5];
             };
-            if (l >= 0) { put_box(0, l); forks[4 * fi].w = as_float(ref_of[l]); }
-            if (r >= 0) { put_box(2, r); forks[4 * fi + 1].w = as_float(ref_of[r]); }
-            // traversal continues with the right child while the left one waits on the stack
-            if (l >= 0 && r >= 0) need[n] = std::max(1 + need[r], need[l]);
-            else if (r >= 0) need[n] = need[r];
-            else if (l >= 0) need[n] = need[l];
-            else need[n] = 0;
+            // Traversal continues with the right child while the left one waits on the stack.  trav_step treats an absent child like a
+            // leaf -- always "passed", never hit -- so a fork with one child still pushes one entry: its only child is stored in the
+            // LEFT slot whichever wire slot it came from.  The step then continues with the never-hit record and pops the child right
+            // after it, with tHit unchanged in between: the same visits in the same order, and the absent entry never sits on the
+            // stack underneath a whole subtree (a chain of one-child forks needs ONE entry, like the reference's own stack).
+            if (l >= 0 && r >= 0) {
+                put_box(0, l); forks[4 * fi].w = as_float(ref_of[l]);
+                put_box(2, r); forks[4 * fi + 1].w = as_float(ref_of[r]);
+                need[n] = std::max(1 + need[r], need[l]);
+            } else if (l >= 0 || r >= 0) {
+                const int only = l >= 0 ? l : r;
+                put_box(0, only); forks[4 * fi].w = as_float(ref_of[only]);
+                need[n] = std::max(1, need[only]);  // the push of the child itself, then the child's own subtree from an empty stack
+            } else need[n] = 1;  // both absent: the left never-hit record is pushed, the right one "visited"
             st.pop_back();
         }
         root_ref = ref_of[0];
@@ -358,6 +386,7 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
     if (root_ref == REF_ABSENT) {  // empty scene: one childless fork, every ray misses
         forks.assign(4, make_float4(0.f, 0.f, 0.f, as_float(~(int)n_tri)));
         root_ref = 0;
+        stack_need = 1;  // a ray that passes the (degenerate) root box pushes the left never-hit record
         P.root_lo = make_float4(0.f, 0.f, 0.f, 0.f);
         P.root_hi = make_float4(0.f, 0.f, 0.f, 0.f);
     } else if (root_ref >= 0) {
@@ -463,21 +492,24 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
         if (n_frames > 1) ok = ok && c->wfPlanes.bytes >= (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4) && c->wfSeeds.bytes >= (size_t)n_frames * sizeof(float2);
         if (!ok) return fail(c, GLRTX_EDEVICE, "internal: wgwf launch shapes inconsistent (ids %zu, max id %zu, grid %d, block_paths %d, frames %d)", ids, max_id, grid, block_paths, n_frames);
     }
+    glrtx_ctx::LaunchRec *rec = nullptr;
+    if ((rc = next_launch_rec(c, rec))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, hipEventRecord(rec->ev0, c->stream));
     c->last_kernel = vine ? "pt_render_wgwf (list scan)" : "pt_render_wgwf";
     c->counters_stale = c->counters_stale || c->count_rays;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (float4 *)c->wfQ.p);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->evm, c->stream));
+    HIP_TRY(c, hipEventRecord(rec->evm, c->stream));
     if (n_frames > 1 && n_planes > 0) {
         const dim3 g((c->width + 63) / 64, (c->owned_rows + 3) / 4);
         hipLaunchKernelGGL(accumulate_planes_kernel, g, dim3(256), 0, c->stream, a.accum, a.pitch_f4, c->width, c->owned_rows,
                            (const float4 *)c->wfPlanes.p, n_planes);
         HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    c->launch_pending = true;
+    HIP_TRY(c, hipEventRecord(rec->ev1, c->stream));
+    rec->kernel = c->last_kernel; rec->frames = n_frames;
+    c->ring_head++;
     c->st.frames_last = n_frames;
     c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples * (uint64_t)n_frames;
     return GLRTX_OK;
@@ -514,7 +546,6 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
     if (!c) return fail(nullptr, GLRTX_ENOMEM, "out of host memory");
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->evm)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipEventCreate(&c->tm0)) != hipSuccess || (e = hipEventCreate(&c->tm1)) != hipSuccess ||
         (e = hipMalloc(&c->counter.p, 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long))) != hipSuccess ||
@@ -523,6 +554,12 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
         glrtx_destroy(c);
         return GLRTX_EDEVICE;
     }
+    for (auto &r : c->ring)
+        if ((e = hipEventCreate(&r.ev0)) != hipSuccess || (e = hipEventCreate(&r.evm)) != hipSuccess || (e = hipEventCreate(&r.ev1)) != hipSuccess) {
+            fail(nullptr, GLRTX_EDEVICE, "context setup failed: %s", hipGetErrorString(e));
+            glrtx_destroy(c);
+            return GLRTX_EDEVICE;
+        }
     c->stream = c->own_stream;
     c->n_cu = prop.multiProcessorCount;
     if (const char *v = std::getenv("GLRTX_VARIANT")) { const int x = std::atoi(v); if (x >= 0 && x <= 2) c->variant = x; }
@@ -539,9 +576,11 @@ void glrtx_destroy(glrtx_ctx *c) {
     dev_free(c->wfState); dev_free(c->wfQ); dev_free(c->wfSeeds); dev_free(c->wfPlanes);
     dev_free(c->bvhVert); dev_free(c->bvhTri); dev_free(c->bvhNodes);
     if (c->bvhWs.p) { (void)hipFree(c->bvhWs.p); c->bvhWs.p = nullptr; c->bvhWs.bytes = 0; }
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->evm) (void)hipEventDestroy(c->evm);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto &r : c->ring) {
+        if (r.ev0) (void)hipEventDestroy(r.ev0);
+        if (r.evm) (void)hipEventDestroy(r.evm);
+        if (r.ev1) (void)hipEventDestroy(r.ev1);
+    }
     if (c->tm0) (void)hipEventDestroy(c->tm0);
     if (c->tm1) (void)hipEventDestroy(c->tm1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -609,6 +648,25 @@ int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t
     if (int rc = pack_scene(nullptr, &g_create_error, P, vert, n_vert, tri, n_tri, mat, n_mat, light, n_light, bvh, n_nodes)) return rc;
     if (n_fork_out) *n_fork_out = (int)(P.forks.size() / 4);
     if (stack_entries_out) *stack_entries_out = P.stack_need;
+    return GLRTX_OK;
+}
+
+// Host-only: the fork records as the device will see them (16 floats each: {minL, refL} {maxL, refR} {minR, -} {maxR, -}; refs as
+// int bit patterns, a ref < 0 is ~triangle and ~n_tri the never-hit record an absent child refers to), for tests that replay
+// trav_step's push / pop rules on the packed tree and compare the deepest stack they reach with stack_entries.
+int glrtx_debug_pack_forks(const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat, size_t n_mat, const float *light,
+                           size_t n_light, const float *bvh, size_t n_nodes, float *forks_out, size_t capacity_forks, int *n_fork_out,
+                           int *root_ref_out, int *stack_entries_out) {
+    Packed P;
+    if (int rc = pack_scene(nullptr, &g_create_error, P, vert, n_vert, tri, n_tri, mat, n_mat, light, n_light, bvh, n_nodes)) return rc;
+    const size_t nf = P.forks.size() / 4;
+    if (n_fork_out) *n_fork_out = (int)nf;
+    if (root_ref_out) *root_ref_out = P.root_ref;
+    if (stack_entries_out) *stack_entries_out = P.stack_need;
+    if (forks_out) {
+        if (capacity_forks < nf) return pfail(nullptr, &g_create_error, GLRTX_EINVAL, "glrtx_debug_pack_forks: %zu forks, room for %zu", nf, capacity_forks);
+        std::memcpy(forks_out, P.forks.data(), nf * 16 * sizeof(float));
+    }
     return GLRTX_OK;
 }
 
@@ -749,7 +807,7 @@ int glrtx_bind_accum(glrtx_ctx *c, void *device_ptr, size_t pitch_bytes, int cap
 int glrtx_set_stream(glrtx_ctx *c, void *hip_stream) {
     if (!c) return GLRTX_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (int rc = fold_launch_time(c)) return rc;
+    if (int rc = fold_launches(c, true)) return rc;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return GLRTX_OK;
 }
@@ -816,7 +874,6 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     if (!c->accum || c->width < 1) return fail(c, GLRTX_EINVAL, "glrtx_render: no accumulator (call glrtx_resize)");
     if (p->n_samples < 0 || p->max_depth < 0) return fail(c, GLRTX_EINVAL, "glrtx_render: negative n_samples/max_depth");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (int rc = fold_launch_time(c)) return rc;
     c->st.launches++;
     if (c->owned_rows == 0) return GLRTX_OK;
 
@@ -852,6 +909,8 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     const bool ext = c->n_spheres > 0 || c->ext_flags != 0;
     const int variant = (ext || (c->variant == 2 && !wgwf_can_hold(p))) ? 1 : c->variant;
     if (variant == 2) return launch_wgwf(c, a, p, c->frames_seeds, c->frames_n);
+    glrtx_ctx::LaunchRec *rec = nullptr;
+    if (int rc = next_launch_rec(c, rec)) return rc;
     if (variant == 1) {
         // persistent kernel: grid = what is resident at once (occupancy x CUs), capped by the work available
         using PKernel = void (*)(const KernelArgs, unsigned *, const ExtArgs);
@@ -870,11 +929,11 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
         int grid = std::min(per_cu * c->n_cu, (n_chunks + waves_per_wg - 1) / waves_per_wg);
         if (grid < 1) grid = 1;
         HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
-        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(c, hipEventRecord(rec->ev0, c->stream));
         c->last_kernel = ext ? "pt_render_persistent (extensions)" : "pt_render_persistent";
         hipLaunchKernelGGL(pk, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, (unsigned *)c->work.p, ex);
     } else {
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, hipEventRecord(rec->ev0, c->stream));
     c->last_kernel = "pt_render_kernel";
     if (c->count_rays) {
         if (lds > 64 * 1024)
@@ -887,10 +946,11 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     }
     }
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->evm, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipEventRecord(rec->evm, c->stream));
+    HIP_TRY(c, hipEventRecord(rec->ev1, c->stream));
+    rec->kernel = c->last_kernel; rec->frames = 1;
+    c->ring_head++;
     c->counters_stale = c->counters_stale || c->count_rays;
-    c->launch_pending = true;
     c->st.frames_last = 1;
     c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples;
     return GLRTX_OK;
@@ -900,7 +960,10 @@ int glrtx_sync(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return fold_launch_time(c);
+    if (c->counters_stale && c->counter.p &&  // the device is idle here: bring the ray counters over now, so that glrtx_get_stats after a sync touches nothing
+        hipMemcpy(c->counters_host, c->counter.p, sizeof c->counters_host, hipMemcpyDeviceToHost) == hipSuccess)
+        c->counters_stale = false;
+    return fold_launches(c, true);
 }
 
 int glrtx_read_accum(glrtx_ctx *c, float *dst, size_t dst_pitch_bytes) {
@@ -946,9 +1009,11 @@ int glrtx_resolve_rgba8(glrtx_ctx *c, uint8_t *dst, size_t dst_pitch_bytes, floa
 
 int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
     if (!c || !out) return GLRTX_EINVAL;
+    if (hipSetDevice(c->device) == hipSuccess) (void)fold_launches(const_cast<glrtx_ctx *>(c), false);  // launches that have finished; never waits
     *out = c->st;
-    // the ray counters live on the device; they are read back (a blocking copy) only when a counting launch was issued since
-    // the last read, so polling the stats of a non-counting render loop costs no device round trip
+    // the ray counters live on the device; glrtx_sync brings them over, so after a sync this call touches nothing.  Only when a
+    // counting launch was issued since the last sync / read are they fetched here (a blocking copy); polling the stats of a
+    // non-counting render loop costs no device round trip
     if (c->counters_stale && c->counter.p && hipSetDevice(c->device) == hipSuccess &&
         hipMemcpy(c->counters_host, c->counter.p, sizeof c->counters_host, hipMemcpyDeviceToHost) == hipSuccess)
         c->counters_stale = false;

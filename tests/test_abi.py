@@ -45,7 +45,7 @@ def test_glrtx_abi_version_and_no_device_error_path():
 def test_python_binding_lists_the_same_exports():
     from glrt_amd import device
     names = declared_functions(ROOT / "include" / "glrtx.h")
-    assert set(device.EXPORTS) | {"glrtx_check_scene"} == set(names)
+    assert set(device.EXPORTS) | {"glrtx_check_scene", "glrtx_debug_pack_forks"} == set(names)  # the two host-only entry points are bound by tests/test_host.py
 
 
 def test_struct_layouts_match_header():

@@ -36,8 +36,13 @@ def test_fuzz_scene_matches_oracle(gpu_device, case):
         d.render_frames(params, seeds); d.sync()
         assert_bit_equal(d.read_accum(), ref, f"seed {seed} frames in flight")
         assert d.stats().rays == ref_rays
+        for variant in (2, 1):  # the compilations WITHOUT ray counting (variant 2's is what bench.py times)
+            d.set_variant(variant); d.clear(); d.reset_stats(); d.count_rays(False)
+            d.render_frames(params, seeds); d.sync()
+            assert_bit_equal(d.read_accum(), ref, f"seed {seed} variant {variant}, kernel without ray counting")
+            assert d.stats().rays == 0
     finally:
-        d.set_variant(2)
+        d.set_variant(2); d.count_rays(True)
 
 
 import os
@@ -71,3 +76,7 @@ def test_fuzz_random_parameters(gpu_device, seed):
     d.render_frames(params, seeds); d.sync()
     assert_bit_equal(d.read_accum(), ref, f"seed {seed}: {n_tri} tris {bvh} {w}x{h} depth {depth} spp {spp} {flags}")
     assert d.stats().rays == ref_rays
+    d.clear(); d.reset_stats(); d.count_rays(False)  # the compilation bench.py times
+    d.render_frames(params, seeds); d.sync()
+    assert_bit_equal(d.read_accum(), ref, f"seed {seed}, kernel without ray counting")
+    d.count_rays(True)

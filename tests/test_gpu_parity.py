@@ -13,6 +13,10 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4  # north_star: "pixels within 1e-4 of the GL reference"
 
+# The render kernels exist in two compilations: with ray counting (what the ray-count assertions need) and without (what bench.py
+# TIMES: pt_render_wgwf<false, *>, its own register allocation around the hand-written inline asm).  The image tests run on both.
+BOTH_INSTANTIATIONS = pytest.mark.parametrize("count_rays", [True, False], ids=["counting", "timed"])
+
 
 def gpu_render(d, scene, params, frames=None, count_rays=True):
     d.upload_scene(scene)
@@ -26,10 +30,11 @@ def gpu_render(d, scene, params, frames=None, count_rays=True):
     return d.read_accum(), d.stats()
 
 
+@BOTH_INSTANTIATIONS
 @pytest.mark.parametrize("name", golden_names())
-def test_hip_matches_reference_golden(gpu_device, name):
+def test_hip_matches_reference_golden(gpu_device, name, count_rays):
     scene, params, rows, frames, rgb, cnt = load_golden(name)
-    acc, st = gpu_render(gpu_device, scene, params, frames)
+    acc, st = gpu_render(gpu_device, scene, params, frames, count_rays=count_rays)
     acc = acc[rows[0]:rows[1]]
     assert np.nanmax(np.abs(acc[..., :3] - rgb)) <= TOL
     assert_bit_equal(acc[..., :3], rgb, f"{name} rgb")
@@ -56,6 +61,9 @@ def test_hip_bit_exact_vs_oracle(gpu_device, cfg, kw):
     acc, st = gpu_render(gpu_device, scene, params)
     assert st.rays == ref_rays
     assert_bit_equal(acc, ref, f"{cfg} {kw}")
+    acc, st = gpu_render(gpu_device, scene, params, count_rays=False)  # the instantiation bench.py times
+    assert st.rays == 0
+    assert_bit_equal(acc, ref, f"{cfg} {kw}, kernel without ray counting")
 
 
 def test_dof_and_seed_sweep_vs_oracle(gpu_device):
@@ -303,6 +311,13 @@ def test_frames_in_flight_equal_consecutive_frames_and_oracle(gpu_device, cfg, k
         ref_rays += n
     assert st.rays == ref_rays
     assert_bit_equal(bat, ref, f"{cfg} frames in flight vs oracle")
+    # the instantiation bench.py times (no ray counting), in flight and frame by frame
+    d.clear(); d.reset_stats(); d.count_rays(False)
+    d.render_frames(params, seeds); d.sync()
+    assert_bit_equal(d.read_accum(), ref, f"{cfg} frames in flight vs oracle, kernel without ray counting")
+    assert d.stats().rays == 0
+    seq_clean, _ = gpu_render(d, scene, params, frames=seeds, count_rays=False)
+    assert_bit_equal(seq_clean, ref, f"{cfg} consecutive launches vs oracle, kernel without ray counting")
 
 
 def test_frames_in_flight_full_size_partitions_and_accumulate_on_top(gpu_device):

@@ -220,6 +220,120 @@ def test_check_scene_rejects_too_deep_tree():
     assert len(forks) == n - 1
 
 
+def _pack(sc):
+    """glrtx_debug_pack_forks: (rc, fork records (n, 16) float32, root ref, stack entries)."""
+    L = device.lib()
+    fp = C.POINTER(C.c_float)
+    L.glrtx_debug_pack_forks.argtypes = [fp, C.c_size_t] * 5 + [fp, C.c_size_t] + [C.POINTER(C.c_int)] * 3
+    arrs = [np.ascontiguousarray(sc[k], np.float32) for k in ("vert", "tri", "mat", "light", "bvh")]
+    args = []
+    for a, n in zip(arrs, (15, 4, 18, 4, 9)):
+        args += [a.ctypes.data_as(fp), a.size // n]
+    nf, root, se = C.c_int(), C.c_int(), C.c_int()
+    rc = L.glrtx_debug_pack_forks(*args, None, 0, C.byref(nf), C.byref(root), C.byref(se))
+    if rc != 0:
+        return rc, None, 0, 0
+    forks = np.zeros((max(nf.value, 1), 16), np.float32)
+    rc = L.glrtx_debug_pack_forks(*args, forks.ctypes.data_as(fp), forks.shape[0], C.byref(nf), C.byref(root), C.byref(se))
+    return rc, forks[:nf.value], root.value, se.value
+
+
+def _deepest_stack(forks, root):
+    """Replay of trav_step's push / pop rules (pt_kernel.hip.h) with every box test passing -- the worst case, a failed test only
+    removes entries: at a fork both children "pass" (a leaf or an absent child always does), the left ref is pushed, the walk goes on
+    with the right one; a leaf (ref < 0, the never-hit record included) pops.  Returns (deepest stack, records visited)."""
+    refs = forks.view(np.int32)[:, [3, 7]]
+    cur, stack, deepest, visited = root, [], 0, 0
+    while True:
+        visited += 1
+        if cur >= 0:
+            stack.append(int(refs[cur, 0]))
+            deepest = max(deepest, len(stack))
+            cur = int(refs[cur, 1])
+        elif stack:
+            cur = stack.pop()
+        else:
+            return deepest, visited
+
+
+def _with_one_child_forks(scene, n_extra, seed, chain=1):
+    """Put `chain` one-child forks (children.x or children.y left out) in front of n_extra children."""
+    nodes = scene["bvh"].reshape(-1, 9).copy()
+    rng = np.random.default_rng(seed)
+    forks = np.flatnonzero(nodes[:, 8] < 0)
+    extra = []
+    for k, f in enumerate(rng.choice(forks, min(n_extra, len(forks)), replace=False)):
+        side = 6 + (k & 1)
+        child = int(nodes[f, side])
+        box = nodes[child, 0:6].copy()            # every inserted fork has the box of the child the chain leads to
+        for j in range(chain):
+            unary = np.zeros(9, np.float32)
+            unary[0:6] = box
+            unary[6:9] = (-1.0, -1.0, -1.0)
+            unary[6 + (((k + j) >> 1) & 1)] = float(child)   # hanging off children.x for some, children.y for others
+            child = nodes.shape[0] + len(extra)
+            extra.append(unary)
+        nodes[f, side] = float(child)
+    return dict(scene, bvh=np.concatenate([nodes, np.array(extra, np.float32).reshape(-1, 9)], 0).reshape(-1, 3))
+
+
+@pytest.mark.parametrize("case", ["sah", "lbvh", "comb", "one_child", "one_child_chains", "single_triangle", "empty"])
+def test_stack_entries_cover_the_deepest_stack_the_traversal_step_can_reach(case):
+    """an absent child is the never-hit record and IS pushed; the stack budget must count it."""
+    if case == "empty":
+        sc = dict(vert=np.zeros((0, 3), np.float32), tri=np.zeros((0, 4), np.float32), mat=np.zeros((6, 3), np.float32),
+                  light=np.zeros((0, 4), np.float32), bvh=np.zeros((0, 3), np.float32))
+    elif case == "single_triangle":
+        sc, _ = scenes.config_c3(16, 16, n=1)
+    elif case == "comb":
+        sc, _ = scenes.config_c3(16, 16, n=60, bvh="chain")
+        nodes = sc["bvh"].reshape(-1, 9).copy()
+        fk = nodes[:, 8] < 0
+        nodes[fk, 6], nodes[fk, 7] = nodes[fk, 7].copy(), nodes[fk, 6].copy()
+        sc = dict(sc, bvh=nodes.reshape(-1, 3))
+    elif case == "lbvh":
+        sc, _ = scenes.config_c3(16, 16, n=3000, bvh="lbvh")
+    else:
+        sc, _ = scenes.config_c1(16, 16, subdiv=1)
+        if case == "one_child":
+            sc = _with_one_child_forks(sc, 60, 5)
+        elif case == "one_child_chains":
+            sc = _with_one_child_forks(sc, 25, 7, chain=5)
+    rc, forks, root, need = _pack(sc)
+    assert rc == 0
+    n_tri = sc["tri"].reshape(-1, 4).shape[0]
+    if root < 0:
+        assert need == 0 and n_tri == 1
+        return
+    deepest, visited = _deepest_stack(forks, root)
+    assert deepest == need, (case, deepest, need)
+    refs = forks.view(np.int32)[:, [3, 7]]
+    assert (refs >= ~n_tri).all() and (refs < len(forks)).all()
+    assert visited >= 2 * len(forks)  # every fork and both of its refs were met once: the packed refs form a tree
+
+
+def test_a_long_chain_of_one_child_forks_needs_one_stack_entry_like_the_reference():
+    """raytrace.frag:299-307 pushes only the children that exist, so a chain of one-child forks keeps its stack at one entry; the
+    packed tree stores an only child in the left slot, and neither overflows the budget nor trips GLRTX_EDEPTH."""
+    sc, _ = scenes.config_c3(16, 16, n=2, bvh="chain")
+    nodes = sc["bvh"].reshape(-1, 9)                # node 0: a fork over two leaves (nodes 1 and 2)
+    assert nodes.shape[0] == 3 and nodes[0, 8] < 0
+    n_chain = 100
+    out = [None] * (3 + n_chain)
+    out[1], out[2] = nodes[1].copy(), nodes[2].copy()
+    out[3 + n_chain - 1] = nodes[0].copy()          # the two-leaf fork, at the end of the chain
+    for j in range(n_chain):                        # node 0, 3, 4, ...: one-child forks, each leading to the next
+        u = nodes[0].copy()
+        u[6:9] = (-1.0, -1.0, -1.0)
+        u[6 + (j & 1)] = float(3 + j)
+        out[0 if j == 0 else 3 + j - 1] = u
+    rc, forks, root, need = _pack(dict(sc, bvh=np.array(out, np.float32).reshape(-1, 3)))
+    assert rc == 0, device.lib().glrtx_last_error(None)
+    assert len(forks) == n_chain + 1
+    deepest, _ = _deepest_stack(forks, root)
+    assert need == deepest == 1
+
+
 def test_empty_scene_is_valid():
     sc = dict(vert=np.zeros((0, 3), np.float32), tri=np.zeros((0, 4), np.float32), mat=np.zeros((6, 3), np.float32),
               light=np.zeros((0, 4), np.float32), bvh=np.zeros((0, 3), np.float32))
