@@ -30,6 +30,7 @@ namespace {
 constexpr int kStripeQuantum = 8;   // stripe heights are multiples of the 8x8 work tile
 constexpr int kGroupStripe = 8;     // stripe height glrtx_group uses: 1080 rows over 8 members = 136 / 128 rows (16-row stripes: 144 / 128)
 constexpr int kFramesBudgetGiB = 32;  // device memory one glrtx_render_frames launch may use for path state and sample planes
+constexpr float kInf = std::numeric_limits<float>::infinity();
 constexpr unsigned kLaunchRing = 16;  // launches that may be outstanding per context before a new one waits for the oldest
 
 thread_local std::string g_create_error;
@@ -281,7 +282,8 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
                     continue;
                 }
                 ref_of[n] = (int)(forks.size() / 4);
-                for (int k = 0; k < 4; k++) forks.push_back(make_float4(0.f, 0.f, 0.f, as_float(~(int)n_tri)));  // absent child: the never-hit record
+                // both children start out absent: the never-hit record ~n_tri behind an infinite box (see put_box)
+                for (int k = 0; k < 4; k++) { const float e = (k & 1) ? kInf : -kInf; forks.push_back(make_float4(e, e, e, as_float(~(int)n_tri))); }
                 // forks are numbered in the order the traversal meets them (children.y first, raytrace.frag:299-307):
                 // the first-visited child's record directly follows its parent's
                 f.stage = 1;
@@ -301,7 +303,11 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
             child(n, 0, l);
             child(n, 1, r);
             const int fi = ref_of[n];
-            auto put_box = [&](int slot, int child) {  // child box into the parent's record
+            // child box into the parent's record.  A LEAF child is never box-tested (raytrace.frag:310-331): it gets the box
+            // (-inf, +inf), for which the slab test passes by itself with entry distance -inf -- the traversal step then needs no
+            // test of the ref's sign (an absent child, the never-hit record, is treated the same way)
+            auto put_box = [&](int slot, int child) {
+                if (!is_fork(child)) return;
                 const float *b = bvh + 9 * (size_t)child;
                 forks[4 * fi + slot].x = b[0]; forks[4 * fi + slot].y = b[1]; forks[4 * fi + slot].z = b[2];
                 forks[4 * fi + slot + 1].x = b[3]; forks[4 * fi + slot + 1].y = b[4]; forks[4 * fi + slot + 1].z = b[5];
@@ -384,7 +390,8 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         root_ref = newid[root_ref];
     }
     if (root_ref == REF_ABSENT) {  // empty scene: one childless fork, every ray misses
-        forks.assign(4, make_float4(0.f, 0.f, 0.f, as_float(~(int)n_tri)));
+        forks.clear();
+        for (int k = 0; k < 4; k++) { const float e = (k & 1) ? kInf : -kInf; forks.push_back(make_float4(e, e, e, as_float(~(int)n_tri))); }
         root_ref = 0;
         stack_need = 1;  // a ray that passes the (degenerate) root box pushes the left never-hit record
         P.root_lo = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1042,6 +1049,15 @@ int glrtx_debug_trav_hist(unsigned long long out[16]) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_hist), 16 * sizeof(unsigned long long)) != hipSuccess) return GLRTX_EDEVICE;
     unsigned long long z[16] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_hist), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
+    return GLRTX_OK;
+}
+#endif
+
+#ifdef GLRTX_STEP_TIMING
+int glrtx_debug_step_timing(unsigned long long out[4]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_timing), 4 * sizeof(unsigned long long)) != hipSuccess) return GLRTX_EDEVICE;
+    unsigned long long z[4] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_step_timing), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
     return GLRTX_OK;
 }
 #endif

@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "trav_asm.hip.h"
+
 namespace glrtx {
 
 constexpr int kBlockThreads = 256;      // 4 wavefronts: a 16x16-pixel tile, one 8x8 sub-tile per wave
@@ -242,7 +244,7 @@ DEV bool box_pass(float4 lo, float4 hi, float ox, float oy, float oz, float ix, 
 // may still shrink; the entry keeps its entry distance t0 and is re-checked against the current tHit
 // when popped, which reproduces the reference's visit set exactly (its test at pop time is
 // t1 >= t0 -- independent of tHit -- and t0 <= tHit).  Leaf children are never box-tested, as in the
-// reference (:310-331).  The per-lane stack lives in LDS as 8-byte {ref, t0} entries, entry e of lane l
+// reference (:310-331).  The per-lane stack lives in LDS as 8-byte {t0, ref} entries, entry e of lane l
 // at byte (e * kBlockThreads + l) * 8: one conflict-free ds_read/write_b64 per pop/push.
 #ifdef GLRTX_TRAV_STATS
 // Diagnostic build only (-DGLRTX_TRAV_STATS): [0] wave loop iterations, [1] active lanes summed over
@@ -384,21 +386,22 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
         float t0l, t0r;
         const bool bl = box_pass(A, B, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0l);
         const bool br = box_pass(C, D, T.ox, T.oy, T.oz, T.ix, T.iy, T.iz, T.h.t, t0r);
-        // leaf children are never box-tested (:310-331); (an absent child is the never-hit record ~n_tri)
-        const bool pl = l < 0 || bl;
-        const bool pr = r < 0 || br;
+        // leaf children are never box-tested (:310-331): in the packed record a leaf child -- and an absent one, the never-hit
+        // record ~n_tri -- carries the box (-inf, +inf), which passes by itself with t0 = -inf (pack_scene)
+        const bool pl = bl;
+        const bool pr = br;
 #ifdef GLRTX_NEAR_FIRST_EXPERIMENT
         // MEASUREMENT ONLY (never shipped: ties may resolve differently from the reference): a path ray visits the nearer child first
         const float kl = l < 0 ? -PT_INFTY : t0l, kr = r < 0 ? -PT_INFTY : t0r;
         const bool lf = pl && pr && T.stop_d == -__builtin_inff() && kl < kr;
         if (pl && pr) {
-            reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = lf ? make_int2(r, __float_as_int(kr)) : make_int2(l, __float_as_int(kl));
+            reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = lf ? make_int2(__float_as_int(kr), r) : make_int2(__float_as_int(kl), l);
             T.sp++;
         }
         T.cur = lf ? l : (pr ? r : l);
 #else
         if (pl && pr) {  // continue with the right child, the left one waits on the stack
-            reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = make_int2(l, __float_as_int(l < 0 ? -PT_INFTY : t0l));  // one ds_write_b64
+            reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = make_int2(__float_as_int(t0l), l);  // {t0, ref}: one ds_write_b64
             T.sp++;
         }
         T.cur = pr ? r : l;
@@ -454,8 +457,8 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
             "s_cbranch_execz 2f\n\t"
             "v_add_u32 %[sp], -1, %[sp]\n\t"
             "v_lshl_add_u32 %[addr], %[sp], 11, %[base]\n\t"
-            "ds_read_b32 %[ref], %[addr]\n\t"
-            "ds_read_b32 %[t0], %[addr] offset:4\n\t"
+            "ds_read_b32 %[ref], %[addr] offset:4\n\t"
+            "ds_read_b32 %[t0], %[addr]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "v_cmp_gt_f32 vcc, %[t0], %[th]\n\t"
             "s_and_b64 exec, exec, vcc\n\t"
@@ -473,6 +476,40 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
     if (T.cur == REF_FIN) { TS_DONE; }
 #endif
     return T.cur == REF_FIN;
+}
+
+// Up to GLRTX_STEPS_PER_TRIP steps of trav_step<true> for the lanes enabled on entry, as one hand-written asm statement
+// (trav_asm.hip.h); a lane leaves early when its ray is finished (T.cur == REF_FIN).  Used by the wavefront kernel.
+#ifdef GLRTX_STEP_TIMING
+// Diagnostic build only: [0] lane-steps, [1] shader clocks of those steps summed per lane, [2] the part spent waiting for the node fetch
+__device__ unsigned long long g_step_timing[4];
+struct StepTiming { unsigned t = 0, w = 0, n = 0; };
+#define GLRTX_TS_PARAM , StepTiming &ST
+#define GLRTX_TS_OPERANDS , [tt] "+&v"(ST.t), [tw] "+&v"(ST.w), [tn] "+&v"(ST.n)
+#define GLRTX_TS_CLOBBERS , "s90", "s91", "s92", "s93", "s94", "s95"
+#else
+#define GLRTX_TS_PARAM
+#define GLRTX_TS_OPERANDS
+#define GLRTX_TS_CLOBBERS
+#endif
+DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) {
+    unsigned long long s_entry, s_act, s_leaf, s_bl, s_br, s_pop, s_tmp;
+    const unsigned stk = (unsigned)(uintptr_t)stack;
+    static_assert(kBlockThreads * 8 == 1 << 11, "trav_asm.hip.h shifts the stack index by 11: entry e of lane l at byte (e * kBlockThreads + l) * 8");
+    static_assert(REF_FIN == INT32_MIN, "trav_asm.hip.h materialises REF_FIN with v_bfrev_b32 v, 1");
+    asm volatile(
+        "s_mov_b64 %[entry], exec\n\t"
+        "s_mov_b64 %[act], exec\n\t"
+        "v_bfrev_b32 v107, 1\n\t"
+        GLRTX_REP(GLRTX_STEPS_PER_TRIP, GLRTX_TRAV_STEP_ASM)
+        "99:\n\t"
+        "s_mov_b64 exec, %[entry]"
+        : [th] "+&v"(T.h.t), [tri] "+&v"(T.h.tri), [hu] "+&v"(T.h.u), [hv] "+&v"(T.h.v), [cur] "+&v"(T.cur), [sp] "+&v"(T.sp),
+          [entry] "=&s"(s_entry), [act] "=&s"(s_act), [leaf] "=&s"(s_leaf), [bl] "=&s"(s_bl), [br] "=&s"(s_br), [pop] "=&s"(s_pop), [tmp] "=&s"(s_tmp) GLRTX_TS_OPERANDS
+        : [ox] "v"(T.ox), [oy] "v"(T.oy), [oz] "v"(T.oz), [dx] "v"(T.dx), [dy] "v"(T.dy), [dz] "v"(T.dz), [ix] "v"(T.ix), [iy] "v"(T.iy), [iz] "v"(T.iz),
+          [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [bias] "s"(sc.node_bias), [eps] "s"(PT_EPS), [big] "s"(0x1p126f)
+        : "vcc", "scc", "memory", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
+          "v112", "v113", "v114", "v115", "v116", "v117" GLRTX_TS_CLOBBERS);
 }
 
 // intersect(Ray, Triangle) :226-257 against the running closest hit; v0 / e1 = v1-v0 / e2 = v2-v0
@@ -1513,7 +1550,7 @@ __device__ uint4 g_trip_log[16][64];
 // dependent round trips -- cost 14 % of the phase.  A second chunk fetched ahead of need was kept in round 1; measured
 // again after the kernel lost its spills it bought nothing (profiles/r02_ab_occupancy.txt) and its 8 registers were freed.)
 template <bool VINE>
-DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, const float4 *lds_top, int *stack, const float4 *rq, int n_rays,
+DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, [[maybe_unused]] const float4 *lds_top, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned *light_bits, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
     if (VINE) {  // list scan: every ray takes the same number of steps, so waves simply take 64 rays at a time
@@ -1537,7 +1574,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         return;
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int n_top = a.sc.n_top;
+    [[maybe_unused]] const int n_top = a.sc.n_top;
     const float4 none = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID));
     float4 cur_o = none, cur_d = none;  // this lane's record of the wave's current chunk
     float cur_ix = 0.f, cur_iy = 0.f, cur_iz = 0.f;  // ... and 1 / direction (:260), computed when the chunk arrives
@@ -1573,6 +1610,9 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
     Trav T;
     T.cur = 0; T.sp = 0;
     T.h.t = PT_INFTY; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
+#ifdef GLRTX_STEP_TIMING
+    StepTiming step_timing;
+#endif
     auto save_hit = [&]() {
         const unsigned id = rid >> 1;  // path id (path ray) or the path's position in the workgroup's path queue (shadow ray)
         if (rid & 1u) {  // the light test of :367, decided here (T.stop_d is the light sample's distance): one bit for the shade phase
@@ -1634,18 +1674,38 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         }
         // GLRTX_STEPS_PER_TRIP traversal steps per trip through the loop: cuts the refill bookkeeping (ballots, branches) on
         // the latency-critical instruction stream; a lane that finishes on the first step idles for one step
+#ifdef GLRTX_PHASE_STATS
+        const unsigned long long sb0 = __builtin_amdgcn_s_memtime();
+#endif
         if (active) {
+#if defined(GLRTX_TRAV_STATS) || GLRTX_LDS_TOP_MAX > 0 || defined(GLRTX_CXX_STEP)  // diagnostic / experiment builds: the C++ statement of the step
             bool fin = trav_step<true>(a.sc, stack, T, lds_top, n_top);
 #pragma unroll
             for (int k = 1; k < GLRTX_STEPS_PER_TRIP; k++)
                 if (!fin) fin = trav_step<true>(a.sc, stack, T, lds_top, n_top);
+#else
+#ifdef GLRTX_STEP_TIMING
+            trav_steps_asm(a.sc, stack, T, step_timing);
+#else
+            trav_steps_asm(a.sc, stack, T);
+#endif
+            const bool fin = T.cur == REF_FIN;
+#endif
             if (fin) {
                 active = false;
                 unsaved = true;
             }
         }
+#ifdef GLRTX_PHASE_STATS
+        if (threadIdx.x == 0) { atomicAdd(&g_phase_cycles[7], __builtin_amdgcn_s_memtime() - sb0); }
+#endif
     }
     if (unsaved) save_hit();
+#ifdef GLRTX_STEP_TIMING
+    atomicAdd(&g_step_timing[0], (unsigned long long)step_timing.n);
+    atomicAdd(&g_step_timing[1], (unsigned long long)step_timing.t);
+    atomicAdd(&g_step_timing[2], (unsigned long long)step_timing.w);
+#endif
 }
 
 // Shade phase of one trip, run by a whole workgroup: every live path (pq[0..n_paths))

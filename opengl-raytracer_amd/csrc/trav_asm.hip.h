@@ -1,0 +1,227 @@
+// trav_asm.hip.h -- the traversal step of the wavefront kernel, written by hand for gfx950.
+//
+// trav_steps_asm() runs up to GLRTX_STEPS_PER_TRIP steps of the BVH state machine of trav_step() (pt_kernel.hip.h; reference:
+// raytrace.frag:276-335 with intersectBBox :259-274 and intersect(Ray, Triangle) :226-257) for the lanes enabled on entry, in ONE asm
+// statement.  It performs the same IEEE operations in the same order as trav_step -- the megakernels keep the C++ statement, and
+// tests/test_gpu_parity.py::test_all_kernel_variants_bit_identical compares the two on the device.
+//
+// Why by hand (profiles/r03_ubench_valu.json): on this chip a scalar instruction costs a SIMD MORE issue time than a vector multiply
+// (3.2 against 2.0 clk with four waves resident), a taken branch 5.9, and the two kinds overlap only partly.  The compiler's version of
+// the step spent ~45 scalar instructions and ~15 branches per wave-step on exec-mask bookkeeping (bools kept as SGPR pairs, merged and
+// re-split around every `if`) next to its ~144 vector instructions.  Here:
+//   * lane sets are exec masks produced directly by v_cmp / v_cmpx; the triangle test's seven-term predicate is a chain of v_cmpx
+//     (each narrows exec, no scalar instruction), with two early exits for waves whose leaf lanes have all failed;
+//   * the hit is committed with four moves under the narrowed exec instead of four selects;
+//   * the fork arm runs without a branch around it (nearly every step has fork lanes), the leaf arm is skipped when no lane is at a leaf;
+//   * a stack entry is {t0, ref}: the fork arm computes t0 of the left child into the register next to its ref, so a push is one
+//     ds_write_b64 of a register pair that already exists, and a pop one ds_read_b64;
+//   * leaf (and absent) children carry an INFINITE box in the packed fork record (pack_scene), so "a leaf child is never box-tested"
+//     (raytrace.frag:310-331) needs no test of the ref's sign: the slab test passes by itself and yields t0 = -inf.
+// ~122 vector + ~13 scalar + ~8 branch instructions per step.
+//
+// Register use: v96-v117 are scratch (clobbered): v96-v99 A, v100-v103 B, v104-v106 C, v108-v110 D (the 56-byte record; the arms
+// compute in place in it), v107 = REF_FIN, v111 an address / u, v112-v117 temporaries.  gfx950 hazards handled by hand (the assembler does not insert wait
+// states into inline asm): one independent instruction between v_rcp_f32 and the first use of its result (trans forwarding);
+// >= 4 instructions between v_div_scale (vcc) and v_div_fmas.
+#pragma once
+
+#ifndef GLRTX_STEPS_PER_TRIP
+#define GLRTX_STEPS_PER_TRIP 6
+#endif
+
+// One step.  On entry exec = the lanes still running (== %[act]).  Falls through with exec = %[act] = the lanes still running after the
+// step, or jumps to 99 (end of block) when none is left.
+// Diagnostic build only (-DGLRTX_STEP_TIMING, tools/gpu_steptime.py): per lane, the shader clocks its steps took and the part of them
+// spent in the s_waitcnt behind the node fetch.  Uses s90-s95 (clobbered) and three more accumulator operands.
+#ifdef GLRTX_STEP_TIMING
+#define GLRTX_TS_BEGIN "s_memtime s[90:91]\n\t"
+#define GLRTX_TS_WAIT0 "s_memtime s[92:93]\n\t"
+#define GLRTX_TS_WAIT1 "s_memtime s[94:95]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s92, s94, s92\n\t"
+#define GLRTX_TS_END "s_memtime s[94:95]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s94, s94, s90\n\tv_add_u32 %[tt], s94, %[tt]\n\tv_add_u32 %[tw], s92, %[tw]\n\tv_add_u32 %[tn], 1, %[tn]\n\t"
+#else
+#define GLRTX_TS_BEGIN
+#define GLRTX_TS_WAIT0
+#define GLRTX_TS_WAIT1
+#define GLRTX_TS_END
+#endif
+
+#define GLRTX_TRAV_STEP_ASM \
+    GLRTX_TS_BEGIN \
+    "v_lshl_add_u32 v111, %[cur], 6, %[bias]\n\t"                                                                                                      \
+    "global_load_dwordx4 v[96:99], v111, %[base]\n\t"                                                                                                  \
+    "global_load_dwordx4 v[100:103], v111, %[base] offset:16\n\t"                                                                                      \
+    "global_load_dwordx3 v[104:106], v111, %[base] offset:32\n\t"                                                                                      \
+    "global_load_dwordx3 v[108:110], v111, %[base] offset:48\n\t"                                                                                      \
+    "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t"                           /* lanes at a triangle */                                                      \
+    "s_andn2_b64 exec, exec, %[leaf]\n\t"                               /* ---- fork arm: exec = lanes at a fork (may be none) */                      \
+    GLRTX_TS_WAIT0 "s_waitcnt vmcnt(0)\n\t" GLRTX_TS_WAIT1                                                                                                                           \
+    "v_sub_f32 v100, v100, %[ox]\n\t"                                   /* left child: (hi - o), (lo - o) in place */                                  \
+    "v_sub_f32 v101, v101, %[oy]\n\t"                                                                                                                  \
+    "v_sub_f32 v102, v102, %[oz]\n\t"                                                                                                                  \
+    "v_sub_f32 v96, v96, %[ox]\n\t"                                                                                                                    \
+    "v_sub_f32 v97, v97, %[oy]\n\t"                                                                                                                    \
+    "v_sub_f32 v98, v98, %[oz]\n\t"                                                                                                                    \
+    "v_mul_f32 v100, v100, %[ix]\n\t"                                   /* f = (hi - o) / d, n = (lo - o) / d */                                       \
+    "v_mul_f32 v101, v101, %[iy]\n\t"                                                                                                                  \
+    "v_mul_f32 v102, v102, %[iz]\n\t"                                                                                                                  \
+    "v_mul_f32 v96, v96, %[ix]\n\t"                                                                                                                    \
+    "v_mul_f32 v97, v97, %[iy]\n\t"                                                                                                                    \
+    "v_mul_f32 v98, v98, %[iz]\n\t"                                                                                                                    \
+    "v_max_f32 v112, v100, v96\n\t"                                                                                                                    \
+    "v_min_f32 v96, v100, v96\n\t"                                                                                                                     \
+    "v_max_f32 v113, v101, v97\n\t"                                                                                                                    \
+    "v_min_f32 v97, v101, v97\n\t"                                                                                                                     \
+    "v_max_f32 v114, v102, v98\n\t"                                                                                                                    \
+    "v_min_f32 v100, v102, v98\n\t"                                                                                                                    \
+    "v_min3_f32 v112, v112, v113, v114\n\t"                             /* t1 */                                                                       \
+    "v_max3_f32 v98, v96, v97, v100\n\t"                                /* t0 of the left child, next to its ref: v[98:99] = {t0, ref} */              \
+    "v_min_f32 v112, v112, %[th]\n\t"                                                                                                                  \
+    "v_cmp_ge_f32_e64 %[bl], v112, v98\n\t"                             /* min(t1, tHit) >= t0 */                                                      \
+    "v_sub_f32 v108, v108, %[ox]\n\t"                                   /* right child: lo v104..106, hi v108..110 */                                  \
+    "v_sub_f32 v109, v109, %[oy]\n\t"                                                                                                                  \
+    "v_sub_f32 v110, v110, %[oz]\n\t"                                                                                                                  \
+    "v_sub_f32 v104, v104, %[ox]\n\t"                                                                                                                  \
+    "v_sub_f32 v105, v105, %[oy]\n\t"                                                                                                                  \
+    "v_sub_f32 v106, v106, %[oz]\n\t"                                                                                                                  \
+    "v_mul_f32 v108, v108, %[ix]\n\t"                                                                                                                  \
+    "v_mul_f32 v109, v109, %[iy]\n\t"                                                                                                                  \
+    "v_mul_f32 v110, v110, %[iz]\n\t"                                                                                                                  \
+    "v_mul_f32 v104, v104, %[ix]\n\t"                                                                                                                  \
+    "v_mul_f32 v105, v105, %[iy]\n\t"                                                                                                                  \
+    "v_mul_f32 v106, v106, %[iz]\n\t"                                                                                                                  \
+    "v_max_f32 v112, v108, v104\n\t"                                                                                                                   \
+    "v_min_f32 v104, v108, v104\n\t"                                                                                                                   \
+    "v_max_f32 v113, v109, v105\n\t"                                                                                                                   \
+    "v_min_f32 v105, v109, v105\n\t"                                                                                                                   \
+    "v_max_f32 v114, v110, v106\n\t"                                                                                                                   \
+    "v_min_f32 v106, v110, v106\n\t"                                                                                                                   \
+    "v_min3_f32 v112, v112, v113, v114\n\t"                                                                                                            \
+    "v_max3_f32 v104, v104, v105, v106\n\t"                                                                                                            \
+    "v_min_f32 v112, v112, %[th]\n\t"                                                                                                                  \
+    "v_cmp_ge_f32_e64 %[br], v112, v104\n\t"                                                                                                           \
+    "v_cndmask_b32_e64 %[cur], v99, v103, %[br]\n\t"                    /* go on with the right child if it passed, else with the left */              \
+    "s_or_b64 %[tmp], %[bl], %[br]\n\t"                                                                                                                \
+    "s_andn2_b64 %[pop], exec, %[tmp]\n\t"                              /* fork lanes with neither child: pop */                                       \
+    "s_and_b64 exec, %[bl], %[br]\n\t"                                  /* both passed: the left one waits on the stack */                             \
+    "v_lshl_add_u32 v111, %[sp], 11, %[stk]\n\t"                                                                                                       \
+    "ds_write_b64 v111, v[98:99]\n\t"                                                                                                                  \
+    "v_add_u32 %[sp], 1, %[sp]\n\t"                                                                                                                    \
+    "s_and_b64 exec, %[act], %[leaf]\n\t"                               /* ---- leaf arm: A = {v0, material} v96..99, B = v1 - v0 v100..102, C = v2 - v0 v104..106 */ \
+    "s_cbranch_scc0 21f\n\t"                                                                                                                           \
+    "v_not_b32 v99, %[cur]\n\t"                                         /* triangle index */                                                           \
+    "v_mov_b32 %[cur], v107\n\t"                                        /* nothing follows a leaf but the stack */                                     \
+    "v_mul_f32 v112, %[dy], v106\n\t"                                   /* p = d x e2 */                                                               \
+    "v_mul_f32 v115, %[dz], v105\n\t"                                                                                                                  \
+    "v_sub_f32 v112, v112, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v113, %[dz], v104\n\t"                                                                                                                  \
+    "v_mul_f32 v115, %[dx], v106\n\t"                                                                                                                  \
+    "v_sub_f32 v113, v113, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v114, %[dx], v105\n\t"                                                                                                                  \
+    "v_mul_f32 v115, %[dy], v104\n\t"                                                                                                                  \
+    "v_sub_f32 v114, v114, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v116, v102, v114\n\t"                                    /* det = (e1.z pz + e1.y py) + e1.x px */                                      \
+    "v_mul_f32 v115, v101, v113\n\t"                                                                                                                   \
+    "v_add_f32 v116, v116, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v115, v100, v112\n\t"                                                                                                                   \
+    "v_add_f32 v116, v116, v115\n\t"                                                                                                                   \
+    "v_rcp_f32 v117, v116\n\t"                                                                                                                         \
+    "v_sub_f32 v96, %[ox], v96\n\t"                                     /* t = o - v0, in place */                                                     \
+    "v_sub_f32 v97, %[oy], v97\n\t"                                                                                                                    \
+    "v_sub_f32 v98, %[oz], v98\n\t"                                                                                                                    \
+    "v_fma_f32 v115, -v116, v117, 1.0\n\t"                              /* 1 / det: v_rcp + one Newton step (rcp_exact) */                             \
+    "v_fma_f32 v117, v115, v117, v117\n\t"                                                                                                             \
+    "v_cmp_lt_f32_e64 vcc, %[big], |v116|\n\t"                          /* |det| > 2^126: the full IEEE quotient */                                    \
+    "s_cbranch_vccz 12f\n\t"                                                                                                                           \
+    "v_div_scale_f32 v115, %[tmp], v116, v116, 1.0\n\t"                                                                                                \
+    "v_rcp_f32 v108, v115\n\t"                                                                                                                         \
+    "v_div_scale_f32 v109, vcc, 1.0, v116, 1.0\n\t"                                                                                                    \
+    "v_fma_f32 v110, -v115, v108, 1.0\n\t"                                                                                                             \
+    "v_fma_f32 v108, v110, v108, v108\n\t"                                                                                                             \
+    "v_mul_f32 v110, v109, v108\n\t"                                                                                                                   \
+    "v_fma_f32 v103, -v115, v110, v109\n\t"                                                                                                            \
+    "v_fma_f32 v110, v103, v108, v110\n\t"                                                                                                             \
+    "v_fma_f32 v115, -v115, v110, v109\n\t"                                                                                                            \
+    "v_div_fmas_f32 v115, v115, v108, v110\n\t"                                                                                                        \
+    "v_div_fixup_f32 v115, v115, v116, 1.0\n\t"                                                                                                        \
+    "v_cmp_lt_f32_e64 vcc, %[big], |v116|\n\t"                                                                                                         \
+    "v_cndmask_b32 v117, v117, v115, vcc\n\t"                                                                                                          \
+    "12:\n\t"                                                                                                                                          \
+    "v_mul_f32 v114, v98, v114\n\t"                                     /* U = (tz pz + ty py) + tx px */                                              \
+    "v_mul_f32 v115, v97, v113\n\t"                                                                                                                    \
+    "v_add_f32 v114, v114, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v115, v96, v112\n\t"                                                                                                                    \
+    "v_add_f32 v114, v114, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v111, v114, v117\n\t"                                    /* u */                                                                        \
+    "v_cmpx_nlt_f32_e64 %[tmp], |v116|, %[eps]\n\t"                     /* !(-EPS < det && det < EPS) */                                               \
+    "v_cmpx_ngt_f32 vcc, 0, v111\n\t"                                   /* !(u < 0) */                                                                 \
+    "v_cmpx_nlt_f32 vcc, 1.0, v111\n\t"                                 /* !(1 < u) */                                                                 \
+    "s_cbranch_execz 20f\n\t"                                                                                                                          \
+    "v_mul_f32 v108, v97, v102\n\t"                                     /* q = t x e1 */                                                               \
+    "v_mul_f32 v115, v98, v101\n\t"                                                                                                                    \
+    "v_sub_f32 v108, v108, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v109, v98, v100\n\t"                                                                                                                    \
+    "v_mul_f32 v115, v96, v102\n\t"                                                                                                                    \
+    "v_sub_f32 v109, v109, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v110, v96, v101\n\t"                                                                                                                    \
+    "v_mul_f32 v115, v97, v100\n\t"                                                                                                                    \
+    "v_sub_f32 v110, v110, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v103, %[dz], v110\n\t"                                   /* V = (dz qz + dy qy) + dx qx */                                              \
+    "v_mul_f32 v115, %[dy], v109\n\t"                                                                                                                  \
+    "v_add_f32 v103, v103, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v115, %[dx], v108\n\t"                                                                                                                  \
+    "v_add_f32 v103, v103, v115\n\t"                                                                                                                   \
+    "v_mul_f32 v112, v103, v117\n\t"                                    /* v */                                                                        \
+    "v_add_f32 v115, v114, v103\n\t"                                                                                                                   \
+    "v_mul_f32 v115, v117, v115\n\t"                                    /* inv (U + V): u + v > 1 is tested on it */                                   \
+    "v_cmpx_ngt_f32 vcc, 0, v112\n\t"                                   /* !(v < 0) */                                                                 \
+    "v_cmpx_nlt_f32 vcc, 1.0, v115\n\t"                                 /* !(1 < inv (U + V)) */                                                       \
+    "s_cbranch_execz 20f\n\t"                                                                                                                          \
+    "v_mul_f32 v115, v106, v110\n\t"                                    /* t = ((e2.z qz + e2.y qy) + e2.x qx) inv */                                  \
+    "v_mul_f32 v103, v105, v109\n\t"                                                                                                                   \
+    "v_add_f32 v115, v115, v103\n\t"                                                                                                                   \
+    "v_mul_f32 v103, v104, v108\n\t"                                                                                                                   \
+    "v_add_f32 v115, v115, v103\n\t"                                                                                                                   \
+    "v_mul_f32 v115, v115, v117\n\t"                                                                                                                   \
+    "v_cmpx_nge_f32 vcc, %[eps], v115\n\t"                              /* !(EPS >= t) */                                                              \
+    "v_cmpx_lt_f32 vcc, v115, %[th]\n\t"                                /* strictly closer: the first one visited wins a tie (:325) */                 \
+    "v_mov_b32 %[tri], v99\n\t"                                                                                                                        \
+    "v_mov_b32 %[hu], v111\n\t"                                                                                                                        \
+    "v_mov_b32 %[hv], v112\n\t"                                                                                                                        \
+    "v_mov_b32 %[th], v115\n\t"                                                                                                                        \
+    "20:\n\t"                                                                                                                                          \
+    "s_and_b64 exec, %[act], %[leaf]\n\t"                               /* every leaf lane again */                                                    \
+    "v_sub_f32 v112, %[sd], %[th]\n\t"                                  /* shadow ray: a known occluder ends the traversal */                          \
+    "v_cmp_nle_f32 vcc, %[eps], v112\n\t"                               /* !(stop_d - tHit >= EPS): on to the stack */                                 \
+    "s_or_b64 %[pop], %[pop], vcc\n\t"                                                                                                                 \
+    "21:\n\t"                                                                                                                                          \
+    "s_mov_b64 exec, %[pop]\n\t"                                        /* ---- pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298 */ \
+    "s_cbranch_execz 30f\n\t"                                                                                                                          \
+    "10:\n\t"                                                                                                                                          \
+    "v_cmp_ne_u32 vcc, 0, %[sp]\n\t"                                                                                                                   \
+    "v_cndmask_b32 %[cur], v107, %[cur], vcc\n\t"                       /* empty stack: the ray is finished */                                         \
+    "s_and_b64 exec, exec, vcc\n\t"                                                                                                                    \
+    "s_cbranch_execz 30f\n\t"                                                                                                                          \
+    "v_add_u32 %[sp], -1, %[sp]\n\t"                                                                                                                   \
+    "v_lshl_add_u32 v111, %[sp], 11, %[stk]\n\t"                                                                                                       \
+    "ds_read_b64 v[112:113], v111\n\t"                                  /* {t0, ref} */                                                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+    "v_mov_b32 %[cur], v113\n\t"                                                                                                                       \
+    "v_cmp_gt_f32 vcc, v112, %[th]\n\t"                                                                                                                \
+    "s_and_b64 exec, exec, vcc\n\t"                                                                                                                    \
+    "s_cbranch_execnz 10b\n\t"                                                                                                                         \
+    "30:\n\t"                                                                                                                                          \
+    "s_mov_b64 exec, %[act]\n\t"                                                                                  \
+    GLRTX_TS_END                                                                                                                       \
+    "v_cmpx_ne_u32_e64 %[act], %[cur], v107\n\t"                        /* the lanes that go on */                                                     \
+    "s_cbranch_execz 99f\n\t"
+
+#define GLRTX_REP1(X) X
+#define GLRTX_REP2(X) X X
+#define GLRTX_REP3(X) X X X
+#define GLRTX_REP4(X) X X X X
+#define GLRTX_REP5(X) X X X X X
+#define GLRTX_REP6(X) X X X X X X
+#define GLRTX_REP7(X) X X X X X X X
+#define GLRTX_REP8(X) X X X X X X X X
+#define GLRTX_REP_(N, X) GLRTX_REP##N(X)
+#define GLRTX_REP(N, X) GLRTX_REP_(N, X)

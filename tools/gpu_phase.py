@@ -14,3 +14,4 @@ names = ["top-up/generate", "traverse", "wait after traverse", "shade", "wait af
 for n, v in zip(names, o): print(f"{n:22s} {v/o.sum()*100:5.1f} %   ({v/1e6:.1f} Mcycles summed over workgroups)")
 o2 = list(out)
 print(f"refill sections (wave 0 of every workgroup): {o2[5]/max(o[1],1)*100:.1f} % of the traverse phase, {o2[6]} events, {o2[5]/max(o2[6],1):.0f} cycles each")
+print(f"stepping blocks (wave 0 of every workgroup): {o2[7]/max(o[1],1)*100:.1f} % of the traverse phase")
