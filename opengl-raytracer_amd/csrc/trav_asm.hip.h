@@ -45,6 +45,26 @@
 #define GLRTX_TS_END
 #endif
 
+// Measurement only (-DGLRTX_EXPERIMENT_EXTRA_LOADS=1|2): one or two MORE loads of the same record into scratch registers -- what a step
+// pays per additional vector-memory instruction on lines it fetches anyway (profiles/r03_traverse_bound.txt).
+#if defined(GLRTX_EXPERIMENT_EXTRA_LOADS) && GLRTX_EXPERIMENT_EXTRA_LOADS == 1
+#define GLRTX_X_LOADS "global_load_dwordx4 v[112:115], v111, %[base]\n\t"
+#elif defined(GLRTX_EXPERIMENT_EXTRA_LOADS) && GLRTX_EXPERIMENT_EXTRA_LOADS == 2
+#define GLRTX_X_LOADS "global_load_dwordx4 v[112:115], v111, %[base]\n\tglobal_load_dwordx2 v[116:117], v111, %[base] offset:16\n\t"
+#else
+#define GLRTX_X_LOADS
+#endif
+
+// Measurement only (-DGLRTX_EXPERIMENT_EXTRA_VALU=16|32): that many more vector multiplies per step on a scratch register.
+#define GLRTX_X_V8 "v_mul_f32 v112, v112, v112\n\tv_mul_f32 v113, v113, v113\n\tv_mul_f32 v114, v114, v114\n\tv_mul_f32 v115, v115, v115\n\tv_mul_f32 v112, v112, v112\n\tv_mul_f32 v113, v113, v113\n\tv_mul_f32 v114, v114, v114\n\tv_mul_f32 v115, v115, v115\n\t"
+#if defined(GLRTX_EXPERIMENT_EXTRA_VALU) && GLRTX_EXPERIMENT_EXTRA_VALU == 16
+#define GLRTX_X_VALU GLRTX_X_V8 GLRTX_X_V8
+#elif defined(GLRTX_EXPERIMENT_EXTRA_VALU) && GLRTX_EXPERIMENT_EXTRA_VALU == 32
+#define GLRTX_X_VALU GLRTX_X_V8 GLRTX_X_V8 GLRTX_X_V8 GLRTX_X_V8
+#else
+#define GLRTX_X_VALU
+#endif
+
 #define GLRTX_TRAV_STEP_ASM \
     GLRTX_TS_BEGIN \
     "v_lshl_add_u32 v111, %[cur], 6, %[bias]\n\t"                                                                                                      \
@@ -52,9 +72,10 @@
     "global_load_dwordx4 v[100:103], v111, %[base] offset:16\n\t"                                                                                      \
     "global_load_dwordx3 v[104:106], v111, %[base] offset:32\n\t"                                                                                      \
     "global_load_dwordx3 v[108:110], v111, %[base] offset:48\n\t"                                                                                      \
+    GLRTX_X_LOADS                                                                                      \
     "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t"                           /* lanes at a triangle */                                                      \
     "s_andn2_b64 exec, exec, %[leaf]\n\t"                               /* ---- fork arm: exec = lanes at a fork (may be none) */                      \
-    GLRTX_TS_WAIT0 "s_waitcnt vmcnt(0)\n\t" GLRTX_TS_WAIT1                                                                                                                           \
+    GLRTX_TS_WAIT0 "s_waitcnt vmcnt(0)\n\t" GLRTX_TS_WAIT1 GLRTX_X_VALU                                                                                                                           \
     "v_sub_f32 v100, v100, %[ox]\n\t"                                   /* left child: (hi - o), (lo - o) in place */                                  \
     "v_sub_f32 v101, v101, %[oy]\n\t"                                                                                                                  \
     "v_sub_f32 v102, v102, %[oz]\n\t"                                                                                                                  \
