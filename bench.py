@@ -31,10 +31,17 @@ shadow rays whose light test cannot change the radiance (config.rays_reference_e
 `python bench.py --gpus N` without WORLD_SIZE in the environment re-launches itself as N ranks under
 torch.distributed.run (child process; the parent never touches the GPU) and exits with the child's status.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with three extra objects:
-  roofline      -- HBM roofline of the render kernel from ALGORITHMIC bytes / measured launch time
-  roofline_valu -- vector-ALU issue roofline of the same kernel (the bound that actually applies)
+Before timing, the accumulator the counting kernel produced for the timed steps is compared, bit for bit, with an untimed replay of the
+same steps by the kernel that is timed (the compilation without ray counting): a mismatch aborts the run.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline      -- HBM roofline of the render kernel from ALGORITHMIC bytes / measured launch time (what north_star asks for)
+  roofline_vmem -- vector-memory INSTRUCTION roofline of the same kernel: the bound that applies (profiles/r03_traverse_bound.txt)
+  roofline_valu -- vector-ALU issue roofline of the same kernel
+  roofline_aux  -- the two kernels that ARE HBM-bound: accumulate_planes_kernel and resolve_kernel, GB/s against the HBM peak
   cpu_baseline  -- the CPU restatement (oracle/, "port") timed on this box's host cores (N = 1 only)
+and in config: `strong` (N > 1: a fixed 24 frames in flight in total, the framebuffer gathered after every launch) and `predicted`
+(N = 1: what rank 0's share of an N-rank step costs on this one GPU, for N = 2, 4, 8 -- the compute side of the curve, no gather).
 """
 from __future__ import annotations
 
@@ -54,7 +61,12 @@ sys.path.insert(0, str(ROOT / "opengl-raytracer_amd" / "python"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_PEAK_GINST = 1024 * 2.4 / 2  # wave64 VALU instructions/ns the chip can issue: 1024 SIMDs x 2.4 GHz / 2 cycles each
+# wave64 VALU instructions/ns the chip can issue: 1024 SIMDs x 2.4 GHz / 2 clk.  Measured (profiles/r03_ubench_valu.json): a SIMD with two or
+# more resident waves issues one v_fma / v_add / v_mul per 1.97 clk (157 TF FP32 is this rate, not a packed one); 1050 G/s sustained chip-wide.
+VALU_PEAK_GINST = 1024 * 2.4 / 2
+# wave-level vector-memory instructions/ns: measured chip-wide rate of scattered dwordx4 gathers on L1-resident data, 16 waves per CU
+# (tools/ubench/ta.hip, profiles/r03_ubench_ta.txt: 24.1 G/s with the lanes of a quad in 3-4 lines, 37.5 G/s when they share a line)
+VMEM_PEAK_GINST = 24.1
 STRIPE = 8  # rows per stripe: 1080 rows over 8 ranks = 136 / 128 rows per rank (16-row stripes: 144 / 128, 6.7 % off balance)
 STEPS_PER_LAUNCH = 24  # frames' worth of paths in flight on every GPU per launch (frames in flight; 8 / 16 / 32: 2.19 / 2.04 / 1.97 ms in round 1)
 
@@ -77,6 +89,17 @@ def effective_cpus(omp_max: int) -> int:
     except Exception:
         pass
     return max(1, n)
+
+
+def kernel_source_sha16() -> str:
+    """Identifies the device code a committed profile belongs to: hash of the kernel sources and the build flags."""
+    import hashlib
+    h = hashlib.sha256()
+    pkg = ROOT / "opengl-raytracer_amd"
+    for f in sorted((pkg / "csrc").glob("*")) + [pkg / "Makefile"]:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def launch_plan(steps: int, per_launch: int):
@@ -160,6 +183,28 @@ class GpuRenderer:
 
     def timer_end(self):
         return self.dev.timer_end()
+
+    def predict_weak(self, world, steps_per_launch, seed_of, launches=3):
+        """ms per step of rank 0's share of a `world`-rank weak-scaling step, on this one GPU (no gather): stripes s % world == 0, world x
+        steps_per_launch frames per launch.  Leaves the partition as it was."""
+        ms = []
+        try:
+            self.dev.set_partition(0, world, STRIPE)
+            for it in range(launches):
+                self.dev.reset_stats()
+                self.dev.render_frames(self.params, [seed_of(it * world * steps_per_launch + f) for f in range(world * steps_per_launch)])
+                self.dev.sync()
+                st = self.dev.stats()
+                ms.append((st.kernel_ms_total + st.accumulate_ms_total) / steps_per_launch)
+        finally:
+            self.dev.set_partition(0, 1, STRIPE)
+        return sorted(ms[1:])[len(ms[1:]) // 2]
+
+    def resolve_ms(self):
+        """Device time of one resolve pass over the owned rows (screen.frag), ms."""
+        self.dev.resolve_rgba8(2.2, True)
+        self.dev.resolve_rgba8(2.2, True)
+        return float(self.dev.stats().resolve_ms_last)
 
     def close(self):
         self.dev.set_stream(0)
@@ -249,6 +294,18 @@ def main(argv=None):
     rays_local = int(R.stats().rays)
     untraced_local = int(R.stats().rays_untraced)
     R.count_rays(False)
+    # ---- the kernel that is timed (compiled without ray counting) must produce the image the counting kernel produced: untimed replay
+    counted_img = R.accum.clone()
+    R.accum.zero_()
+    R.reset_stats()
+    run(args.warmup, args.steps, gather=False)
+    R.sync()
+    same = torch.tensor([1 if torch.equal(R.accum.view(torch.int32), counted_img.view(torch.int32)) else 0], dtype=torch.int32, device=R.accum.device)
+    if world > 1:
+        td.all_reduce(same, op=td.ReduceOp.MIN)
+    if int(same.item()) != 1:
+        raise SystemExit("bench.py: the timed kernel's image differs from the counting kernel's image for the same steps: refusing to time it")
+    del counted_img
     R.accum.zero_()
     R.reset_stats()
 
@@ -278,15 +335,45 @@ def main(argv=None):
         barrier()
         single = (time.perf_counter() - t2) / n1
 
+    # ---- strong scaling (N > 1): the SAME K frames as a one-GPU run of K steps -- S frames in flight in total per launch, i.e. S / N
+    # frames' worth of paths on every GPU -- and the framebuffer gathered to rank 0 after EVERY launch
+    strong_s = None
+    if world > 1:
+        def run_strong(f0, n_frames):
+            img = None
+            for a, k in launch_plan(n_frames, S):
+                R.render_frames(f0 + a, k, seed)
+                if gatherer is not None and not args.no_gather:
+                    img = gatherer.gather_to_root(R.accum)
+            return img
+        run_strong(0, min(S, args.steps))
+        barrier()
+        t2 = time.perf_counter()
+        img = run_strong(args.warmup * world, args.steps)
+        barrier()
+        strong_s = time.perf_counter() - t2
+        del img
+        R.sync()
+
+    # ---- what rank 0's share of an N-rank weak step costs on this GPU, N = 2, 4, 8 (N = 1 runs on a GPU only)
+    predicted = None
+    if world == 1 and hasattr(R, "predict_weak") and not args.no_single:
+        predicted = {}
+        for w in (2, 4, 8):
+            ms = R.predict_weak(w, S, seed)
+            predicted[str(w)] = {"ms_per_step": round(ms, 4)}
+    resolve_ms = R.resolve_ms() if (world == 1 and hasattr(R, "resolve_ms")) else None
+
     dev0 = R.accum.device
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev0)
+    elapsed = torch.tensor([t1 - t0] + ([strong_s] if strong_s is not None else []), dtype=torch.float64, device=dev0)
     rays = torch.tensor([rays_local, untraced_local], dtype=torch.int64, device=dev0)
     kern_ms = torch.tensor([st.kernel_ms_total / max(st.kernel_launches, 1)], dtype=torch.float64, device=dev0)
     if world > 1:
         td.all_reduce(elapsed, op=td.ReduceOp.MAX)
         td.all_reduce(rays, op=td.ReduceOp.SUM)
         td.all_reduce(kern_ms, op=td.ReduceOp.MAX)
-    elapsed_s, ref_rays, total_untraced, kernel_ms = float(elapsed.item()), int(rays[0].item()), int(rays[1].item()), float(kern_ms.item())
+    elapsed_s, ref_rays, total_untraced, kernel_ms = float(elapsed[0].item()), int(rays[0].item()), int(rays[1].item()), float(kern_ms.item())
+    strong_s = float(elapsed[1].item()) if strong_s is not None else None
     traced_rays = ref_rays - total_untraced
     n_frames = args.steps * world
 
@@ -296,35 +383,68 @@ def main(argv=None):
     # HBM: per frame 16 B read + 16 B write per owned pixel, times the frames one launch covers, + one read of the compact scene
     algo_bytes = int(len(ys) * W * 32 * frames_per_launch) + scene_b
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic, valu = None, None
-    prof = None
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    # PMC counters cannot be collected inside this run (rocprofv3 wraps the process): the per-frame instruction counts and HBM-side bytes
+    # come from the committed profile of this same command (tools/profile.sh -> profiles/r03_pmc_summary.json) and are scaled to the
+    # frames' worth of pixels a launch covers on this GPU.  The summary records a hash of the kernel sources it was taken from; if the
+    # sources have changed since, the derived figures are reported as null ("stale_profile") instead of looking measured.
+    traffic, valu, vmem, prof, stale = None, None, None, None, None
+    for name in ("r03_pmc_summary.json",):
         if (ROOT / "profiles" / name).exists():
             try:
                 prof = json.loads((ROOT / "profiles" / name).read_text())
                 prof["file"] = f"profiles/{name}"
-                break
             except Exception:
                 prof = None
+    if prof is not None and prof.get("kernel_source_sha16") != kernel_source_sha16():
+        stale = f"{prof['file']} was taken from kernel sources {prof.get('kernel_source_sha16')}, this build is {kernel_source_sha16()}"
+        prof = None
     if prof is not None and args.config == "headline":
-        # PMC counters cannot be collected inside this run (rocprofv3 wraps the process): the per-frame figures come from the
-        # committed profile of this same command and are scaled to the full frames' worth of pixels a launch covers on this GPU
         frames_equiv = frames_per_launch * len(ys) / H
+        sec = kernel_ms * 1e-3
         traffic = prof["hbm_bytes_per_frame"] * frames_equiv
         vi = prof["valu_insts_per_frame"] * frames_equiv
-        rate = vi / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        rate = vi / sec / 1e9 if sec > 0 else 0.0
         valu = {"bound": "valu-issue", "achieved": round(rate, 2), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                 "frac": round(rate / VALU_PEAK_GINST, 4), "lane_util": prof.get("lane_util"),
                 "effective_fp32_lane_frac": None if prof.get("lane_util") is None else round(rate / VALU_PEAK_GINST * prof["lane_util"], 4),
-                "valu_insts_per_launch": int(vi), "source": prof["file"],
-                "note": "SQ_INSTS_VALU per frame from the committed rocprofv3 --pmc pass of this command / kernel time measured in this run; "
-                        "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; lane_util = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64"}
+                "valu_insts_per_launch": int(vi), "salu_insts_per_launch": int(prof.get("salu_insts_per_frame", 0) * frames_equiv), "source": prof["file"],
+                "note": "SQ_INSTS_VALU per frame from the committed rocprofv3 --pmc pass of this command / kernel time measured in this run; peak = 1024 SIMDs x "
+                        "2.4 GHz / 2 clk per wave64 v_fma/v_add/v_mul, as measured (profiles/r03_ubench_valu.json: 1.97 clk per instruction per SIMD with 2+ waves; "
+                        "SQ_ACTIVE_INST_VALU counts instructions, not busy time); lane_util = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64, calibrated 1.000 / 0.500 "
+                        "on full / half exec masks"}
+        if prof.get("vmem_insts_per_frame"):
+            mi = prof["vmem_insts_per_frame"] * frames_equiv
+            mrate = mi / sec / 1e9 if sec > 0 else 0.0
+            vmem = {"bound": "vmem-issue", "achieved": round(mrate, 3), "peak": VMEM_PEAK_GINST, "unit": "G wave-level vector-memory instructions/s",
+                    "frac": round(mrate / VMEM_PEAK_GINST, 4), "vmem_insts_per_launch": int(mi), "source": prof["file"],
+                    "note": "SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR per frame from the committed --pmc pass / kernel time measured in this run; peak = measured chip-wide "
+                            "rate of scattered dwordx4 gathers on L1-resident data (tools/ubench/ta.hip).  The traverse phase issues four such loads per step and the frame "
+                            "time moves +9.7 % per load added to the step against +0.13 % per vector-ALU instruction (profiles/r03_traverse_bound.txt): this is the roof the "
+                            "kernel sits under; L1 misses (~1.3 clk per line) come on top of the instruction rate"}
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "traffic_source": None if traffic is None else f"{prof['file']} (separate --pmc FETCH_SIZE / WRITE_SIZE passes, {prof.get('traffic_note', '')})",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_measured_in_run": False,
+                "traffic_source": None if traffic is None else f"{prof['file']} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled by this run's launch; {prof.get('traffic_note', '')})",
+                "stale_profile": stale,
                 "kernel": "pt_render_wgwf<false, false>", "kernel_ms_avg": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes, "frames_per_launch": round(frames_per_launch, 3),
-                "note": "branchy scalar-FP32 traversal: VALU/latency-bound, not HBM-bound (DESIGN.md section 6); see roofline_valu"}
+                "note": "a per-lane BVH gather: bound by the CUs' vector-memory instruction rate, not by HBM (DESIGN.md section 6); see roofline_vmem"}
+    # the two kernels of the path that ARE HBM-bound, timed in this run by HIP events on the launch stream
+    aux = None
+    if world == 1 and RENDERER_FACTORY is None:
+        aux = {}
+        n_planes = frames_per_launch * params["n_samples"]
+        if st.kernel_launches and st.accumulate_ms_total > 0 and n_planes > 1:
+            ms = st.accumulate_ms_total / st.kernel_launches
+            by = len(ys) * W * 16 * (n_planes + 2)  # every plane read once, the accumulator read and written
+            aux["accumulate_planes_kernel"] = {"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms": round(ms, 4), "bytes": int(by),
+                                               "what": f"{n_planes:g} sample planes of {W}x{len(ys)} float4 added to the accumulator"}
+        if resolve_ms:
+            by = len(ys) * W * 20  # 16 B accumulator texel in, 4 B RGBA8 out (screen.frag:15-25)
+            aux["resolve_kernel"] = {"bound": "hbm", "achieved": round(by / (resolve_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(by / (resolve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms": round(resolve_ms, 4), "bytes": int(by),
+                                     "what": f"{W}x{len(ys)}: rgb / count, clamp, pow(1 / 2.2), RGBA8; at this size the launch itself (~10 us) is a third of the time "
+                                             "-- profiles/r03_aux_kernels.json has 4K"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and RENDERER_FACTORY is None:
@@ -377,9 +497,21 @@ def main(argv=None):
                        "rays_untraced_per_frame": round(total_untraced / n_frames, 1),
                        "mrays_per_s_reference_equivalent": round(ref_rays / elapsed_s / 1e6, 3),
                        "mpaths_per_s": round(W * H * params["n_samples"] * n_frames / elapsed_s / 1e6, 3),
-                       "event_ms_per_step": round(ev_ms / args.steps, 4)},
+                       "event_ms_per_step": round(ev_ms / args.steps, 4),
+                       "timed_kernel_image_check": f"bit-identical to the counting kernel's accumulator over the {args.steps} timed steps (untimed replay)",
+                       # strong scaling: the same K frames whatever N is, S frames in flight IN TOTAL per launch, framebuffer gathered after every launch
+                       "strong": None if strong_s is None else
+                           {"frames": args.steps, "frames_in_flight_total": S, "gather": "none" if args.no_gather else "to rank 0 after every launch",
+                            "ms_per_frame": round(strong_s / args.steps * 1e3, 4),
+                            "value": round(traced_rays / world / strong_s / 1e6, 3), "unit": "Mrays/s",
+                            "note": "rays of K frames / elapsed; compare with the N = 1 line's value for strong-scaling efficiency"},
+                       # N = 1: rank 0's share of an N-rank weak step on this GPU (kernel + plane accumulation, no gather, RCCL not involved)
+                       "predicted": None if predicted is None else
+                           {n: dict(v, value=round(traced_rays / args.steps * int(n) / (v["ms_per_step"] * 1e-3) / 1e6, 1)) for n, v in predicted.items()}},
             "roofline": roofline,
+            "roofline_vmem": vmem,
             "roofline_valu": valu,
+            "roofline_aux": aux,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)

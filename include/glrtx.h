@@ -55,7 +55,7 @@ extern "C" {
 #define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
 #define GLRTX_ENOMEM (-5)
 
-#define GLRTX_ABI_VERSION 6
+#define GLRTX_ABI_VERSION 7
 
 typedef struct glrtx_ctx glrtx_ctx;
 
@@ -89,7 +89,18 @@ typedef struct glrtx_stats {
     int32_t stack_entries;  /* traversal stack entries the uploaded BVH needs */
     int32_t lds_bytes;      /* dynamic LDS per workgroup of the render kernel */
     int32_t n_tri, n_fork, n_mat, n_light;
+    int32_t variant_last;   /* kernel the last launch actually ran: 2 workgroup-local wavefront, 1 persistent megakernel, 0 tile megakernel */
+    int32_t fallback_last;  /* 0, or why the last launch left the selected wavefront kernel (GLRTX_FALLBACK_* bits) */
+    float resolve_ms_last;  /* device time of the last resolve kernel (glrtx_resolve_rgba8), without the copy to the host */
+    int32_t reserved0;
+    uint64_t fallback_launches; /* launches since reset_stats that ran on the persistent megakernel although variant 2 was selected:
+                                   ~2x slower per ray and without frames in flight -- visible here instead of silent */
 } glrtx_stats;
+
+/* glrtx_stats.fallback_last: the wavefront kernel packs depth and sample index into one word of its path state */
+#define GLRTX_FALLBACK_DEPTH 1      /* u_maxDepth > 255 */
+#define GLRTX_FALLBACK_SAMPLES 2    /* u_nSamples >= 2^20 */
+#define GLRTX_FALLBACK_EXTENSIONS 4 /* analytic spheres uploaded or extension flags set (the extension kernel is a megakernel) */
 
 int glrtx_abi_version(void);
 
@@ -203,7 +214,8 @@ int glrtx_set_extensions(glrtx_ctx *ctx, int flags);
  * No reference counterpart (the reference is single-GPU); SURVEY.md 8(b) sketches glrtx_create(ctx**, device_ids, n) with a
  * gathering read_accum -- this is that, kept apart from the single-context calls.  Member i owns the 8-row stripes s with
  * s % n == i (global pixel coordinates, resident accumulator rows, its own stream); rendering exchanges nothing; read_accum
- * and resolve_rgba8 first copy the stripes device-to-device into a full frame on member 0's GPU (xGMI peer copies), i.e. they
+ * and resolve_rgba8 first copy the stripes device-to-device into a full frame on member 0's GPU (one strided xGMI peer copy per member,
+ * issued on the member's own stream so that the links work side by side), i.e. they
  * return the FULL image.  device_ids may name the same GPU more than once (partition emulation, used by the tests).
  * glrtx_group_ctx borrows a member for the per-context knobs (glrtx_set_variant, glrtx_count_rays, glrtx_get_stats);
  * do not resize, partition or destroy a member directly.  glrtx_group_get_stats sums rays / paths / rows and takes the
@@ -224,6 +236,9 @@ int glrtx_group_sync(glrtx_group *grp);
 int glrtx_group_read_accum(glrtx_group *grp, float *dst_rgba, size_t dst_pitch_bytes);
 int glrtx_group_resolve_rgba8(glrtx_group *grp, uint8_t *dst, size_t dst_pitch_bytes, float gamma, int flip_y);
 int glrtx_group_get_stats(const glrtx_group *grp, glrtx_stats *out);
+/* Device-to-device copies the last gather (read_accum / resolve_rgba8) issued: one strided copy per member, on the member's own
+ * stream, plus one for a partial last stripe -- at most 2 x members (diagnostic; the tests pin it). */
+int glrtx_group_gather_copies(const glrtx_group *grp);
 
 #ifdef __cplusplus
 }

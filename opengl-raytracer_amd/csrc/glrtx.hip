@@ -57,6 +57,7 @@ struct glrtx_ctx {
     LaunchRec ring[kLaunchRing];
     unsigned ring_head = 0, ring_tail = 0;  // launches [tail, head) are recorded and not yet folded
     hipEvent_t tm0 = nullptr, tm1 = nullptr;      // glrtx_timer_*
+    hipEvent_t rs0 = nullptr, rs1 = nullptr;      // around the resolve kernel
     std::string err;
 
     DevBuf forks, nrms, mats, lights, vine, accum_own, counter, rgba8, work;
@@ -73,6 +74,7 @@ struct glrtx_ctx {
     int n_tri = 0, n_fork = 0, n_mat = 0, n_light = 0;
     const float *frames_seeds = nullptr;  // set only inside glrtx_render_frames
     int frames_n = 1;
+    int budget_share = 1;     // contexts of one group on this device: each takes 1 / budget_share of the frames-in-flight memory budget
 
     int width = 0, height = 0;
     int rank = 0, world = 1, stripe = 16;
@@ -554,6 +556,7 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->tm0)) != hipSuccess || (e = hipEventCreate(&c->tm1)) != hipSuccess ||
+        (e = hipEventCreate(&c->rs0)) != hipSuccess || (e = hipEventCreate(&c->rs1)) != hipSuccess ||
         (e = hipMalloc(&c->counter.p, 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc(&c->work.p, 64)) != hipSuccess) {
@@ -590,6 +593,8 @@ void glrtx_destroy(glrtx_ctx *c) {
     }
     if (c->tm0) (void)hipEventDestroy(c->tm0);
     if (c->tm1) (void)hipEventDestroy(c->tm1);
+    if (c->rs0) (void)hipEventDestroy(c->rs0);
+    if (c->rs1) (void)hipEventDestroy(c->rs1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -853,6 +858,7 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
     const size_t per_frame = px * kWfStatePlanes * sizeof(float4) + (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
     size_t budget = (size_t)kFramesBudgetGiB << 30;
     if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
+    budget /= (size_t)std::max(c->budget_share, 1);
     const size_t id_cap = (((size_t)1 << 31) - 2) / std::max<size_t>(px, 1);  // ray ids are 2 id + shadow bit, below 0xFFFFFFFF
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, id_cap), budget / std::max<size_t>(per_frame, 1)));
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
@@ -915,6 +921,13 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     // Extensions (analytic spheres, dielectric, Whitted termination) exist only in the persistent megakernel's EXT instantiation.
     const bool ext = c->n_spheres > 0 || c->ext_flags != 0;
     const int variant = (ext || (c->variant == 2 && !wgwf_can_hold(p))) ? 1 : c->variant;
+    c->st.variant_last = variant;
+    c->st.fallback_last = 0;
+    if (c->variant == 2 && variant != 2) {  // not silently: the reason and a count are in the stats
+        c->st.fallback_last = (ext ? GLRTX_FALLBACK_EXTENSIONS : 0) | (p->max_depth > kWfDepthMax ? GLRTX_FALLBACK_DEPTH : 0) |
+                              (p->n_samples > kWfSampleMax ? GLRTX_FALLBACK_SAMPLES : 0);
+        c->st.fallback_launches++;
+    }
     if (variant == 2) return launch_wgwf(c, a, p, c->frames_seeds, c->frames_n);
     glrtx_ctx::LaunchRec *rec = nullptr;
     if (int rc = next_launch_rec(c, rec)) return rc;
@@ -1005,10 +1018,13 @@ int glrtx_resolve_rgba8(glrtx_ctx *c, uint8_t *dst, size_t dst_pitch_bytes, floa
         c->rgba8.bytes = bytes;
     }
     dim3 grid((c->width + 63) / 64, (c->owned_rows + 3) / 4);
+    HIP_TRY(c, hipEventRecord(c->rs0, c->stream));
     hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, c->stream, (const float4 *)c->accum, (int)(c->pitch_bytes / sizeof(float4)),
                        c->width, c->owned_rows, (uchar4 *)c->rgba8.p, c->width, 1.0f / gamma, flip_y ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->rs1, c->stream));
     if (int rc = glrtx_sync(c)) return rc;
+    HIP_TRY(c, hipEventElapsedTime(&c->st.resolve_ms_last, c->rs0, c->rs1));
     HIP_TRY(c, hipMemcpy2D(dst, dst_pitch_bytes, c->rgba8.p, (size_t)c->width * 4, (size_t)c->width * 4, (size_t)c->owned_rows,
                            hipMemcpyDeviceToHost));
     return GLRTX_OK;
@@ -1033,7 +1049,7 @@ int glrtx_reset_stats(glrtx_ctx *c) {
     if (int rc = glrtx_sync(c)) return rc;
     HIP_TRY(c, hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long)));
     c->counters_host[0] = c->counters_host[1] = 0; c->counters_stale = false;
-    c->st.rays = 0; c->st.rays_untraced = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f;
+    c->st.rays = 0; c->st.rays_untraced = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f; c->st.fallback_launches = 0;
     return GLRTX_OK;
 }
 
@@ -1105,6 +1121,8 @@ struct glrtx_group {
     std::vector<glrtx_ctx *> ctx;
     std::vector<hipEvent_t> done;  // per context: "its render stream has reached this point"
     DevBuf full, full8;            // on ctx[0]'s device: gathered accumulator (pitch = ctx[0]'s), resolved RGBA8
+    std::vector<char> peer_ok;     // per context: its device can write the root's memory directly (same device, or peer access enabled)
+    int gather_copies = 0;         // copies the last gather issued (tests)
     int width = 0, height = 0;
     std::string err;
 };
@@ -1131,7 +1149,12 @@ int gsub(glrtx_group *g, int i, int rc) {
         if (e_ != hipSuccess) return gfail(g, GLRTX_EDEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-// All stripes -> g->full on ctx[0]'s device, ordered behind every context's outstanding work; leaves the copies on ctx[0]'s stream.
+// All stripes -> g->full on ctx[0]'s device, ordered behind every context's outstanding work.  ONE strided copy per member
+// (hipMemcpy2DAsync: a row of the copy is a whole stripe -- stripe x pitch bytes, contiguous on both sides -- the source steps by a
+// stripe, the destination by world stripes), plus one for a partial last stripe, issued on the MEMBER's own stream right behind its
+// render work: the members' copies run side by side over their own xGMI links, and the root stream only waits for their events.
+// (Round 2 issued every stripe as its own hipMemcpyPeerAsync on the root's stream: 135 serialised copies at 1080p / 8 members.)
+// Members without peer access to the root's memory fall back to hipMemcpyPeerAsync per stripe on the root's stream.
 int group_gather(glrtx_group *g) {
     glrtx_ctx *r = g->ctx[0];
     if (g->width < 1) return gfail(g, GLRTX_EINVAL, "glrtx_group: call glrtx_group_resize first");
@@ -1143,18 +1166,40 @@ int group_gather(glrtx_group *g) {
         g->full.bytes = pitch * (size_t)g->height;
     }
     const int n = (int)g->ctx.size();
+    g->gather_copies = 0;
     for (int i = 0; i < n; i++) {
         glrtx_ctx *c = g->ctx[i];
         if (c->pitch_bytes != pitch) return gfail(g, GLRTX_EINVAL, "glrtx_group: member accumulators have different pitches");
-        GHIP_TRY(g, hipSetDevice(c->device));
-        GHIP_TRY(g, hipEventRecord(g->done[i], c->stream));
-        GHIP_TRY(g, hipSetDevice(r->device));
-        GHIP_TRY(g, hipStreamWaitEvent(r->stream, g->done[i], 0));
-        for (int row = 0; row < c->owned_rows; row += c->stripe) {  // one contiguous block per stripe
-            const int rows = std::min(c->stripe, c->owned_rows - row);
-            const int y = ((row / c->stripe) * c->world + c->rank) * c->stripe;
-            GHIP_TRY(g, hipMemcpyPeerAsync((char *)g->full.p + (size_t)y * pitch, r->device, (const char *)c->accum + (size_t)row * pitch, c->device,
-                                           (size_t)rows * pitch, r->stream));
+        if (c->owned_rows == 0) continue;
+        const size_t stripe_b = (size_t)c->stripe * pitch;
+        const int full_stripes = c->owned_rows / c->stripe, tail_rows = c->owned_rows % c->stripe;
+        char *dst0 = (char *)g->full.p + (size_t)c->rank * stripe_b;  // stripe s of this member lies at global stripe s * world + rank
+        if (g->peer_ok[i]) {
+            GHIP_TRY(g, hipSetDevice(c->device));
+            if (full_stripes > 0) {
+                GHIP_TRY(g, hipMemcpy2DAsync(dst0, (size_t)c->world * stripe_b, c->accum, stripe_b, stripe_b, (size_t)full_stripes, hipMemcpyDeviceToDevice, c->stream));
+                g->gather_copies++;
+            }
+            if (tail_rows > 0) {
+                GHIP_TRY(g, hipMemcpyAsync(dst0 + (size_t)full_stripes * c->world * stripe_b, (const char *)c->accum + (size_t)full_stripes * stripe_b,
+                                           (size_t)tail_rows * pitch, hipMemcpyDeviceToDevice, c->stream));
+                g->gather_copies++;
+            }
+            GHIP_TRY(g, hipEventRecord(g->done[i], c->stream));
+            GHIP_TRY(g, hipSetDevice(r->device));
+            GHIP_TRY(g, hipStreamWaitEvent(r->stream, g->done[i], 0));
+        } else {
+            GHIP_TRY(g, hipSetDevice(c->device));
+            GHIP_TRY(g, hipEventRecord(g->done[i], c->stream));
+            GHIP_TRY(g, hipSetDevice(r->device));
+            GHIP_TRY(g, hipStreamWaitEvent(r->stream, g->done[i], 0));
+            for (int row = 0; row < c->owned_rows; row += c->stripe) {  // one contiguous block per stripe
+                const int rows = std::min(c->stripe, c->owned_rows - row);
+                const int y = ((row / c->stripe) * c->world + c->rank) * c->stripe;
+                GHIP_TRY(g, hipMemcpyPeerAsync((char *)g->full.p + (size_t)y * pitch, r->device, (const char *)c->accum + (size_t)row * pitch, c->device,
+                                               (size_t)rows * pitch, r->stream));
+                g->gather_copies++;
+            }
         }
     }
     return GLRTX_OK;
@@ -1182,14 +1227,25 @@ int glrtx_group_create(glrtx_group **out, const int *device_ids, int n_devices) 
         }
         g->done.push_back(ev);
     }
-    // direct peer access from the gathering device where the platform offers it (the copies work, staged, without it)
+    // every member's device gets direct access to the root's memory where the platform offers it (its gather copy then runs on its own
+    // stream over its own link); without it that member's stripes are copied by the root with hipMemcpyPeerAsync
+    g->peer_ok.assign((size_t)n_devices, 1);
     for (int i = 1; i < n_devices; i++) {
+        if (g->ctx[i]->device == g->ctx[0]->device) continue;
         int can = 0;
-        if (g->ctx[i]->device != g->ctx[0]->device && hipDeviceCanAccessPeer(&can, g->ctx[0]->device, g->ctx[i]->device) == hipSuccess && can) {
-            (void)hipSetDevice(g->ctx[0]->device);
-            (void)hipDeviceEnablePeerAccess(g->ctx[i]->device, 0);
+        g->peer_ok[i] = 0;
+        if (hipDeviceCanAccessPeer(&can, g->ctx[i]->device, g->ctx[0]->device) == hipSuccess && can) {
+            (void)hipSetDevice(g->ctx[i]->device);
+            const hipError_t e = hipDeviceEnablePeerAccess(g->ctx[0]->device, 0);
             (void)hipGetLastError();  // "already enabled" is fine
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) g->peer_ok[i] = 1;
         }
+    }
+    // members that share a GPU also share its memory: the frames-in-flight budget is split between them
+    for (int i = 0; i < n_devices; i++) {
+        int same = 0;
+        for (int j = 0; j < n_devices; j++) same += g->ctx[j]->device == g->ctx[i]->device;
+        g->ctx[i]->budget_share = same;
     }
     *out = g;
     return GLRTX_OK;
@@ -1286,6 +1342,8 @@ int glrtx_group_resolve_rgba8(glrtx_group *g, uint8_t *dst, size_t dst_pitch_byt
     return glrtx_group_sync(g);
 }
 
+int glrtx_group_gather_copies(const glrtx_group *g) { return g ? g->gather_copies : 0; }
+
 int glrtx_group_get_stats(const glrtx_group *g, glrtx_stats *out) {
     if (!g || !out || g->ctx.empty()) return GLRTX_EINVAL;
     glrtx_stats s{};
@@ -1295,6 +1353,7 @@ int glrtx_group_get_stats(const glrtx_group *g, glrtx_stats *out) {
         if (i == 0) s = t;
         else {
             s.rays += t.rays; s.rays_untraced += t.rays_untraced; s.paths += t.paths; s.owned_rows += t.owned_rows;
+            s.fallback_launches += t.fallback_launches; s.fallback_last |= t.fallback_last;
             s.kernel_ms_total = std::max(s.kernel_ms_total, t.kernel_ms_total);  // the GPUs run side by side
             s.accumulate_ms_total = std::max(s.accumulate_ms_total, t.accumulate_ms_total);
             s.kernel_ms_last = std::max(s.kernel_ms_last, t.kernel_ms_last);

@@ -104,6 +104,18 @@ void Window::render() {
     frameParams(p);
     glrt_frame_seed(frame_++, p.seed);
     GLRTX_CHECK(glrtx_group_render(grp_, &p));  // window.cpp:290, the draw that runs the path tracer
+    noteFallback();
+}
+
+// Once per run: say so when launches leave the wavefront kernel for the (slower) persistent megakernel (glrtx_stats.fallback_last).
+void Window::noteFallback() {
+    if (fallbackNoted_) return;
+    glrtx_stats st;
+    if (glrtx_group_get_stats(grp_, &st) != GLRTX_OK || st.fallback_launches == 0) return;
+    fallbackNoted_ = true;
+    GLRT_Info("Render kernel: persistent megakernel instead of the wavefront kernel (%s%s%s): about half the rays per second, no frames in flight",
+              (st.fallback_last & GLRTX_FALLBACK_DEPTH) ? "u_maxDepth > 255 " : "", (st.fallback_last & GLRTX_FALLBACK_SAMPLES) ? "u_nSamples >= 2^20 " : "",
+              (st.fallback_last & GLRTX_FALLBACK_EXTENSIONS) ? "extension scene" : "");
 }
 
 void Window::renderFrames(int n) {
@@ -112,6 +124,7 @@ void Window::renderFrames(int n) {
     std::vector<float> seeds(2 * (size_t)n);
     for (int f = 0; f < n; f++) glrt_frame_seed(frame_++, &seeds[2 * (size_t)f]);
     GLRTX_CHECK(glrtx_group_render_frames(grp_, &p, seeds.data(), n));
+    noteFallback();
 }
 
 void Window::resizeDefault(int w, int h) {

@@ -58,6 +58,7 @@ private:
     void resizeDefault(int width, int height);
     void resetBuffer();
     void saveCurrentFrame(const std::string &filename, bool overwrite = true) const;
+    void noteFallback();
 
     glrtx_group *grp_ = nullptr;
     std::vector<int> devices_ = {-1};  // -1: the current HIP device
@@ -65,6 +66,7 @@ private:
     int frameLimit_ = 16, maxDepth_ = 16, samplesPerFrame_ = 1, framesInFlight_ = 16;
     unsigned frame_ = 0;
     bool saveEveryFrame_ = false;
+    bool fallbackNoted_ = false;
     std::string output_ = "output.png";
     double lastMs_ = 0.0;
     std::shared_ptr<Scene> scene = nullptr;

@@ -15,6 +15,7 @@ from .host import LIB_DIR, PKG_ROOT
 GLRTX_OK = 0
 GLRTX_EINVAL, GLRTX_EDEVICE, GLRTX_ESCENE, GLRTX_EDEPTH, GLRTX_ENOMEM = -1, -2, -3, -4, -5
 EXT_DIELECTRIC, EXT_WHITTED = 1, 2
+FALLBACK_DEPTH, FALLBACK_SAMPLES, FALLBACK_EXTENSIONS = 1, 2, 4
 
 
 class Params(C.Structure):
@@ -27,7 +28,8 @@ class Stats(C.Structure):
                 ("kernel_ms_total", C.c_double), ("accumulate_ms_total", C.c_double), ("kernel_ms_last", C.c_float),
                 ("frames_last", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("owned_rows", C.c_int32),
                 ("stack_entries", C.c_int32), ("lds_bytes", C.c_int32), ("n_tri", C.c_int32), ("n_fork", C.c_int32),
-                ("n_mat", C.c_int32), ("n_light", C.c_int32)]
+                ("n_mat", C.c_int32), ("n_light", C.c_int32), ("variant_last", C.c_int32), ("fallback_last", C.c_int32),
+                ("resolve_ms_last", C.c_float), ("reserved0", C.c_int32), ("fallback_launches", C.c_uint64)]
 
 
 EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_error", "glrtx_upload_scene", "glrtx_build_lbvh",
@@ -37,7 +39,7 @@ EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_err
            "glrtx_timer_begin", "glrtx_timer_end", "glrtx_upload_spheres", "glrtx_set_extensions",
            "glrtx_group_create", "glrtx_group_destroy", "glrtx_group_last_error", "glrtx_group_size", "glrtx_group_ctx",
            "glrtx_group_upload_scene", "glrtx_group_resize", "glrtx_group_clear", "glrtx_group_render", "glrtx_group_render_frames",
-           "glrtx_group_sync", "glrtx_group_read_accum", "glrtx_group_resolve_rgba8", "glrtx_group_get_stats"]
+           "glrtx_group_sync", "glrtx_group_read_accum", "glrtx_group_resolve_rgba8", "glrtx_group_get_stats", "glrtx_group_gather_copies"]
 
 _lib = None
 
@@ -101,6 +103,7 @@ def lib():
         L.glrtx_group_read_accum.argtypes = [vp, vp, C.c_size_t]
         L.glrtx_group_resolve_rgba8.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_int]
         L.glrtx_group_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.glrtx_group_gather_copies.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -316,6 +319,9 @@ class Group:
         out = np.zeros((self.hgt, self.w, 4), np.float32)
         self._ck(self.L.glrtx_group_read_accum(self.h, out.ctypes.data, self.w * 16))
         return out
+
+    def gather_copies(self) -> int:
+        return int(self.L.glrtx_group_gather_copies(self.h))
 
     def resolve_rgba8(self, gamma=2.2, flip_y=True) -> np.ndarray:
         out = np.zeros((self.hgt, self.w, 4), np.uint8)

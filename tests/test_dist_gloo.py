@@ -76,17 +76,24 @@ def test_bench_self_spawns_its_ranks_and_gathers_to_root(tmp_path):
     assert out["config"]["frames_per_step"] == 2 and out["config"]["launches"] == [2, 2, 1]
     assert abs(out["config"]["ms_per_frame"] * 2 - out["ms_per_step"]) < 1e-3 * out["ms_per_step"] + 1e-4
     assert out["value"] > 0 and out["cpu_baseline"] is None
-    # the counting pass, the warm-up and the timed region cover these frames, in this order, on every rank
+    # weak and strong figures are both in the line; the one-GPU predictions only exist at N = 1 on a GPU
+    strong = out["config"]["strong"]
+    assert strong["frames"] == steps and strong["frames_in_flight_total"] == spl and strong["value"] > 0 and "every launch" in strong["gather"]
+    assert out["config"]["predicted"] is None and "bit-identical" in out["config"]["timed_kernel_image_check"]
+    assert out["roofline"]["traffic_measured_in_run"] is False and out["roofline_aux"] is None
+    # the counting pass, its replay by the timed kernel (image check), the warm-up, the timed region, and the strong-scaling region
+    # (one warm launch, then `steps` FRAMES in launches of `spl` frames in total) cover these frames, in this order, on every rank
     timed = list(range(warm * 2, (warm + steps) * 2))
-    want = timed + list(range(0, warm * 2)) + timed
+    strong_frames = list(range(0, min(spl, steps))) + list(range(warm * 2, warm * 2 + steps))
+    want = timed + timed + list(range(0, warm * 2)) + timed + strong_frames
     for k in range(2):
         assert np.load(tmp_path / f"frames_rank{k}.npy").tolist() == want
-    # image: warm-up frames + timed frames accumulated from zero (the counting pass is cleared), gathered to rank 0
+    # image: everything after the last clear -- warm-up, timed and strong-region frames -- accumulated from zero, gathered to rank 0
     from glrt_amd import host
     from tests.bench_rehearsal import small_config
     sc, pr = small_config()
     ref = np.zeros((pr["height"], pr["width"], 4), np.float32)
-    for f in list(range(0, warm * 2)) + timed:
+    for f in list(range(0, warm * 2)) + timed + strong_frames:
         pt_oracle.render(sc, dict(pr, seed=host.frame_seed(f)), accum=ref, threads=2)
     got = np.load(tmp_path / "gathered.npy")
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -494,11 +494,53 @@ def test_group_renders_the_single_context_image(gpu_device, n_members):
         st = g.stats()
         assert st.owned_rows == 104 and st.rays == ref_rays
         assert_bit_equal(g.read_accum(), ref, f"group of {n_members}")
+        assert g.gather_copies() <= min(2 * n_members, 13)  # one strided copy per member (+ one for a partial last stripe), never one per stripe
         assert np.array_equal(g.resolve_rgba8(2.2, True), ref8)
         g.clear()
         g.render(dict(params, seed=seeds[0]))
         one, _ = gpu_render(d, scene, params)
         assert_bit_equal(g.read_accum(), one, "after clear")
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("w,h,n_members", [(50, 38, 3), (33, 7, 2), (64, 8, 8), (40, 9, 8)])
+def test_group_with_a_partial_last_stripe(gpu_device, w, h, n_members):
+    """Heights that are not a multiple of the 8-row stripe: the last stripe is short, some members own nothing at all."""
+    scene, params = scenes.config_c1(w, h, max_depth=3, n_samples=2, subdiv=1)
+    seeds = [host.frame_seed(f) for f in range(3)]
+    ref, ref_st = gpu_render(gpu_device, scene, params, frames=seeds)
+    ref8 = gpu_device.resolve_rgba8(2.2, True)
+    g = device.Group([0] * n_members)
+    try:
+        g.upload_scene(scene); g.resize(w, h)
+        g.member_call(g.L.glrtx_count_rays, 1)
+        g.render_frames(params, seeds)
+        assert_bit_equal(g.read_accum(), ref, f"{w}x{h} over {n_members} members")
+        assert g.stats().rays == ref_st.rays and g.stats().owned_rows == h
+        assert np.array_equal(g.resolve_rgba8(2.2, True), ref8)
+        assert g.gather_copies() <= 2 * n_members
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("cfg,kw,frames", [("headline", {}, 2), ("c4", dict(n_samples=16), 1)], ids=["1080p", "4k_16spp"])
+def test_group_of_eight_at_full_size(gpu_device, cfg, kw, frames):
+    """BASELINE's multi-GPU shapes through the C-ABI group (eight members, here all on one GPU): 1920x1080 / 8 bounces and config 4,
+    3840x2160 / 8 bounces / 16 spp -- the gathered frame equals the single-context frame bit for bit, with 8 gather copies (1080 rows =
+    135 stripes, 2160 = 270: round 2 issued one copy per stripe)."""
+    scene, params = scenes.CONFIGS[cfg](**kw)
+    seeds = [host.frame_seed(f) for f in range(frames)]
+    ref, _ = gpu_render(gpu_device, scene, params, frames=seeds, count_rays=False)
+    g = device.Group([0] * 8)
+    try:
+        g.upload_scene(scene); g.resize(params["width"], params["height"])
+        if frames > 1:
+            g.render_frames(params, seeds)
+        else:
+            g.render(dict(params, seed=seeds[0]))
+        assert_bit_equal(g.read_accum(), ref, f"{cfg} over 8 members")
+        assert g.gather_copies() == 8
     finally:
         g.close()
 
@@ -513,6 +555,57 @@ def test_group_error_paths():
         assert e.value.code == device.GLRTX_EINVAL and "context 0" in str(e.value) and "no scene" in str(e.value)
     finally:
         g.close()
+
+
+def test_leaving_the_wavefront_kernel_is_visible_in_the_stats(gpu_device):
+    """u_maxDepth > 255 (and extension scenes) run on the persistent megakernel: stats.variant_last / fallback_last / fallback_launches say so."""
+    d = gpu_device
+    scene, params = scenes.config_c1(48, 32, max_depth=4, subdiv=1)
+    _, st = gpu_render(d, scene, params)
+    assert st.variant_last == 2 and st.fallback_last == 0 and st.fallback_launches == 0
+    _, st = gpu_render(d, scene, dict(params, max_depth=256), frames=[host.frame_seed(0), host.frame_seed(1)])
+    assert st.variant_last == 1 and st.fallback_last == device.FALLBACK_DEPTH and st.fallback_launches == 2
+    d.set_extensions(device.EXT_WHITTED)
+    try:
+        _, st = gpu_render(d, scene, params)
+        assert st.variant_last == 1 and st.fallback_last == device.FALLBACK_EXTENSIONS and st.fallback_launches == 1
+    finally:
+        d.set_extensions(0)
+    d.set_variant(1)
+    try:
+        _, st = gpu_render(d, scene, params)
+        assert st.variant_last == 1 and st.fallback_last == 0 and st.fallback_launches == 0  # asked for, not a fallback
+    finally:
+        d.set_variant(2)
+
+
+def test_render_calls_return_before_the_device_is_done(gpu_device):
+    """glrtx_render is asynchronous (include/glrtx.h): consecutive calls are enqueued without waiting for the previous launch -- the host
+    returns from several 1080p launches in a fraction of the time the device needs for them -- and the per-launch kernel times are
+    folded into the stats afterwards (ring of event triples, also beyond its 16 entries)."""
+    import time
+    d = gpu_device
+    scene, params = scenes.config_headline()
+    d.upload_scene(scene); d.set_partition(0, 1, 16); d.resize(params["width"], params["height"]); d.count_rays(False)
+    d.render(dict(params, seed=host.frame_seed(0))); d.sync(); d.reset_stats()
+    n = 6
+    t0 = time.perf_counter()
+    for f in range(n):
+        d.render(dict(params, seed=host.frame_seed(1 + f)))
+    t_enqueue = time.perf_counter() - t0
+    d.sync()
+    t_all = time.perf_counter() - t0
+    st = d.stats()
+    assert st.kernel_launches == n and st.launches == n
+    device_s = st.kernel_ms_total * 1e-3
+    assert device_s > 0.004                      # six 1080p frames: > 4 ms of device time
+    assert t_enqueue < 0.5 * device_s, (t_enqueue, device_s, t_all)   # the host did not wait for the launches it issued
+    d.reset_stats()
+    for f in range(40):                          # more launches in flight than the ring holds: the oldest are folded on the way
+        d.render(dict(params, seed=host.frame_seed(f)))
+    d.sync()
+    st = d.stats()
+    assert st.kernel_launches == 40 and st.kernel_ms_total > 0.02
 
 
 def _closed_box(width, height, max_depth, n_samples):

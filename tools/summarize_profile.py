@@ -49,7 +49,13 @@ if main:
     FRAMES = int(sys.argv[3]) if len(sys.argv) > 3 else 16  # frames per launch of the profiled command (tools/profile.sh)
     m = out[main[0]]
     c = m["counters_avg_per_launch"]
-    summ = {"kernel": main[0], "source": f"profiles/{tag}_pmc.json", "frames_per_launch": FRAMES,
+    import hashlib
+    hh = hashlib.sha256()
+    pkg = root / "opengl-raytracer_amd"
+    for f in sorted((pkg / "csrc").glob("*")) + [pkg / "Makefile"]:  # == bench.py: kernel_source_sha16()
+        hh.update(f.name.encode())
+        hh.update(f.read_bytes())
+    summ = {"kernel": main[0], "source": f"profiles/{tag}_pmc.json", "frames_per_launch": FRAMES, "kernel_source_sha16": hh.hexdigest()[:16],
             "vgpr": m["vgpr"], "sgpr": m["sgpr"], "scratch": m["scratch"]}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
@@ -60,10 +66,16 @@ if main:
                                  "Infinity-Cache hits are included in both counters")
     if "SQ_INSTS_VALU" in c:
         summ["valu_insts_per_frame"] = c["SQ_INSTS_VALU"] / FRAMES
-    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles, SQ_THREAD_CYCLES_VALU thread-cycles: lanes = threads / (4 * quad-cycles)... both as rocprofv3
-        # reports them for this kernel give thread-cycles per active VALU cycle; divided by 64 lanes
-        summ["lane_util"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"] / 64.0
+    for key, name in (("SQ_INSTS_SALU", "salu_insts_per_frame"), ("SQ_INSTS_BRANCH", "branch_insts_per_frame"), ("SQ_INSTS_LDS", "lds_insts_per_frame"),
+                      ("SQ_INSTS_VMEM_RD", "vmem_rd_insts_per_frame"), ("SQ_INSTS_VMEM_WR", "vmem_wr_insts_per_frame")):
+        if key in c:
+            summ[name] = c[key] / FRAMES
+    if "SQ_INSTS_VMEM_RD" in c:
+        summ["vmem_insts_per_frame"] = (c["SQ_INSTS_VMEM_RD"] + c.get("SQ_INSTS_VMEM_WR", 0.0)) / FRAMES
+    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_INSTS_VALU" in c:
+        # enabled lanes per vector instruction / 64.  Calibrated with tools/ubench/valu.hip (profiles/r03_ubench_valu.json): 1.000 with all
+        # lanes enabled, 0.500 with exec = 0xFFFFFFFF; SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU there and is not used
+        summ["lane_util"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"] / 64.0
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
         summ["wave_cycles_waiting_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
