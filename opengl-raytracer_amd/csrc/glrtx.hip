@@ -188,6 +188,7 @@ struct Packed {
     int vine_uniform = 0;
     float4 root_lo = make_float4(0.f, 0.f, 0.f, 0.f), root_hi = make_float4(0.f, 0.f, 0.f, 0.f);
     int root_ref = REF_ABSENT;
+    int root_boxed = 0;   // the wire root is a fork: its own box (root_lo / root_hi) is tested before anything else
     int stack_need = 0;
 };
 
@@ -204,8 +205,9 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         return true;
     };
 
-    // ---- triangles: {v0, material} {v1-v0} {v2-v0}; normals {n0} {n1} {n2}
-    std::vector<float4> &tris = P.tris, &nrms = P.nrms;
+    // ---- triangles: {v0, material} {v1-v0} {v2-v0}; normals {n0} {n1} {n2} -- staged per wire triangle here; the device gets one
+    // record per LEAF of the tree (P.tris / P.nrms, filled behind the tree walk below)
+    std::vector<float4> tris, nrms;
     tris.assign(4 * n_tri, make_float4(0.f, 0.f, 0.f, 0.f));  // 64-byte records, same shape as a fork record
     nrms.assign(3 * n_tri, make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t t = 0; t < n_tri; t++) {
@@ -249,11 +251,23 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         }
     }
 
-    // ---- BVH: walk the wire-format tree from node 0, fold leaves into refs, renumber forks in DFS order
+    // ---- BVH: walk the wire-format tree from node 0, fold leaves into refs, renumber forks in DFS order.
+    // Leaf records.  Every leaf the walk reaches gets its own triangle record, numbered in the order the traversal meets them:
+    // leaf record k has triangle id k + 1 and lies at record index ~(k + 1) (id 0 / index -1 is the all-zero never-hit record that
+    // stands for an absent child).  The id -- not the wire triangle index -- is what the kernels carry in a hit.
+    // Leaf pairs.  A fork whose two children are both leaves gets NO fork record: nothing of it is ever tested but its own box, and
+    // that sits in its parent's record.  Its two triangle records are chained instead -- the first-visited child's record names the
+    // other one's index (its predecessor in memory) in the spare word of its second float4, REF_FIN otherwise -- and the parent refers
+    // to the first of them: the traversal step goes from one triangle to the next without a fork fetch, a push and a pop in
+    // between (raytrace.frag:299-331: children.y is popped and tested first, then children.x; neither is box-tested).  With the
+    // reference's builder 40 % of the forks are such pairs and 94 % of the headline config's triangle tests come through one.
     std::vector<float4> &forks = P.forks;
     forks.clear();
+    std::vector<int> leaf_tri;   // leaf record k -> wire triangle
+    std::vector<int> leaf_next;  // leaf record k -> ref of the record chained behind it, or REF_FIN
     int root_ref = REF_ABSENT;
     int stack_need = 0;
+    const bool chain_pairs = std::getenv("GLRTX_NO_LEAF_CHAINS") == nullptr;  // (A/B switch)
     if (n_nodes > 0 && n_tri > 0) {
         std::vector<int> ref_of(n_nodes, 0);          // ref assigned to each wire node
         std::vector<unsigned char> seen(n_nodes, 0);
@@ -268,36 +282,59 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
             out = (int)f;
             return true;
         };
+        auto add_leaf = [&](int n, int &rc) {  // a leaf record for wire node n; returns its ref
+            rc = GLRTX_OK;
+            if (seen[n]) { rc = pfail(c, err_out, GLRTX_ESCENE, "BVH node %d is referenced more than once (not a tree)", n); return 0; }
+            seen[n] = 1;
+            const float tf = bvh[9 * (size_t)n + 8];
+            if ((size_t)tf >= n_tri) { rc = pfail(c, err_out, GLRTX_ESCENE, "BVH leaf %d: triangle %g out of range", n, tf); return 0; }
+            leaf_tri.push_back((int)tf);
+            leaf_next.push_back(REF_FIN);
+            ref_of[n] = ~(int)leaf_tri.size();  // id = record count so far (ids start at 1)
+            need[n] = 0;
+            return ref_of[n];
+        };
         st.push_back({0, 0});
         while (!st.empty()) {
             Frame &f = st.back();
             const int n = f.node;
             if (f.stage == 0) {
+                if (!is_fork(n)) {
+                    int rc;
+                    add_leaf(n, rc);
+                    if (rc) return rc;
+                    st.pop_back();
+                    continue;
+                }
                 if (seen[n]) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d is referenced more than once (not a tree)", n);
                 seen[n] = 1;
-                if (!is_fork(n)) {
-                    const float tf = bvh[9 * (size_t)n + 8];
-                    if ((size_t)tf >= n_tri) return pfail(c, err_out, GLRTX_ESCENE, "BVH leaf %d: triangle %g out of range", n, tf);
-                    ref_of[n] = ~(int)tf;
+                int l, r;
+                if (!child(n, 0, l) || !child(n, 1, r)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
+                if (chain_pairs && l >= 0 && r >= 0 && l != r && !is_fork(l) && !is_fork(r)) {  // a leaf pair: children.y first, then children.x
+                    int rc;
+                    const int first = add_leaf(r, rc);
+                    if (rc) return rc;
+                    const int second = add_leaf(l, rc);
+                    if (rc) return rc;
+                    leaf_next[(size_t)~first - 1] = second;  // == first - 1: the record in front of it in memory
+                    ref_of[n] = first;
                     need[n] = 0;
                     st.pop_back();
                     continue;
                 }
                 ref_of[n] = (int)(forks.size() / 4);
-                // both children start out absent: the never-hit record ~n_tri behind an infinite box (see put_box)
-                for (int k = 0; k < 4; k++) { const float e = (k & 1) ? kInf : -kInf; forks.push_back(make_float4(e, e, e, as_float(~(int)n_tri))); }
+                // both children start out absent: the never-hit record (index -1) behind an infinite box (see put_box)
+                for (int k = 0; k < 4; k++) { const float e = (k & 1) ? kInf : -kInf; forks.push_back(make_float4(e, e, e, as_float(-1))); }
                 // forks are numbered in the order the traversal meets them (children.y first, raytrace.frag:299-307):
                 // the first-visited child's record directly follows its parent's
                 f.stage = 1;
-                int r;
-                if (!child(n, 1, r)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
                 if (r >= 0) { st.push_back({r, 0}); }
                 continue;
             }
             if (f.stage == 1) {
                 f.stage = 2;
                 int l;
-                if (!child(n, 0, l)) return pfail(c, err_out, GLRTX_ESCENE, "BVH node %d: child index out of range", n);
+                child(n, 0, l);
                 if (l >= 0) { st.push_back({l, 0}); }
                 continue;
             }
@@ -307,7 +344,8 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
             const int fi = ref_of[n];
             // child box into the parent's record.  A LEAF child is never box-tested (raytrace.frag:310-331): it gets the box
             // (-inf, +inf), for which the slab test passes by itself with entry distance -inf -- the traversal step then needs no
-            // test of the ref's sign (an absent child, the never-hit record, is treated the same way)
+            // test of the ref's sign (an absent child, the never-hit record, is treated the same way).  A leaf PAIR is a fork in the
+            // wire format: its own box goes here like any fork's.
             auto put_box = [&](int slot, int child) {
                 if (!is_fork(child)) return;
                 const float *b = bvh + 9 * (size_t)child;
@@ -332,17 +370,28 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         }
         root_ref = ref_of[0];
         stack_need = need[0];
+        P.root_boxed = is_fork(0) ? 1 : 0;  // the wire root's own box is tested first (:296-298) -- also when it is packed as a leaf pair
+
+        // the per-leaf triangle records: id 0 the never-hit record, id k + 1 leaf record k
+        P.tris.assign(4 * (leaf_tri.size() + 1), make_float4(0.f, 0.f, 0.f, 0.f));
+        P.nrms.assign(3 * (leaf_tri.size() + 1), make_float4(0.f, 0.f, 0.f, 0.f));
+        for (size_t k = 0; k < leaf_tri.size(); k++) {
+            for (int j = 0; j < 4; j++) P.tris[4 * (k + 1) + j] = tris[4 * (size_t)leaf_tri[k] + j];
+            for (int j = 0; j < 3; j++) P.nrms[3 * (k + 1) + j] = nrms[3 * (size_t)leaf_tri[k] + j];
+            P.tris[4 * (k + 1) + 1].w = as_float(leaf_next[k]);
+        }
+        P.tris[1].w = as_float(REF_FIN);
 
         // ---- vine: every fork has a leaf as children.y and the chain continues through children.x (what
         // glrt_bvh_build_chain emits for "brute force, no BVH").  Stored additionally as the list the traversal visits:
         // record i = {box of fork i, its children.y triangle}; the last record = the last fork's children.x leaf.
-        if (root_ref >= 0 && n_tri >= 2) {
+        if (is_fork(0) && leaf_tri.size() >= 2) {
             std::vector<float4> v;
-            v.reserve(4 * n_tri);
+            v.reserve(4 * leaf_tri.size());
             bool is_vine = true, uniform = true;
             int n = 0;
-            auto rec = [&](const float *lo, const float *hi, int t) {
-                const float4 *T = &tris[4 * (size_t)t];  // {v0, mat} {e1} {e2}
+            auto rec = [&](const float *lo, const float *hi, int t) {  // t: triangle id of a leaf record
+                const float4 *T = &P.tris[4 * (size_t)t];  // {v0, mat} {e1} {e2}
                 v.push_back(make_float4(lo[0], lo[1], lo[2], T[0].x));
                 v.push_back(make_float4(hi[0], hi[1], hi[2], T[0].y));
                 v.push_back(make_float4(T[0].z, T[1].x, T[1].y, T[1].z));
@@ -361,7 +410,7 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
                 if (!is_fork(l)) { rec(all_lo, all_hi, ~ref_of[l]); break; }
                 n = l;
             }
-            if (is_vine && v.size() == 4 * n_tri) { P.vine.swap(v); P.vine_uniform = uniform ? 1 : 0; }
+            if (is_vine && v.size() == 4 * leaf_tri.size()) { P.vine.swap(v); P.vine_uniform = uniform ? 1 : 0; }
         }
     }
     // Renumbering: the forks of the tree's top levels (breadth-first from the root, kTopForks of them) take the first indices, the
@@ -393,12 +442,16 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
     }
     if (root_ref == REF_ABSENT) {  // empty scene: one childless fork, every ray misses
         forks.clear();
-        for (int k = 0; k < 4; k++) { const float e = (k & 1) ? kInf : -kInf; forks.push_back(make_float4(e, e, e, as_float(~(int)n_tri))); }
+        for (int k = 0; k < 4; k++) { const float e = (k & 1) ? kInf : -kInf; forks.push_back(make_float4(e, e, e, as_float(-1))); }
         root_ref = 0;
         stack_need = 1;  // a ray that passes the (degenerate) root box pushes the left never-hit record
+        P.root_boxed = 1;
         P.root_lo = make_float4(0.f, 0.f, 0.f, 0.f);
         P.root_hi = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else if (root_ref >= 0) {
+        P.tris.assign(4, make_float4(0.f, 0.f, 0.f, 0.f));  // the never-hit record alone
+        P.tris[1].w = as_float(REF_FIN);
+        P.nrms.assign(3, make_float4(0.f, 0.f, 0.f, 0.f));
+    } else if (P.root_boxed) {
         P.root_lo = make_float4(bvh[0], bvh[1], bvh[2], 0.f);
         P.root_hi = make_float4(bvh[3], bvh[4], bvh[5], 0.f);
     }
@@ -610,12 +663,12 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     const int root_ref = P.root_ref, stack_need = P.stack_need;
 
     int rc;
-    // one node array: the all-zero record ~n_tri (what an absent child refers to: never hit), the triangle records in reverse order,
-    // then the forks (DevScene::forks points at fork 0)
-    const size_t tri_f4 = 4 * (n_tri + 1);
+    // one node array: the leaf records in reverse order of their ids (id k at record index ~k; id 0, directly in front of fork 0, is the
+    // all-zero record an absent child refers to: never hit), then the forks (DevScene::forks points at fork 0)
+    const size_t tri_f4 = tris.size(), n_ids = tris.size() / 4;
     if ((tri_f4 + forks.size()) * sizeof(float4) >= ((size_t)1 << 32)) return fail(c, GLRTX_EINVAL, "glrtx_upload_scene: node array exceeds 4 GiB");
     std::vector<float4> nodes(tri_f4 + forks.size(), make_float4(0.f, 0.f, 0.f, 0.f));
-    for (size_t t = 0; t < n_tri; t++) std::memcpy(&nodes[4 * (n_tri - t)], &tris[4 * t], 4 * sizeof(float4));
+    for (size_t id = 0; id < n_ids; id++) std::memcpy(&nodes[4 * (n_ids - 1 - id)], &tris[4 * id], 4 * sizeof(float4));
     std::memcpy(nodes.data() + tri_f4, forks.data(), forks.size() * sizeof(float4));
     if ((rc = dev_upload(c, c->forks, nodes.data(), nodes.size() * sizeof(float4)))) return rc;
     if ((rc = dev_upload(c, c->nrms, nrms.data(), nrms.size() * sizeof(float4)))) return rc;
@@ -631,6 +684,7 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     sc.mats = (const float4 *)c->mats.p;
     sc.lights = (const float4 *)c->lights.p;
     sc.root_ref = root_ref;
+    sc.root_boxed = P.root_boxed;
     sc.root_lo = P.root_lo; sc.root_hi = P.root_hi;
     sc.n_light = (int)n_light;
     sc.n_mat = (int)n_mat;

@@ -20,12 +20,15 @@
 //            {minL.xyz, refL} {maxL.xyz, refR} {minR.xyz, -} {maxR.xyz, -}
 //            ref >= 0 -> fork index, ref < 0 -> ~triangle (leaf nodes are folded into their
 //            parent's ref: the reference never tests a leaf's own box, raytrace.frag:310-331).
-//            A child the wire format leaves out (children.x/y < 0; no builder of this repository does) is ~n_tri: a record of
-//            zeros in front of the triangles, "tested" like a leaf and never hit (det = 0), so that the step carries no test
+//            A child the wire format leaves out (children.x/y < 0; no builder of this repository does) is record -1 (triangle id 0):
+//            zeros, "tested" like a leaf and never hit (det = 0), so that the step carries no test
 //            for absent children.  The root's own box is in DevScene.
-//   tris   : 4 x float4 (64 B, the shape of a fork record) per triangle {v0.xyz, materialId} {v1-v0, -} {v2-v0, -} {-},
-//            in the same array as the forks, triangle t at record index ~t (DevScene::forks)
-//   nrms   : 3 x float4 per triangle {n0} {n1} {n2}   (read once per ray, for the closest hit only)
+//   tris   : 4 x float4 (64 B, the shape of a fork record) per LEAF of the tree {v0.xyz, materialId} {v1-v0, next} {v2-v0, -} {-},
+//            in the same array as the forks: the leaf with triangle id k (k >= 1, numbered in the order the traversal meets the leaves;
+//            a hit carries this id, not the wire triangle index) at record index ~k; id 0 is the never-hit record.  `next` = REF_FIN, or
+//            the ref of the triangle record chained behind this one: the two leaves of a fork with two leaf children are tested one
+//            after the other without a fork record in between (pack_scene)
+//   nrms   : 3 x float4 per triangle id {n0} {n1} {n2}   (read once per ray, for the closest hit only)
 //   mats   : 3 x float4 per material {emission.xyz, type} {param0.xyz, alpha.x} {param1.xyz, alpha.y}
 //   lights : 6 x float4 per light triangle {v0, materialId} {v1} {v2} {n0} {n1} {n2}
 #pragma once
@@ -59,6 +62,8 @@ struct DevScene {
     const float4 *lights;
     float4 root_lo, root_hi;  // the root fork's own box
     int root_ref;
+    int root_boxed;     // the tree's root is a fork in the wire format: root_lo / root_hi are tested before the first step (also when the
+                        // root is packed as a chained leaf pair and root_ref is a triangle record)
     int n_light;
     int n_mat;
     int n_fork;
@@ -321,7 +326,7 @@ DEV bool trav_init(const DevScene &sc, const float4 *root, Trav &T, float ox, fl
 #ifdef GLRTX_TRAV_STATS
     T.iters = 0;
 #endif
-    if (T.cur >= 0) {  // the root fork's own box
+    if (sc.root_boxed) {  // the root fork's own box
         float t0;
         if (!box_pass(root[0], root[1], ox, oy, oz, T.ix, T.iy, T.iz, T.h.t, t0)) return false;
     }
@@ -434,9 +439,12 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
         T.h.tri = closer ? t : T.h.tri;
         if (CLOSEST) { T.h.u = closer ? u : T.h.u; T.h.v = closer ? v : T.h.v; }
         T.h.t = closer ? tt : T.h.t;  // == hit ? min(tHit, tt) : tHit (a NaN tt is never closer)
-        // shadow ray: once an occluder is known the light test has failed and the traversal ends; otherwise on to the stack
-        need_pop = !(T.stop_d - T.h.t >= PT_EPS);
-        T.cur = REF_FIN;
+        // shadow ray: once an occluder is known the light test has failed and the traversal ends; otherwise on to the triangle chained
+        // behind this one (the other leaf of a leaf pair, pack_scene) or, without one, to the stack
+        const bool stopped = T.stop_d - T.h.t >= PT_EPS;
+        const int next = __float_as_int(B.w);
+        T.cur = stopped ? REF_FIN : next;
+        need_pop = !stopped && next == REF_FIN;
     }
     // pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298.  Hand-written: as C++ the
     // compiler's structurizer spends ~30 instructions of exec-mask bookkeeping per trip on this loop-with-two-exits, the loop
@@ -1594,7 +1602,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
             cur_ix = 1.0f / d.x; cur_iy = 1.0f / d.y; cur_iz = 1.0f / d.z;
             const bool shadow = (__float_as_uint(o.w) & 1u) != 0u;
             float t0;
-            if (a.sc.root_ref >= 0 && !box_pass(root[0], root[1], o.x, o.y, o.z, cur_ix, cur_iy, cur_iz, shadow ? shadow_limit(d.w) : PT_INFTY, t0))
+            if (a.sc.root_boxed && !box_pass(root[0], root[1], o.x, o.y, o.z, cur_ix, cur_iy, cur_iz, shadow ? shadow_limit(d.w) : PT_INFTY, t0))
                 d.w = __uint_as_float(__float_as_uint(d.w) | 0x80000000u);
         }
         return cnt;

@@ -15,6 +15,8 @@
 //   * the fork arm runs without a branch around it (nearly every step has fork lanes), the leaf arm is skipped when no lane is at a leaf;
 //   * a stack entry is {t0, ref}: the fork arm computes t0 of the left child into the register next to its ref, so a push is one
 //     ds_write_b64 of a register pair that already exists, and a pop one ds_read_b64;
+//   * the two leaves of a fork with two leaf children are chained: the first one's record names the second (pack_scene), and the leaf arm
+//     hands a lane on to it without a fork fetch, a push and a pop in between;
 //   * leaf (and absent) children carry an INFINITE box in the packed fork record (pack_scene), so "a leaf child is never box-tested"
 //     (raytrace.frag:310-331) needs no test of the ref's sign: the slab test passes by itself and yields t0 = -inf.
 // ~122 vector + ~13 scalar + ~8 branch instructions per step.
@@ -130,7 +132,7 @@
     "s_and_b64 exec, %[act], %[leaf]\n\t"                               /* ---- leaf arm: A = {v0, material} v96..99, B = v1 - v0 v100..102, C = v2 - v0 v104..106 */ \
     "s_cbranch_scc0 21f\n\t"                                                                                                                           \
     "v_not_b32 v99, %[cur]\n\t"                                         /* triangle index */                                                           \
-    "v_mov_b32 %[cur], v107\n\t"                                        /* nothing follows a leaf but the stack */                                     \
+    "v_mov_b32 %[cur], v103\n\t"                                       /* the triangle chained behind this one (the other leaf of a leaf pair), or REF_FIN */            \
     "v_mul_f32 v112, %[dy], v106\n\t"                                   /* p = d x e2 */                                                               \
     "v_mul_f32 v115, %[dz], v105\n\t"                                                                                                                  \
     "v_sub_f32 v112, v112, v115\n\t"                                                                                                                   \
@@ -212,8 +214,11 @@
     "20:\n\t"                                                                                                                                          \
     "s_and_b64 exec, %[act], %[leaf]\n\t"                               /* every leaf lane again */                                                    \
     "v_sub_f32 v112, %[sd], %[th]\n\t"                                  /* shadow ray: a known occluder ends the traversal */                          \
-    "v_cmp_nle_f32 vcc, %[eps], v112\n\t"                               /* !(stop_d - tHit >= EPS): on to the stack */                                 \
-    "s_or_b64 %[pop], %[pop], vcc\n\t"                                                                                                                 \
+    "v_cmp_nle_f32 vcc, %[eps], v112\n\t"                              /* !(stop_d - tHit >= EPS): the ray goes on */                                 \
+    "v_cndmask_b32 %[cur], v107, %[cur], vcc\n\t"                      /* ... with the chained triangle if there is one; a stopped ray is finished */ \
+    "v_cmp_eq_u32_e64 %[tmp], %[cur], v107\n\t"                                                                                                       \
+    "s_and_b64 vcc, vcc, %[tmp]\n\t"                                   /* goes on and has nothing chained: on to the stack */                         \
+    "s_or_b64 %[pop], %[pop], vcc\n\t"                                                                                                                \
     "21:\n\t"                                                                                                                                          \
     "s_mov_b64 exec, %[pop]\n\t"                                        /* ---- pop; entries whose entry distance now lies beyond tHit are the ones the reference culls at :298 */ \
     "s_cbranch_execz 30f\n\t"                                                                                                                          \

@@ -184,13 +184,43 @@ def _check(sc):
     return rc, nf.value, se.value, L.glrtx_last_error(None).decode()
 
 
+def _leaf_pairs(sc):
+    """Forks of the wire tree whose two children are both leaves: packed as two chained triangle records, without a fork record."""
+    n = sc["bvh"].reshape(-1, 9)
+    fork = n[:, 8] < 0
+    f = np.flatnonzero(fork)
+    l, r = n[f, 6].astype(int), n[f, 7].astype(int)
+    return int(((l >= 0) & (r >= 0) & ~fork[np.maximum(l, 0)] & ~fork[np.maximum(r, 0)]).sum())
+
+
 def test_check_scene_accepts_generated_scenes():
     for name in ("c1", "c2"):
         sc, _ = scenes.CONFIGS[name](32, 32)
         rc, n_fork, need, _ = _check(sc)
-        assert rc == 0 and n_fork == sc["tri"].shape[0] - 1 and 0 < need <= sc["bvh_depth"]
+        assert rc == 0 and n_fork == sc["tri"].shape[0] - 1 - _leaf_pairs(sc) and 0 < need <= sc["bvh_depth"]
+        assert _leaf_pairs(sc) > 0.3 * sc["tri"].shape[0] / 2  # the SAH builder ends most branches in a pair of leaves
     sc, _ = scenes.config_c3(32, 32, n=300, bvh="chain")
-    assert _check(sc)[:3] == (0, 299, 1)
+    assert _check(sc)[:3] == (0, 298, 1)  # 299 forks, the last one holds two leaves
+
+
+def test_leaf_pairs_are_chained_triangle_records():
+    """A fork with two leaf children leaves no fork record: its parent refers to the triangle record of children.y (popped first,
+    raytrace.frag:299-307), which names the record of children.x -- its predecessor in memory.  Checked on the packed refs."""
+    sc, _ = scenes.config_c1(16, 16, subdiv=1)
+    rc, forks, root, need = _pack(sc)
+    assert rc == 0
+    refs = forks.view(np.int32)[:, [3, 7]]
+    n_tri = sc["tri"].reshape(-1, 4).shape[0]
+    leaf_refs = refs[refs < -1]
+    assert len(forks) == n_tri - 1 - _leaf_pairs(sc)
+    # every triangle id 1..n_tri is reachable: directly from a fork, or as the second record of a pair (first - 1)
+    ids = set((~leaf_refs).tolist())
+    assert len(ids) == len(leaf_refs)
+    assert len(ids) + _leaf_pairs(sc) == n_tri and max(ids) <= n_tri and min(ids) >= 1
+    # two-triangle scene: the root itself is a pair -> no fork at all, the root ref is a triangle record and the root box is still tested
+    sc2, _ = scenes.config_c3(16, 16, n=2, bvh="chain")
+    rc, forks2, root2, need2 = _pack(sc2)
+    assert rc == 0 and len(forks2) == 0 and root2 == ~1 and need2 == 0
 
 
 def test_check_scene_rejects_malformed_scenes():
@@ -329,7 +359,7 @@ def test_a_long_chain_of_one_child_forks_needs_one_stack_entry_like_the_referenc
         out[0 if j == 0 else 3 + j - 1] = u
     rc, forks, root, need = _pack(dict(sc, bvh=np.array(out, np.float32).reshape(-1, 3)))
     assert rc == 0, device.lib().glrtx_last_error(None)
-    assert len(forks) == n_chain + 1
+    assert len(forks) == n_chain  # the two-leaf fork at the end of the chain is packed as a pair of chained triangle records
     deepest, _ = _deepest_stack(forks, root)
     assert need == deepest == 1
 
