@@ -993,9 +993,11 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
         ExtArgs ex{};
         ex.spheres = (const float4 *)c->spheres.p; ex.sphere_mat = (const int *)c->sphereMat.p;
         ex.n_spheres = c->n_spheres; ex.flags = c->ext_flags;
-        if (lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        const int lds_p = lds + (ext ? c->n_spheres * (int)sizeof(float4) : 0);  // extension kernel: the spheres are staged behind the stacks
+        if (lds_p > 160 * 1024) return fail(c, GLRTX_EDEVICE, "render kernel needs %d B of LDS (> 160 KiB)", lds_p);
+        if (lds_p > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
         int per_cu = 0;
-        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pk, kBlockThreads, lds));
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pk, kBlockThreads, lds_p));
         if (per_cu < 1) per_cu = 1;
         const int tiles8 = ((c->width + 7) / 8) * ((c->owned_rows + 7) / 8);
         const int n_chunks = (tiles8 * 64 + kChunk - 1) / kChunk;
@@ -1005,7 +1007,7 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
         HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(rec->ev0, c->stream));
         c->last_kernel = ext ? "pt_render_persistent (extensions)" : "pt_render_persistent";
-        hipLaunchKernelGGL(pk, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, (unsigned *)c->work.p, ex);
+        hipLaunchKernelGGL(pk, dim3(grid), dim3(kBlockThreads), lds_p, c->stream, a, (unsigned *)c->work.p, ex);
     } else {
     HIP_TRY(c, hipEventRecord(rec->ev0, c->stream));
     c->last_kernel = "pt_render_kernel";

@@ -1056,25 +1056,28 @@ DEV float sphere_t(float4 sp, float ox, float oy, float oz, float dx, float dy, 
 }
 
 // Closest hit over triangles (the reference traversal) and spheres; Hit::tri >= 0 triangle, -2 - k sphere k, -1 miss.
+// The spheres are staged into LDS at kernel start (ext_stage_spheres): the scan reads them with a wave-uniform ds_read_b128 each --
+// "scene primitives staged into LDS" as BASELINE.json's north_star words it.
 template <bool CLOSEST>
-DEV Hit traverse_ext(const DevScene &sc, const ExtArgs &ex, int *stack, float ox, float oy, float oz, float dx, float dy, float dz,
+DEV Hit traverse_ext(const DevScene &sc, const ExtArgs &ex, const float4 *lds_spheres, int *stack, float ox, float oy, float oz, float dx, float dy, float dz,
                      float limit = PT_INFTY, float stop_d = -__builtin_inff()) {
     Hit h = traverse<CLOSEST>(sc, stack, ox, oy, oz, dx, dy, dz, limit, stop_d);
+    const lds_cf4 q = (lds_cf4)lds_spheres;
     for (int k = 0; k < ex.n_spheres; k++) {
-        const float t = sphere_t(ex.spheres[k], ox, oy, oz, dx, dy, dz);
+        const float t = sphere_t(to_f4(q[k]), ox, oy, oz, dx, dy, dz);
         if (t < h.t) { h.t = t; h.tri = -2 - k; }
     }
     return h;
 }
 
-DEV bool bounce_ext(const KernelArgs &a, const ExtArgs &ex, const float4 *lds_mats, int *stack, Rng &rng, Path &P, unsigned long long &rays) {
-    const Hit h = traverse_ext<true>(a.sc, ex, stack, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz);
+DEV bool bounce_ext(const KernelArgs &a, const ExtArgs &ex, const float4 *lds_spheres, const float4 *lds_mats, int *stack, Rng &rng, Path &P, unsigned long long &rays) {
+    const Hit h = traverse_ext<true>(a.sc, ex, lds_spheres, stack, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz);
     rays++;
     Surf S;
     S.nx = S.ny = S.nz = 0.f; S.mtrl = 0;
     if (h.tri >= 0) S = surf_tri(a.sc, h);
     else if (h.tri < -1) {
-        const float4 sp = ex.spheres[-2 - h.tri];
+        const float4 sp = to_f4(((lds_cf4)lds_spheres)[-2 - h.tri]);
         const float qx = (P.ox + h.t * P.dx) - sp.x, qy = (P.oy + h.t * P.dy) - sp.y, qz = (P.oz + h.t * P.dz) - sp.z;
         const float r = rsq(dot3(qx, qy, qz, qx, qy, qz));
         S.nx = qx * r; S.ny = qy * r; S.nz = qz * r;
@@ -1084,7 +1087,7 @@ DEV bool bounce_ext(const KernelArgs &a, const ExtArgs &ex, const float4 *lds_ma
     shade_core<true>(a, lds_mats, rng, P, h.t, h.tri != -1, S, ex.flags, sh);
     bool ok = false;
     if (sh.has_shadow) {
-        const Hit s = traverse_ext<false>(a.sc, ex, stack, P.ox, P.oy, P.oz, sh.sdx, sh.sdy, sh.sdz, shadow_limit(sh.dist), sh.dist);
+        const Hit s = traverse_ext<false>(a.sc, ex, lds_spheres, stack, P.ox, P.oy, P.oz, sh.sdx, sh.sdy, sh.sdz, shadow_limit(sh.dist), sh.dist);
         rays++;
         ok = nee_accepted(sh.dist, s.t, s.tri != -1);
     } else if (sh.untraced) {
@@ -1164,6 +1167,15 @@ DEV void lds_setup(const KernelArgs &a, unsigned char *lds_raw, float4 *&lds_mat
     }
 }
 
+// Extension kernel: the analytic spheres ({centre, radius}, 16 B each, at most kMaxSpheres) go into LDS behind the traversal stacks.
+DEV float4 *ext_stage_spheres(const KernelArgs &a, const ExtArgs &ex, unsigned char *lds_raw) {
+    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    float4 *dst = reinterpret_cast<float4 *>(lds_raw + (size_t)mat_f4 * sizeof(float4) + (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int));
+    for (int i = threadIdx.x; i < ex.n_spheres; i += kBlockThreads) dst[i] = ex.spheres[i];
+    __syncthreads();
+    return dst;
+}
+
 template <bool COUNT_RAYS>
 DEV void flush_rays(const KernelArgs &a, unsigned long long rays) {
     if (COUNT_RAYS) {  // wave-level sums, one atomic per wavefront and counter
@@ -1221,12 +1233,30 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_kernel(const KernelAr
 // Work order: pixel id -> 8x8 tile (row-major over the tile grid) -> pixel within the tile.
 constexpr int kChunk = 256;
 
+// The kernel's by-value arguments as they lie in the kernarg segment.  The loop below reads its launch constants from there, through a
+// pointer the compiler cannot see through and takes anew in every trip, instead of from the by-value copies: those are loaded once at
+// kernel entry and stay live -- in ~100 scalar registers, most of them spilled to vector lanes -- across the traversal loops.
+struct PersistKernArgs {
+    KernelArgs a;
+    unsigned *work_counter;
+    ExtArgs ex;
+};
+DEV const PersistKernArgs *persist_kernargs() {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();  // constant address space
+    asm volatile("" : "+s"(p));  // opaque: loads through it stay behind this point
+    return (const PersistKernArgs *)p;
+}
+
 template <bool COUNT_RAYS, bool EXT = false>
-__global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const KernelArgs a, unsigned *work_counter, const ExtArgs ex) {
+__global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const KernelArgs a_entry, unsigned *work_counter_entry, const ExtArgs ex_entry) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4 *lds_mats;
     int *stack;
-    lds_setup(a, lds_raw, lds_mats, stack);
+    (void)work_counter_entry; (void)ex_entry;
+    lds_setup(a_entry, lds_raw, lds_mats, stack);
+    float4 *lds_spheres = nullptr;
+    if (EXT) lds_spheres = ext_stage_spheres(a_entry, ex_entry, lds_raw);
+    const KernelArgs &a = persist_kernargs()->a;  // (re-taken inside the loop)
 
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1247,6 +1277,9 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
     unsigned long long rays = 0;  // low half: reference rays, high half: those resolved without a traversal
 
     for (;;) {
+        const PersistKernArgs *ka = persist_kernargs();
+        const KernelArgs &a = ka->a;
+        unsigned *const work_counter = ka->work_counter;
         // ---- regeneration: idle lanes take the next pixels of the wave's chunk
         unsigned long long idle = __ballot(!alive);
         while (idle != 0ull && !exhausted) {
@@ -1293,7 +1326,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
                 fresh = false;
             }
             bool finished = true;
-            if (a.max_depth > 0) finished = EXT ? bounce_ext(a, ex, lds_mats, stack, rng, P, rays) : bounce(a, lds_mats, stack, rng, P, rays);
+            if (a.max_depth > 0) finished = EXT ? bounce_ext(a, ka->ex, lds_spheres, lds_mats, stack, rng, P, rays) : bounce(a, lds_mats, stack, rng, P, rays);
             if (finished) {
                 acc.x = acc.x + fmin_c(P.Lx, 100.0f);  // :558, :608
                 acc.y = acc.y + fmin_c(P.Ly, 100.0f);
@@ -1309,7 +1342,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
             }
         }
     }
-    flush_rays<COUNT_RAYS>(a, rays);
+    flush_rays<COUNT_RAYS>(persist_kernargs()->a, rays);
 }
 
 // ------------------------------------------------------------------------------------------ wavefront formulation
