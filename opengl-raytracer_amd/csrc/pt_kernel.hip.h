@@ -508,7 +508,8 @@ DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) 
     asm volatile(
         "s_mov_b64 %[entry], exec\n\t"
         "s_mov_b64 %[act], exec\n\t"
-        "v_bfrev_b32 v107, 1\n\t"
+        GLRTX_ASM_SET_VBASE
+        "v_bfrev_b32 v[GLRTX_VB+11], 1\n\t"
         GLRTX_REP(GLRTX_STEPS_PER_TRIP, GLRTX_TRAV_STEP_ASM)
         "99:\n\t"
         "s_mov_b64 exec, %[entry]"
@@ -516,8 +517,7 @@ DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) 
           [entry] "=&s"(s_entry), [act] "=&s"(s_act), [leaf] "=&s"(s_leaf), [bl] "=&s"(s_bl), [br] "=&s"(s_br), [pop] "=&s"(s_pop), [tmp] "=&s"(s_tmp) GLRTX_TS_OPERANDS
         : [ox] "v"(T.ox), [oy] "v"(T.oy), [oz] "v"(T.oz), [dx] "v"(T.dx), [dy] "v"(T.dy), [dz] "v"(T.dz), [ix] "v"(T.ix), [iy] "v"(T.iy), [iz] "v"(T.iz),
           [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [bias] "s"(sc.node_bias), [eps] "s"(PT_EPS), [big] "s"(0x1p126f)
-        : "vcc", "scc", "memory", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-          "v112", "v113", "v114", "v115", "v116", "v117" GLRTX_TS_CLOBBERS);
+        : "vcc", "scc", "memory", GLRTX_ASM_VCLOBBERS GLRTX_TS_CLOBBERS);
 }
 
 // intersect(Ray, Triangle) :226-257 against the running closest hit; v0 / e1 = v1-v0 / e2 = v2-v0

@@ -21,7 +21,8 @@
 //     (raytrace.frag:310-331) needs no test of the ref's sign: the slab test passes by itself and yields t0 = -inf.
 // ~122 vector + ~13 scalar + ~8 branch instructions per step.
 //
-// Register use: v96-v117 are scratch (clobbered): v96-v99 A, v100-v103 B, v104-v106 C, v108-v110 D (the 56-byte record; the arms
+// Register use: 22 scratch registers v[GLRTX_VB .. GLRTX_VB+21] (GLRTX_ASM_VBASE, default 96; clobbered), written below relative to the
+// assembler symbol GLRTX_VB; in the default build they are v96-v117: v96-v99 A, v100-v103 B, v104-v106 C, v108-v110 D (the 56-byte record; the arms
 // compute in place in it), v107 = REF_FIN, v111 an address / u, v112-v117 temporaries.  gfx950 hazards handled by hand (the assembler does not insert wait
 // states into inline asm): one independent instruction between v_rcp_f32 and the first use of its result (trans forwarding);
 // >= 4 instructions between v_div_scale (vcc) and v_div_fmas.
@@ -29,6 +30,21 @@
 
 #ifndef GLRTX_STEPS_PER_TRIP
 #define GLRTX_STEPS_PER_TRIP 6
+#endif
+// First of the 22 scratch VGPRs.  96 leaves v0-v95 to the compiler (four waves per SIMD: 128 VGPRs); an experiment build with five
+// waves per SIMD (96 VGPRs) moves the block down (-DGLRTX_ASM_VBASE=72 -DGLRTX_WGWF_WAVES=5).
+#ifndef GLRTX_ASM_VBASE
+#define GLRTX_ASM_VBASE 96
+#endif
+#define GLRTX_STR_(x) #x
+#define GLRTX_STR(x) GLRTX_STR_(x)
+#define GLRTX_ASM_SET_VBASE ".set GLRTX_VB, " GLRTX_STR(GLRTX_ASM_VBASE) "\n\t"
+#if GLRTX_ASM_VBASE == 96
+#define GLRTX_ASM_VCLOBBERS "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117"
+#elif GLRTX_ASM_VBASE == 72
+#define GLRTX_ASM_VCLOBBERS "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93"
+#else
+#error "GLRTX_ASM_VBASE: add the clobber list for this base"
 #endif
 
 // One step.  On entry exec = the lanes still running (== %[act]).  Falls through with exec = %[act] = the lanes still running after the
@@ -50,15 +66,15 @@
 // Measurement only (-DGLRTX_EXPERIMENT_EXTRA_LOADS=1|2): one or two MORE loads of the same record into scratch registers -- what a step
 // pays per additional vector-memory instruction on lines it fetches anyway (profiles/r03_traverse_bound.txt).
 #if defined(GLRTX_EXPERIMENT_EXTRA_LOADS) && GLRTX_EXPERIMENT_EXTRA_LOADS == 1
-#define GLRTX_X_LOADS "global_load_dwordx4 v[112:115], v111, %[base]\n\t"
+#define GLRTX_X_LOADS "global_load_dwordx4 v[GLRTX_VB+16:GLRTX_VB+19], v[GLRTX_VB+15], %[base]\n\t"
 #elif defined(GLRTX_EXPERIMENT_EXTRA_LOADS) && GLRTX_EXPERIMENT_EXTRA_LOADS == 2
-#define GLRTX_X_LOADS "global_load_dwordx4 v[112:115], v111, %[base]\n\tglobal_load_dwordx2 v[116:117], v111, %[base] offset:16\n\t"
+#define GLRTX_X_LOADS "global_load_dwordx4 v[GLRTX_VB+16:GLRTX_VB+19], v[GLRTX_VB+15], %[base]\n\tglobal_load_dwordx2 v[GLRTX_VB+20:GLRTX_VB+21], v[GLRTX_VB+15], %[base] offset:16\n\t"
 #else
 #define GLRTX_X_LOADS
 #endif
 
 // Measurement only (-DGLRTX_EXPERIMENT_EXTRA_VALU=16|32): that many more vector multiplies per step on a scratch register.
-#define GLRTX_X_V8 "v_mul_f32 v112, v112, v112\n\tv_mul_f32 v113, v113, v113\n\tv_mul_f32 v114, v114, v114\n\tv_mul_f32 v115, v115, v115\n\tv_mul_f32 v112, v112, v112\n\tv_mul_f32 v113, v113, v113\n\tv_mul_f32 v114, v114, v114\n\tv_mul_f32 v115, v115, v115\n\t"
+#define GLRTX_X_V8 "v_mul_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+16]\n\tv_mul_f32 v[GLRTX_VB+17], v[GLRTX_VB+17], v[GLRTX_VB+17]\n\tv_mul_f32 v[GLRTX_VB+18], v[GLRTX_VB+18], v[GLRTX_VB+18]\n\tv_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+19]\n\tv_mul_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+16]\n\tv_mul_f32 v[GLRTX_VB+17], v[GLRTX_VB+17], v[GLRTX_VB+17]\n\tv_mul_f32 v[GLRTX_VB+18], v[GLRTX_VB+18], v[GLRTX_VB+18]\n\tv_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+19]\n\t"
 #if defined(GLRTX_EXPERIMENT_EXTRA_VALU) && GLRTX_EXPERIMENT_EXTRA_VALU == 16
 #define GLRTX_X_VALU GLRTX_X_V8 GLRTX_X_V8
 #elif defined(GLRTX_EXPERIMENT_EXTRA_VALU) && GLRTX_EXPERIMENT_EXTRA_VALU == 32
@@ -69,154 +85,154 @@
 
 #define GLRTX_TRAV_STEP_ASM \
     GLRTX_TS_BEGIN \
-    "v_lshl_add_u32 v111, %[cur], 6, %[bias]\n\t"                                                                                                      \
-    "global_load_dwordx4 v[96:99], v111, %[base]\n\t"                                                                                                  \
-    "global_load_dwordx4 v[100:103], v111, %[base] offset:16\n\t"                                                                                      \
-    "global_load_dwordx3 v[104:106], v111, %[base] offset:32\n\t"                                                                                      \
-    "global_load_dwordx3 v[108:110], v111, %[base] offset:48\n\t"                                                                                      \
+    "v_lshl_add_u32 v[GLRTX_VB+15], %[cur], 6, %[bias]\n\t"                                                                                                      \
+    "global_load_dwordx4 v[GLRTX_VB+0:GLRTX_VB+3], v[GLRTX_VB+15], %[base]\n\t"                                                                                                  \
+    "global_load_dwordx4 v[GLRTX_VB+4:GLRTX_VB+7], v[GLRTX_VB+15], %[base] offset:16\n\t"                                                                                      \
+    "global_load_dwordx3 v[GLRTX_VB+8:GLRTX_VB+10], v[GLRTX_VB+15], %[base] offset:32\n\t"                                                                                      \
+    "global_load_dwordx3 v[GLRTX_VB+12:GLRTX_VB+14], v[GLRTX_VB+15], %[base] offset:48\n\t"                                                                                      \
     GLRTX_X_LOADS                                                                                      \
     "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t"                           /* lanes at a triangle */                                                      \
     "s_andn2_b64 exec, exec, %[leaf]\n\t"                               /* ---- fork arm: exec = lanes at a fork (may be none) */                      \
     GLRTX_TS_WAIT0 "s_waitcnt vmcnt(0)\n\t" GLRTX_TS_WAIT1 GLRTX_X_VALU                                                                                                                           \
-    "v_sub_f32 v100, v100, %[ox]\n\t"                                   /* left child: (hi - o), (lo - o) in place */                                  \
-    "v_sub_f32 v101, v101, %[oy]\n\t"                                                                                                                  \
-    "v_sub_f32 v102, v102, %[oz]\n\t"                                                                                                                  \
-    "v_sub_f32 v96, v96, %[ox]\n\t"                                                                                                                    \
-    "v_sub_f32 v97, v97, %[oy]\n\t"                                                                                                                    \
-    "v_sub_f32 v98, v98, %[oz]\n\t"                                                                                                                    \
-    "v_mul_f32 v100, v100, %[ix]\n\t"                                   /* f = (hi - o) / d, n = (lo - o) / d */                                       \
-    "v_mul_f32 v101, v101, %[iy]\n\t"                                                                                                                  \
-    "v_mul_f32 v102, v102, %[iz]\n\t"                                                                                                                  \
-    "v_mul_f32 v96, v96, %[ix]\n\t"                                                                                                                    \
-    "v_mul_f32 v97, v97, %[iy]\n\t"                                                                                                                    \
-    "v_mul_f32 v98, v98, %[iz]\n\t"                                                                                                                    \
-    "v_max_f32 v112, v100, v96\n\t"                                                                                                                    \
-    "v_min_f32 v96, v100, v96\n\t"                                                                                                                     \
-    "v_max_f32 v113, v101, v97\n\t"                                                                                                                    \
-    "v_min_f32 v97, v101, v97\n\t"                                                                                                                     \
-    "v_max_f32 v114, v102, v98\n\t"                                                                                                                    \
-    "v_min_f32 v100, v102, v98\n\t"                                                                                                                    \
-    "v_min3_f32 v112, v112, v113, v114\n\t"                             /* t1 */                                                                       \
-    "v_max3_f32 v98, v96, v97, v100\n\t"                                /* t0 of the left child, next to its ref: v[98:99] = {t0, ref} */              \
-    "v_min_f32 v112, v112, %[th]\n\t"                                                                                                                  \
-    "v_cmp_ge_f32_e64 %[bl], v112, v98\n\t"                             /* min(t1, tHit) >= t0 */                                                      \
-    "v_sub_f32 v108, v108, %[ox]\n\t"                                   /* right child: lo v104..106, hi v108..110 */                                  \
-    "v_sub_f32 v109, v109, %[oy]\n\t"                                                                                                                  \
-    "v_sub_f32 v110, v110, %[oz]\n\t"                                                                                                                  \
-    "v_sub_f32 v104, v104, %[ox]\n\t"                                                                                                                  \
-    "v_sub_f32 v105, v105, %[oy]\n\t"                                                                                                                  \
-    "v_sub_f32 v106, v106, %[oz]\n\t"                                                                                                                  \
-    "v_mul_f32 v108, v108, %[ix]\n\t"                                                                                                                  \
-    "v_mul_f32 v109, v109, %[iy]\n\t"                                                                                                                  \
-    "v_mul_f32 v110, v110, %[iz]\n\t"                                                                                                                  \
-    "v_mul_f32 v104, v104, %[ix]\n\t"                                                                                                                  \
-    "v_mul_f32 v105, v105, %[iy]\n\t"                                                                                                                  \
-    "v_mul_f32 v106, v106, %[iz]\n\t"                                                                                                                  \
-    "v_max_f32 v112, v108, v104\n\t"                                                                                                                   \
-    "v_min_f32 v104, v108, v104\n\t"                                                                                                                   \
-    "v_max_f32 v113, v109, v105\n\t"                                                                                                                   \
-    "v_min_f32 v105, v109, v105\n\t"                                                                                                                   \
-    "v_max_f32 v114, v110, v106\n\t"                                                                                                                   \
-    "v_min_f32 v106, v110, v106\n\t"                                                                                                                   \
-    "v_min3_f32 v112, v112, v113, v114\n\t"                                                                                                            \
-    "v_max3_f32 v104, v104, v105, v106\n\t"                                                                                                            \
-    "v_min_f32 v112, v112, %[th]\n\t"                                                                                                                  \
-    "v_cmp_ge_f32_e64 %[br], v112, v104\n\t"                                                                                                           \
-    "v_cndmask_b32_e64 %[cur], v99, v103, %[br]\n\t"                    /* go on with the right child if it passed, else with the left */              \
+    "v_sub_f32 v[GLRTX_VB+4], v[GLRTX_VB+4], %[ox]\n\t"                                   /* left child: (hi - o), (lo - o) in place */                                  \
+    "v_sub_f32 v[GLRTX_VB+5], v[GLRTX_VB+5], %[oy]\n\t"                                                                                                                  \
+    "v_sub_f32 v[GLRTX_VB+6], v[GLRTX_VB+6], %[oz]\n\t"                                                                                                                  \
+    "v_sub_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ox]\n\t"                                                                                                                    \
+    "v_sub_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[oy]\n\t"                                                                                                                    \
+    "v_sub_f32 v[GLRTX_VB+2], v[GLRTX_VB+2], %[oz]\n\t"                                                                                                                    \
+    "v_mul_f32 v[GLRTX_VB+4], v[GLRTX_VB+4], %[ix]\n\t"                                   /* f = (hi - o) / d, n = (lo - o) / d */                                       \
+    "v_mul_f32 v[GLRTX_VB+5], v[GLRTX_VB+5], %[iy]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+6], v[GLRTX_VB+6], %[iz]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ix]\n\t"                                                                                                                    \
+    "v_mul_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[iy]\n\t"                                                                                                                    \
+    "v_mul_f32 v[GLRTX_VB+2], v[GLRTX_VB+2], %[iz]\n\t"                                                                                                                    \
+    "v_max_f32 v[GLRTX_VB+16], v[GLRTX_VB+4], v[GLRTX_VB+0]\n\t"                                                                                                                    \
+    "v_min_f32 v[GLRTX_VB+0], v[GLRTX_VB+4], v[GLRTX_VB+0]\n\t"                                                                                                                     \
+    "v_max_f32 v[GLRTX_VB+17], v[GLRTX_VB+5], v[GLRTX_VB+1]\n\t"                                                                                                                    \
+    "v_min_f32 v[GLRTX_VB+1], v[GLRTX_VB+5], v[GLRTX_VB+1]\n\t"                                                                                                                     \
+    "v_max_f32 v[GLRTX_VB+18], v[GLRTX_VB+6], v[GLRTX_VB+2]\n\t"                                                                                                                    \
+    "v_min_f32 v[GLRTX_VB+4], v[GLRTX_VB+6], v[GLRTX_VB+2]\n\t"                                                                                                                    \
+    "v_min3_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+17], v[GLRTX_VB+18]\n\t"                             /* t1 */                                                                       \
+    "v_max3_f32 v[GLRTX_VB+2], v[GLRTX_VB+0], v[GLRTX_VB+1], v[GLRTX_VB+4]\n\t"                                /* t0 of the left child, next to its ref: v[GLRTX_VB+2:GLRTX_VB+3] = {t0, ref} */              \
+    "v_min_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], %[th]\n\t"                                                                                                                  \
+    "v_cmp_ge_f32_e64 %[bl], v[GLRTX_VB+16], v[GLRTX_VB+2]\n\t"                             /* min(t1, tHit) >= t0 */                                                      \
+    "v_sub_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], %[ox]\n\t"                                   /* right child: lo v[GLRTX_VB+8]..106, hi v[GLRTX_VB+12]..110 */                                  \
+    "v_sub_f32 v[GLRTX_VB+13], v[GLRTX_VB+13], %[oy]\n\t"                                                                                                                  \
+    "v_sub_f32 v[GLRTX_VB+14], v[GLRTX_VB+14], %[oz]\n\t"                                                                                                                  \
+    "v_sub_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], %[ox]\n\t"                                                                                                                  \
+    "v_sub_f32 v[GLRTX_VB+9], v[GLRTX_VB+9], %[oy]\n\t"                                                                                                                  \
+    "v_sub_f32 v[GLRTX_VB+10], v[GLRTX_VB+10], %[oz]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], %[ix]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+13], v[GLRTX_VB+13], %[iy]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+14], v[GLRTX_VB+14], %[iz]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], %[ix]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+9], v[GLRTX_VB+9], %[iy]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+10], v[GLRTX_VB+10], %[iz]\n\t"                                                                                                                  \
+    "v_max_f32 v[GLRTX_VB+16], v[GLRTX_VB+12], v[GLRTX_VB+8]\n\t"                                                                                                                   \
+    "v_min_f32 v[GLRTX_VB+8], v[GLRTX_VB+12], v[GLRTX_VB+8]\n\t"                                                                                                                   \
+    "v_max_f32 v[GLRTX_VB+17], v[GLRTX_VB+13], v[GLRTX_VB+9]\n\t"                                                                                                                   \
+    "v_min_f32 v[GLRTX_VB+9], v[GLRTX_VB+13], v[GLRTX_VB+9]\n\t"                                                                                                                   \
+    "v_max_f32 v[GLRTX_VB+18], v[GLRTX_VB+14], v[GLRTX_VB+10]\n\t"                                                                                                                   \
+    "v_min_f32 v[GLRTX_VB+10], v[GLRTX_VB+14], v[GLRTX_VB+10]\n\t"                                                                                                                   \
+    "v_min3_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+17], v[GLRTX_VB+18]\n\t"                                                                                                            \
+    "v_max3_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], v[GLRTX_VB+9], v[GLRTX_VB+10]\n\t"                                                                                                            \
+    "v_min_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], %[th]\n\t"                                                                                                                  \
+    "v_cmp_ge_f32_e64 %[br], v[GLRTX_VB+16], v[GLRTX_VB+8]\n\t"                                                                                                           \
+    "v_cndmask_b32_e64 %[cur], v[GLRTX_VB+3], v[GLRTX_VB+7], %[br]\n\t"                    /* go on with the right child if it passed, else with the left */              \
     "s_or_b64 %[tmp], %[bl], %[br]\n\t"                                                                                                                \
     "s_andn2_b64 %[pop], exec, %[tmp]\n\t"                              /* fork lanes with neither child: pop */                                       \
     "s_and_b64 exec, %[bl], %[br]\n\t"                                  /* both passed: the left one waits on the stack */                             \
-    "v_lshl_add_u32 v111, %[sp], 11, %[stk]\n\t"                                                                                                       \
-    "ds_write_b64 v111, v[98:99]\n\t"                                                                                                                  \
+    "v_lshl_add_u32 v[GLRTX_VB+15], %[sp], 11, %[stk]\n\t"                                                                                                       \
+    "ds_write_b64 v[GLRTX_VB+15], v[GLRTX_VB+2:GLRTX_VB+3]\n\t"                                                                                                                  \
     "v_add_u32 %[sp], 1, %[sp]\n\t"                                                                                                                    \
-    "s_and_b64 exec, %[act], %[leaf]\n\t"                               /* ---- leaf arm: A = {v0, material} v96..99, B = v1 - v0 v100..102, C = v2 - v0 v104..106 */ \
+    "s_and_b64 exec, %[act], %[leaf]\n\t"                               /* ---- leaf arm: A = {v0, material} v[GLRTX_VB+0]..99, B = v1 - v0 v[GLRTX_VB+4]..102, C = v2 - v0 v[GLRTX_VB+8]..106 */ \
     "s_cbranch_scc0 21f\n\t"                                                                                                                           \
-    "v_not_b32 v99, %[cur]\n\t"                                         /* triangle index */                                                           \
-    "v_mov_b32 %[cur], v103\n\t"                                       /* the triangle chained behind this one (the other leaf of a leaf pair), or REF_FIN */            \
-    "v_mul_f32 v112, %[dy], v106\n\t"                                   /* p = d x e2 */                                                               \
-    "v_mul_f32 v115, %[dz], v105\n\t"                                                                                                                  \
-    "v_sub_f32 v112, v112, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v113, %[dz], v104\n\t"                                                                                                                  \
-    "v_mul_f32 v115, %[dx], v106\n\t"                                                                                                                  \
-    "v_sub_f32 v113, v113, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v114, %[dx], v105\n\t"                                                                                                                  \
-    "v_mul_f32 v115, %[dy], v104\n\t"                                                                                                                  \
-    "v_sub_f32 v114, v114, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v116, v102, v114\n\t"                                    /* det = (e1.z pz + e1.y py) + e1.x px */                                      \
-    "v_mul_f32 v115, v101, v113\n\t"                                                                                                                   \
-    "v_add_f32 v116, v116, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v115, v100, v112\n\t"                                                                                                                   \
-    "v_add_f32 v116, v116, v115\n\t"                                                                                                                   \
-    "v_rcp_f32 v117, v116\n\t"                                                                                                                         \
-    "v_sub_f32 v96, %[ox], v96\n\t"                                     /* t = o - v0, in place */                                                     \
-    "v_sub_f32 v97, %[oy], v97\n\t"                                                                                                                    \
-    "v_sub_f32 v98, %[oz], v98\n\t"                                                                                                                    \
-    "v_fma_f32 v115, -v116, v117, 1.0\n\t"                              /* 1 / det: v_rcp + one Newton step (rcp_exact) */                             \
-    "v_fma_f32 v117, v115, v117, v117\n\t"                                                                                                             \
-    "v_cmp_lt_f32_e64 vcc, %[big], |v116|\n\t"                          /* |det| > 2^126: the full IEEE quotient */                                    \
+    "v_not_b32 v[GLRTX_VB+3], %[cur]\n\t"                                         /* triangle index */                                                           \
+    "v_mov_b32 %[cur], v[GLRTX_VB+7]\n\t"                                       /* the triangle chained behind this one (the other leaf of a leaf pair), or REF_FIN */            \
+    "v_mul_f32 v[GLRTX_VB+16], %[dy], v[GLRTX_VB+10]\n\t"                                   /* p = d x e2 */                                                               \
+    "v_mul_f32 v[GLRTX_VB+19], %[dz], v[GLRTX_VB+9]\n\t"                                                                                                                  \
+    "v_sub_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+17], %[dz], v[GLRTX_VB+8]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+19], %[dx], v[GLRTX_VB+10]\n\t"                                                                                                                  \
+    "v_sub_f32 v[GLRTX_VB+17], v[GLRTX_VB+17], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+18], %[dx], v[GLRTX_VB+9]\n\t"                                                                                                                  \
+    "v_mul_f32 v[GLRTX_VB+19], %[dy], v[GLRTX_VB+8]\n\t"                                                                                                                  \
+    "v_sub_f32 v[GLRTX_VB+18], v[GLRTX_VB+18], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+20], v[GLRTX_VB+6], v[GLRTX_VB+18]\n\t"                                    /* det = (e1.z pz + e1.y py) + e1.x px */                                      \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+5], v[GLRTX_VB+17]\n\t"                                                                                                                   \
+    "v_add_f32 v[GLRTX_VB+20], v[GLRTX_VB+20], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+4], v[GLRTX_VB+16]\n\t"                                                                                                                   \
+    "v_add_f32 v[GLRTX_VB+20], v[GLRTX_VB+20], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_rcp_f32 v[GLRTX_VB+21], v[GLRTX_VB+20]\n\t"                                                                                                                         \
+    "v_sub_f32 v[GLRTX_VB+0], %[ox], v[GLRTX_VB+0]\n\t"                                     /* t = o - v0, in place */                                                     \
+    "v_sub_f32 v[GLRTX_VB+1], %[oy], v[GLRTX_VB+1]\n\t"                                                                                                                    \
+    "v_sub_f32 v[GLRTX_VB+2], %[oz], v[GLRTX_VB+2]\n\t"                                                                                                                    \
+    "v_fma_f32 v[GLRTX_VB+19], -v[GLRTX_VB+20], v[GLRTX_VB+21], 1.0\n\t"                              /* 1 / det: v_rcp + one Newton step (rcp_exact) */                             \
+    "v_fma_f32 v[GLRTX_VB+21], v[GLRTX_VB+19], v[GLRTX_VB+21], v[GLRTX_VB+21]\n\t"                                                                                                             \
+    "v_cmp_lt_f32_e64 vcc, %[big], |v[GLRTX_VB+20]|\n\t"                          /* |det| > 2^126: the full IEEE quotient */                                    \
     "s_cbranch_vccz 12f\n\t"                                                                                                                           \
-    "v_div_scale_f32 v115, %[tmp], v116, v116, 1.0\n\t"                                                                                                \
-    "v_rcp_f32 v108, v115\n\t"                                                                                                                         \
-    "v_div_scale_f32 v109, vcc, 1.0, v116, 1.0\n\t"                                                                                                    \
-    "v_fma_f32 v110, -v115, v108, 1.0\n\t"                                                                                                             \
-    "v_fma_f32 v108, v110, v108, v108\n\t"                                                                                                             \
-    "v_mul_f32 v110, v109, v108\n\t"                                                                                                                   \
-    "v_fma_f32 v103, -v115, v110, v109\n\t"                                                                                                            \
-    "v_fma_f32 v110, v103, v108, v110\n\t"                                                                                                             \
-    "v_fma_f32 v115, -v115, v110, v109\n\t"                                                                                                            \
-    "v_div_fmas_f32 v115, v115, v108, v110\n\t"                                                                                                        \
-    "v_div_fixup_f32 v115, v115, v116, 1.0\n\t"                                                                                                        \
-    "v_cmp_lt_f32_e64 vcc, %[big], |v116|\n\t"                                                                                                         \
-    "v_cndmask_b32 v117, v117, v115, vcc\n\t"                                                                                                          \
+    "v_div_scale_f32 v[GLRTX_VB+19], %[tmp], v[GLRTX_VB+20], v[GLRTX_VB+20], 1.0\n\t"                                                                                                \
+    "v_rcp_f32 v[GLRTX_VB+12], v[GLRTX_VB+19]\n\t"                                                                                                                         \
+    "v_div_scale_f32 v[GLRTX_VB+13], vcc, 1.0, v[GLRTX_VB+20], 1.0\n\t"                                                                                                    \
+    "v_fma_f32 v[GLRTX_VB+14], -v[GLRTX_VB+19], v[GLRTX_VB+12], 1.0\n\t"                                                                                                             \
+    "v_fma_f32 v[GLRTX_VB+12], v[GLRTX_VB+14], v[GLRTX_VB+12], v[GLRTX_VB+12]\n\t"                                                                                                             \
+    "v_mul_f32 v[GLRTX_VB+14], v[GLRTX_VB+13], v[GLRTX_VB+12]\n\t"                                                                                                                   \
+    "v_fma_f32 v[GLRTX_VB+7], -v[GLRTX_VB+19], v[GLRTX_VB+14], v[GLRTX_VB+13]\n\t"                                                                                                            \
+    "v_fma_f32 v[GLRTX_VB+14], v[GLRTX_VB+7], v[GLRTX_VB+12], v[GLRTX_VB+14]\n\t"                                                                                                             \
+    "v_fma_f32 v[GLRTX_VB+19], -v[GLRTX_VB+19], v[GLRTX_VB+14], v[GLRTX_VB+13]\n\t"                                                                                                            \
+    "v_div_fmas_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+12], v[GLRTX_VB+14]\n\t"                                                                                                        \
+    "v_div_fixup_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+20], 1.0\n\t"                                                                                                        \
+    "v_cmp_lt_f32_e64 vcc, %[big], |v[GLRTX_VB+20]|\n\t"                                                                                                         \
+    "v_cndmask_b32 v[GLRTX_VB+21], v[GLRTX_VB+21], v[GLRTX_VB+19], vcc\n\t"                                                                                                          \
     "12:\n\t"                                                                                                                                          \
-    "v_mul_f32 v114, v98, v114\n\t"                                     /* U = (tz pz + ty py) + tx px */                                              \
-    "v_mul_f32 v115, v97, v113\n\t"                                                                                                                    \
-    "v_add_f32 v114, v114, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v115, v96, v112\n\t"                                                                                                                    \
-    "v_add_f32 v114, v114, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v111, v114, v117\n\t"                                    /* u */                                                                        \
-    "v_cmpx_nlt_f32_e64 %[tmp], |v116|, %[eps]\n\t"                     /* !(-EPS < det && det < EPS) */                                               \
-    "v_cmpx_ngt_f32 vcc, 0, v111\n\t"                                   /* !(u < 0) */                                                                 \
-    "v_cmpx_nlt_f32 vcc, 1.0, v111\n\t"                                 /* !(1 < u) */                                                                 \
+    "v_mul_f32 v[GLRTX_VB+18], v[GLRTX_VB+2], v[GLRTX_VB+18]\n\t"                                     /* U = (tz pz + ty py) + tx px */                                              \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+1], v[GLRTX_VB+17]\n\t"                                                                                                                    \
+    "v_add_f32 v[GLRTX_VB+18], v[GLRTX_VB+18], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+0], v[GLRTX_VB+16]\n\t"                                                                                                                    \
+    "v_add_f32 v[GLRTX_VB+18], v[GLRTX_VB+18], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+15], v[GLRTX_VB+18], v[GLRTX_VB+21]\n\t"                                    /* u */                                                                        \
+    "v_cmpx_nlt_f32_e64 %[tmp], |v[GLRTX_VB+20]|, %[eps]\n\t"                     /* !(-EPS < det && det < EPS) */                                               \
+    "v_cmpx_ngt_f32 vcc, 0, v[GLRTX_VB+15]\n\t"                                   /* !(u < 0) */                                                                 \
+    "v_cmpx_nlt_f32 vcc, 1.0, v[GLRTX_VB+15]\n\t"                                 /* !(1 < u) */                                                                 \
     "s_cbranch_execz 20f\n\t"                                                                                                                          \
-    "v_mul_f32 v108, v97, v102\n\t"                                     /* q = t x e1 */                                                               \
-    "v_mul_f32 v115, v98, v101\n\t"                                                                                                                    \
-    "v_sub_f32 v108, v108, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v109, v98, v100\n\t"                                                                                                                    \
-    "v_mul_f32 v115, v96, v102\n\t"                                                                                                                    \
-    "v_sub_f32 v109, v109, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v110, v96, v101\n\t"                                                                                                                    \
-    "v_mul_f32 v115, v97, v100\n\t"                                                                                                                    \
-    "v_sub_f32 v110, v110, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v103, %[dz], v110\n\t"                                   /* V = (dz qz + dy qy) + dx qx */                                              \
-    "v_mul_f32 v115, %[dy], v109\n\t"                                                                                                                  \
-    "v_add_f32 v103, v103, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v115, %[dx], v108\n\t"                                                                                                                  \
-    "v_add_f32 v103, v103, v115\n\t"                                                                                                                   \
-    "v_mul_f32 v112, v103, v117\n\t"                                    /* v */                                                                        \
-    "v_add_f32 v115, v114, v103\n\t"                                                                                                                   \
-    "v_mul_f32 v115, v117, v115\n\t"                                    /* inv (U + V): u + v > 1 is tested on it */                                   \
-    "v_cmpx_ngt_f32 vcc, 0, v112\n\t"                                   /* !(v < 0) */                                                                 \
-    "v_cmpx_nlt_f32 vcc, 1.0, v115\n\t"                                 /* !(1 < inv (U + V)) */                                                       \
+    "v_mul_f32 v[GLRTX_VB+12], v[GLRTX_VB+1], v[GLRTX_VB+6]\n\t"                                     /* q = t x e1 */                                                               \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+2], v[GLRTX_VB+5]\n\t"                                                                                                                    \
+    "v_sub_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+13], v[GLRTX_VB+2], v[GLRTX_VB+4]\n\t"                                                                                                                    \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+0], v[GLRTX_VB+6]\n\t"                                                                                                                    \
+    "v_sub_f32 v[GLRTX_VB+13], v[GLRTX_VB+13], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+14], v[GLRTX_VB+0], v[GLRTX_VB+5]\n\t"                                                                                                                    \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+1], v[GLRTX_VB+4]\n\t"                                                                                                                    \
+    "v_sub_f32 v[GLRTX_VB+14], v[GLRTX_VB+14], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+7], %[dz], v[GLRTX_VB+14]\n\t"                                   /* V = (dz qz + dy qy) + dx qx */                                              \
+    "v_mul_f32 v[GLRTX_VB+19], %[dy], v[GLRTX_VB+13]\n\t"                                                                                                                  \
+    "v_add_f32 v[GLRTX_VB+7], v[GLRTX_VB+7], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+19], %[dx], v[GLRTX_VB+12]\n\t"                                                                                                                  \
+    "v_add_f32 v[GLRTX_VB+7], v[GLRTX_VB+7], v[GLRTX_VB+19]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+16], v[GLRTX_VB+7], v[GLRTX_VB+21]\n\t"                                    /* v */                                                                        \
+    "v_add_f32 v[GLRTX_VB+19], v[GLRTX_VB+18], v[GLRTX_VB+7]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+21], v[GLRTX_VB+19]\n\t"                                    /* inv (U + V): u + v > 1 is tested on it */                                   \
+    "v_cmpx_ngt_f32 vcc, 0, v[GLRTX_VB+16]\n\t"                                   /* !(v < 0) */                                                                 \
+    "v_cmpx_nlt_f32 vcc, 1.0, v[GLRTX_VB+19]\n\t"                                 /* !(1 < inv (U + V)) */                                                       \
     "s_cbranch_execz 20f\n\t"                                                                                                                          \
-    "v_mul_f32 v115, v106, v110\n\t"                                    /* t = ((e2.z qz + e2.y qy) + e2.x qx) inv */                                  \
-    "v_mul_f32 v103, v105, v109\n\t"                                                                                                                   \
-    "v_add_f32 v115, v115, v103\n\t"                                                                                                                   \
-    "v_mul_f32 v103, v104, v108\n\t"                                                                                                                   \
-    "v_add_f32 v115, v115, v103\n\t"                                                                                                                   \
-    "v_mul_f32 v115, v115, v117\n\t"                                                                                                                   \
-    "v_cmpx_nge_f32 vcc, %[eps], v115\n\t"                              /* !(EPS >= t) */                                                              \
-    "v_cmpx_lt_f32 vcc, v115, %[th]\n\t"                                /* strictly closer: the first one visited wins a tie (:325) */                 \
-    "v_mov_b32 %[tri], v99\n\t"                                                                                                                        \
-    "v_mov_b32 %[hu], v111\n\t"                                                                                                                        \
-    "v_mov_b32 %[hv], v112\n\t"                                                                                                                        \
-    "v_mov_b32 %[th], v115\n\t"                                                                                                                        \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+10], v[GLRTX_VB+14]\n\t"                                    /* t = ((e2.z qz + e2.y qy) + e2.x qx) inv */                                  \
+    "v_mul_f32 v[GLRTX_VB+7], v[GLRTX_VB+9], v[GLRTX_VB+13]\n\t"                                                                                                                   \
+    "v_add_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+7]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+7], v[GLRTX_VB+8], v[GLRTX_VB+12]\n\t"                                                                                                                   \
+    "v_add_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+7]\n\t"                                                                                                                   \
+    "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+21]\n\t"                                                                                                                   \
+    "v_cmpx_nge_f32 vcc, %[eps], v[GLRTX_VB+19]\n\t"                              /* !(EPS >= t) */                                                              \
+    "v_cmpx_lt_f32 vcc, v[GLRTX_VB+19], %[th]\n\t"                                /* strictly closer: the first one visited wins a tie (:325) */                 \
+    "v_mov_b32 %[tri], v[GLRTX_VB+3]\n\t"                                                                                                                        \
+    "v_mov_b32 %[hu], v[GLRTX_VB+15]\n\t"                                                                                                                        \
+    "v_mov_b32 %[hv], v[GLRTX_VB+16]\n\t"                                                                                                                        \
+    "v_mov_b32 %[th], v[GLRTX_VB+19]\n\t"                                                                                                                        \
     "20:\n\t"                                                                                                                                          \
     "s_and_b64 exec, %[act], %[leaf]\n\t"                               /* every leaf lane again */                                                    \
-    "v_sub_f32 v112, %[sd], %[th]\n\t"                                  /* shadow ray: a known occluder ends the traversal */                          \
-    "v_cmp_nle_f32 vcc, %[eps], v112\n\t"                              /* !(stop_d - tHit >= EPS): the ray goes on */                                 \
-    "v_cndmask_b32 %[cur], v107, %[cur], vcc\n\t"                      /* ... with the chained triangle if there is one; a stopped ray is finished */ \
-    "v_cmp_eq_u32_e64 %[tmp], %[cur], v107\n\t"                                                                                                       \
+    "v_sub_f32 v[GLRTX_VB+16], %[sd], %[th]\n\t"                                  /* shadow ray: a known occluder ends the traversal */                          \
+    "v_cmp_nle_f32 vcc, %[eps], v[GLRTX_VB+16]\n\t"                              /* !(stop_d - tHit >= EPS): the ray goes on */                                 \
+    "v_cndmask_b32 %[cur], v[GLRTX_VB+11], %[cur], vcc\n\t"                      /* ... with the chained triangle if there is one; a stopped ray is finished */ \
+    "v_cmp_eq_u32_e64 %[tmp], %[cur], v[GLRTX_VB+11]\n\t"                                                                                                       \
     "s_and_b64 vcc, vcc, %[tmp]\n\t"                                   /* goes on and has nothing chained: on to the stack */                         \
     "s_or_b64 %[pop], %[pop], vcc\n\t"                                                                                                                \
     "21:\n\t"                                                                                                                                          \
@@ -224,21 +240,21 @@
     "s_cbranch_execz 30f\n\t"                                                                                                                          \
     "10:\n\t"                                                                                                                                          \
     "v_cmp_ne_u32 vcc, 0, %[sp]\n\t"                                                                                                                   \
-    "v_cndmask_b32 %[cur], v107, %[cur], vcc\n\t"                       /* empty stack: the ray is finished */                                         \
+    "v_cndmask_b32 %[cur], v[GLRTX_VB+11], %[cur], vcc\n\t"                       /* empty stack: the ray is finished */                                         \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                                                    \
     "s_cbranch_execz 30f\n\t"                                                                                                                          \
     "v_add_u32 %[sp], -1, %[sp]\n\t"                                                                                                                   \
-    "v_lshl_add_u32 v111, %[sp], 11, %[stk]\n\t"                                                                                                       \
-    "ds_read_b64 v[112:113], v111\n\t"                                  /* {t0, ref} */                                                                \
+    "v_lshl_add_u32 v[GLRTX_VB+15], %[sp], 11, %[stk]\n\t"                                                                                                       \
+    "ds_read_b64 v[GLRTX_VB+16:GLRTX_VB+17], v[GLRTX_VB+15]\n\t"                                  /* {t0, ref} */                                                                \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
-    "v_mov_b32 %[cur], v113\n\t"                                                                                                                       \
-    "v_cmp_gt_f32 vcc, v112, %[th]\n\t"                                                                                                                \
+    "v_mov_b32 %[cur], v[GLRTX_VB+17]\n\t"                                                                                                                       \
+    "v_cmp_gt_f32 vcc, v[GLRTX_VB+16], %[th]\n\t"                                                                                                                \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                                                    \
     "s_cbranch_execnz 10b\n\t"                                                                                                                         \
     "30:\n\t"                                                                                                                                          \
     "s_mov_b64 exec, %[act]\n\t"                                                                                  \
     GLRTX_TS_END                                                                                                                       \
-    "v_cmpx_ne_u32_e64 %[act], %[cur], v107\n\t"                        /* the lanes that go on */                                                     \
+    "v_cmpx_ne_u32_e64 %[act], %[cur], v[GLRTX_VB+11]\n\t"                        /* the lanes that go on */                                                     \
     "s_cbranch_execz 99f\n\t"
 
 #define GLRTX_REP1(X) X
