@@ -63,7 +63,7 @@ struct glrtx_ctx {
     DevBuf forks, nrms, mats, lights, vine, accum_own, counter, rgba8, work;
     DevBuf spheres, sphereMat;  // extension kernel: analytic spheres
     int n_spheres = 0, ext_flags = 0;
-    DevBuf wfState, wfQ;      // wavefront path state (7 planes of float4 x ids) + per-workgroup queues (variant 2)
+    DevBuf wfState, wfQ;      // wavefront path state (kWfStatePlanes = 6 planes of float4 x ids) + per-workgroup queues (variant 2)
     DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
     DevBuf bvhVert, bvhTri, bvhNodes;  // glrtx_build_lbvh staging
     lbvh::Workspace bvhWs;

@@ -1589,7 +1589,7 @@ __device__ uint4 g_trip_log[16][64];
 // counter).  A refill therefore touches no memory: the idle lane with rank r takes the record held by lane
 // (consumed + r) through a cross-lane read.  (Fetching a ray when a lane fell idle -- queue index, then path state, two
 // dependent round trips -- cost 14 % of the phase.  A second chunk fetched ahead of need was kept in round 1; measured
-// again after the kernel lost its spills it bought nothing (profiles/r02_ab_occupancy.txt) and its 8 registers were freed.)
+// again in round 2, after the kernel had lost its spills, it bought nothing and its 8 registers were freed; that A/B table was not kept.)
 template <bool VINE>
 DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, [[maybe_unused]] const float4 *lds_top, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned *light_bits, unsigned long long &rays) {
