@@ -56,6 +56,18 @@ class RowGather:
         dist.gather(local, self.blocks if rank == dst else None, dst=dst, group=self.group)
         return self.stack.index_select(0, self.src) if rank == dst else None
 
+    def gather_to_root_async(self, local, dst: int = 0):
+        """Start the gather of `local` (which must stay untouched until finish()) and return a handle for finish()."""
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group)
+        return (dist.gather(local, self.blocks if rank == dst else None, dst=dst, group=self.group, async_op=True), rank == dst)
+
+    def finish(self, handle):
+        """Complete a gather_to_root_async: the full image on the root, None elsewhere."""
+        work, is_root = handle
+        work.wait()
+        return self.stack.index_select(0, self.src) if is_root else None
+
     def all_gather(self, local):
         """The full image on every rank."""
         import torch.distributed as dist
