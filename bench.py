@@ -154,7 +154,13 @@ class GpuRenderer:
         # the accumulator lives in a torch tensor so that RCCL can gather it; the kernel writes it in place
         self.accum = torch.zeros((pad_rows, W, 4), dtype=torch.float32, device="cuda")
         self.dev.bind_accum(self.accum.data_ptr(), W * 16, pad_rows)
-        self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        # ONE stream for the render launches, torch's own kernels on the accumulator (zero_, clone, index_select) and the point at which RCCL picks
+        # the rows up: a torch stream of our own, made current.  (torch's default stream has handle 0, which glrtx_set_stream reads as "use the
+        # context's own non-blocking stream": launches there would not be ordered with torch's work or with the collective.)
+        self.stream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(self.stream)
+        self.dev.set_stream(self.stream.cuda_stream)
+        assert self.stream.cuda_stream != 0
         self.device = torch.device("cuda", local_rank)
 
     def render_frames(self, f0, n, seed_of):

@@ -80,6 +80,11 @@ def assert_bit_equal(a, b, what=""):
 @pytest.fixture(scope="session")
 def gpu_device():
     from glrt_amd import device
+    # torch brings its own copy of the HIP runtime; initialise it BEFORE libglrtx's (the other order leaves torch without a device:
+    # "No HIP GPUs are available" in the tests that hand a torch tensor or stream to the C ABI)
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     d = device.Device()
     yield d
     d.close()

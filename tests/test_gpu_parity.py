@@ -194,6 +194,37 @@ def test_bound_torch_accumulator_and_stream(gpu_device):
         d.bind_accum(0, 0, 0)
 
 
+def test_render_launches_are_ordered_with_torch_work_on_the_same_stream(gpu_device):
+    """What bench.py relies on for the RCCL gather: with a torch stream of its own set on the context, a torch kernel enqueued right after
+    glrtx_render_frames -- no sync in between -- sees the finished accumulator, and a zero_() enqueued before a launch is seen by it.
+    (torch's default stream has handle 0, which glrtx_set_stream takes as "the context's own stream": no ordering with torch there.)"""
+    import torch
+    d = gpu_device
+    scene, params = scenes.config_headline()
+    W, H = params["width"], params["height"]
+    seeds = [host.frame_seed(f) for f in range(4)]
+    ref, _ = gpu_render(d, scene, params, frames=seeds, count_rays=False)
+    stream = torch.cuda.Stream()
+    assert stream.cuda_stream != 0
+    t = torch.full((H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    d.bind_accum(t.data_ptr(), W * 16, H)
+    d.set_stream(stream.cuda_stream)
+    try:
+        with torch.cuda.stream(stream):
+            t.zero_()                                   # enqueued, not waited for
+            d.render_frames(params, seeds)              # 4 x 1080p: a few milliseconds of device time
+            snap = t.clone()                            # enqueued right behind the launch
+            total = t.sum(dtype=torch.float64)
+        stream.synchronize()
+        assert_bit_equal(snap.cpu().numpy(), ref, "clone enqueued behind the launch")
+        assert abs(float(total) - float(ref.astype(np.float64).sum())) <= 1e-6 * abs(float(ref.astype(np.float64).sum()))
+    finally:
+        d.sync()
+        d.set_stream(0)
+        d.bind_accum(0, 0, 0)
+
+
 def test_error_behaviour(gpu_device):
     d2 = device.Device()
     try:
