@@ -1,4 +1,5 @@
-"""bench.py's output contract: one JSON line with the driver's keys plus `roofline` and `cpu_baseline`."""
+"""bench.py's output contract: one JSON line with the driver's keys plus `roofline` (and the vector-memory, vector-ALU and auxiliary-kernel
+rooflines), `cpu_baseline`, the strong-scaling / predicted figures, and the check of the timed kernel's image."""
 import json
 import pathlib
 import subprocess
@@ -42,6 +43,17 @@ def test_bench_prints_one_contract_json_line():
     if rv is not None:  # needs the committed PMC summary under profiles/
         assert rv["unit"] == "G wave-instructions/s" and abs(rv["frac"] - rv["achieved"] / rv["peak"]) < 1e-3 and 0 < rv["lane_util"] <= 1
         assert rf["traffic"] is not None and rf["traffic"] > rf["algorithmic_bytes_per_launch"]
+    assert rf["traffic_measured_in_run"] is False and "stale_profile" in rf
+    if rf["stale_profile"] is None and rv is not None:  # the committed profile belongs to these kernel sources
+        vm = out["roofline_vmem"]
+        assert vm["bound"] == "vmem-issue" and abs(vm["frac"] - vm["achieved"] / vm["peak"]) < 1e-3 and 0.2 < vm["frac"] < 1.0
+    aux = out["roofline_aux"]
+    assert set(aux) == {"accumulate_planes_kernel", "resolve_kernel"}
+    for k in aux.values():
+        assert k["bound"] == "hbm" and k["peak"] == 8000.0 and 0.05 < k["frac"] < 1.0 and abs(k["achieved"] - k["bytes"] / (k["ms"] * 1e-3) / 1e9) / k["achieved"] < 1e-2
+    assert "bit-identical" in cfg["timed_kernel_image_check"] and cfg["strong"] is None
+    pred = cfg["predicted"]
+    assert set(pred) == {"2", "4", "8"} and all(0.5 < v["ms_per_step"] / out["ms_per_step"] < 2.0 for v in pred.values())
     cb = out["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
