@@ -31,6 +31,7 @@ constexpr int kStripeQuantum = 8;   // stripe heights are multiples of the 8x8 w
 constexpr int kGroupStripe = 8;     // stripe height glrtx_group uses: 1080 rows over 8 members = 136 / 128 rows (16-row stripes: 144 / 128)
 constexpr int kFramesBudgetGiB = 32;  // device memory one glrtx_render_frames launch may use for path state and sample planes
 constexpr float kInf = std::numeric_limits<float>::infinity();
+constexpr unsigned kPipeSlots = 4;    // single-frame launches that may render side by side (each with its own stream, state, queues, planes)
 constexpr unsigned kLaunchRing = 16;  // launches that may be outstanding per context before a new one waits for the oldest
 
 thread_local std::string g_create_error;
@@ -50,7 +51,8 @@ struct glrtx_ctx {
     // earlier launch; finished launches are folded into the stats lazily (glrtx_sync, glrtx_get_stats, or -- without blocking -- at the
     // next launch).  Only with kLaunchRing launches outstanding does a new launch wait, for the oldest one.
     struct LaunchRec {
-        hipEvent_t ev0 = nullptr, evm = nullptr, ev1 = nullptr;
+        hipEvent_t ev0 = nullptr, evm = nullptr, eva = nullptr, ev1 = nullptr;  // render start / end, accumulation start / end (eva recorded only by overlapped launches)
+        bool has_eva = false;
         const char *kernel = "";
         int frames = 0;
     };
@@ -65,6 +67,17 @@ struct glrtx_ctx {
     int n_spheres = 0, ext_flags = 0;
     DevBuf wfState, wfQ;      // wavefront path state (kWfStatePlanes = 6 planes of float4 x ids) + per-workgroup queues (variant 2)
     DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
+    // Single-frame launches that overlap (launch_wgwf): kPipeSlots slots used in turn, each with its own stream, path state, queues, tile
+    // counter and sample planes; the accumulator is only touched by the plane-accumulation pass, on the context's stream, in launch order.
+    struct PipeSlot {
+        hipStream_t stream = nullptr;
+        hipEvent_t render_done = nullptr, acc_done = nullptr;
+        bool used = false;
+        DevBuf state, queues, planes, work;
+    } pipe[kPipeSlots];
+    unsigned pipe_next = 0;
+    bool pipeline = true;           // GLRTX_NO_PIPELINE=1 switches it off (A/B)
+    int pipe_share = 2;             // an overlapped launch issued while others still render takes 1 / pipe_share of the workgroup slots (GLRTX_PIPE_SHARE; 1: all)
     DevBuf bvhVert, bvhTri, bvhNodes;  // glrtx_build_lbvh staging
     lbvh::Workspace bvhWs;
     int variant = 2;          // 0 = tile megakernel, 1 = persistent megakernel with path regeneration, 2 = workgroup-local wavefront
@@ -147,7 +160,7 @@ int fold_launches(glrtx_ctx *c, bool block, unsigned keep = 0) {
                         r.kernel, c->width, c->height, c->owned_rows, r.frames, c->device);
         float ms = 0.f, ms2 = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, r.ev0, r.evm));   // render kernel
-        HIP_TRY(c, hipEventElapsedTime(&ms2, r.evm, r.ev1));  // plane accumulation (frames in flight), else ~0
+        HIP_TRY(c, hipEventElapsedTime(&ms2, r.has_eva ? r.eva : r.evm, r.ev1));  // plane accumulation (frames in flight, overlapped single frames), else ~0
         c->st.kernel_ms_last = ms;
         c->st.kernel_ms_total += ms;
         c->st.accumulate_ms_total += ms2;
@@ -485,10 +498,22 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     if (2 * ids + 1 >= (size_t)UINT32_MAX)
         return fail(c, GLRTX_EINVAL, "glrtx_render_frames: %d frames of %zu pixels exceed the 32-bit ray id space", n_frames, total);
     int rc;
-    if ((rc = ensure(c, c->wfState, kWfStatePlanes * ids * sizeof(float4)))) return rc;
+    // A single-frame launch runs on one of two side streams with buffers of its own and hands its samples over in planes, so that the
+    // tail of one launch overlaps the head of the next (a persistent grid that holds a whole frame fills and drains slowly): what a
+    // caller that renders, resolves and saves every frame -- the reference's loop, window.cpp:121-169 -- gets without batching frames.
+    // Per pixel the additions happen in the same order (the plane-accumulation passes run on the context's stream, in launch order).
+    const size_t plane_bytes = (size_t)a.pitch_f4 * (size_t)c->owned_rows * sizeof(float4);
+    const bool piped = n_frames == 1 && c->pipeline && p->n_samples >= 1 && (size_t)p->n_samples * plane_bytes <= ((size_t)1 << 30);
+    glrtx_ctx::PipeSlot *slot = piped ? &c->pipe[c->pipe_next++ % kPipeSlots] : nullptr;
+    DevBuf &stateBuf = slot ? slot->state : c->wfState;
+    DevBuf &queueBuf = slot ? slot->queues : c->wfQ;
+    DevBuf &planeBuf = slot ? slot->planes : c->wfPlanes;
+    unsigned *const workPtr = (unsigned *)(slot ? slot->work.p : c->work.p);
+    const hipStream_t rstream = slot ? slot->stream : c->stream;  // the render kernel's stream
+    if ((rc = ensure(c, stateBuf, kWfStatePlanes * ids * sizeof(float4)))) return rc;
     WfArgs w;
     std::memset(&w, 0, sizeof w);
-    w.state = (float4 *)c->wfState.p;
+    w.state = (float4 *)stateBuf.p;
     w.ids = ids;
     w.total = (int)total;
     w.tiles8_x = tiles8_x;
@@ -500,10 +525,12 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const int n_planes = n_frames * p->n_samples;
     if (n_frames > 1) {
         if ((rc = ensure(c, c->wfSeeds, (size_t)n_frames * sizeof(float2)))) return rc;
-        if ((rc = ensure(c, c->wfPlanes, (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4)))) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->wfSeeds.p, seeds_xy, (size_t)n_frames * sizeof(float2), hipMemcpyHostToDevice, c->stream));
         w.seeds = (const float2 *)c->wfSeeds.p;
-        w.planes = (float4 *)c->wfPlanes.p;
+    }
+    if (n_frames > 1 || slot) {
+        if ((rc = ensure(c, planeBuf, (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4)))) return rc;
+        w.planes = (float4 *)planeBuf.p;
     }
 
     const int lds_base = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
@@ -529,8 +556,19 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockThreads, lds));
     if (per_cu < 1) per_cu = 1;
     if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));  // occupancy experiments
+    // An overlapped single-frame launch issued while earlier ones are still rendering takes a FRACTION (half) of the CUs' workgroup slots, so
+    // that launches are resident side by side -- one in its early, dense trips, the other in its late, sparse ones -- instead of the second
+    // waiting for the first to drain (all workgroups of a launch finish together by design).  A launch that finds the device idle takes all.
+    int share = 1;
+    if (slot && c->pipe_share > 1) {
+        int busy = 0;
+        for (auto &o : c->pipe)
+            if (&o != slot && o.used && hipEventQuery(o.render_done) == hipErrorNotReady) busy++;
+        (void)hipGetLastError();
+        if (busy > 0) share = c->pipe_share;
+    }
     // paths kept alive per workgroup: 1024, less when the launch cannot give every resident workgroup that many pixels
-    const int resident = per_cu * c->n_cu;
+    const int resident = std::max(1, per_cu / share) * c->n_cu;
     const size_t work = total * (size_t)n_frames;
     int block_paths = kWgPathsMax;
     while (block_paths > 256 && work < (size_t)resident * block_paths) block_paths /= 2;
@@ -539,7 +577,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const int grid = std::max(1, (int)std::min<size_t>((size_t)resident, (work + block_paths - 1) / block_paths));
     w.gss_div = 4 * grid;
     if (const char *v = std::getenv("GLRTX_GSS_DIV")) w.gss_div = std::max(0, std::atoi(v));
-    if ((rc = ensure(c, c->wfQ, (size_t)grid * kWgQueueF4 * sizeof(float4)))) return rc;  // per-workgroup queues
+    if ((rc = ensure(c, queueBuf, (size_t)grid * kWgQueueF4 * sizeof(float4)))) return rc;  // per-workgroup queues
     // Shape invariants of the hand-written kernel, checked on the host before every launch (an access past one of these
     // buffers is a GPU memory fault, not an error code): every path id the launch can form indexes inside the state arrays;
     // every workgroup of the grid has its own queue slice; a slice holds both halves of the double-buffered ray queue
@@ -548,27 +586,37 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
         const size_t max_id = ids - 1;
         const size_t slice_f4 = 2 * (size_t)2 * 2 * block_paths /* ray records */ + (2 * (size_t)block_paths * sizeof(unsigned) + 15) / 16 /* path ids [2] */;
         bool ok = max_id < ids && 2 * max_id + 1 < (size_t)WF_INVALID && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
-                  block_paths <= kWgPathsMax && slice_f4 <= kWgQueueF4 && c->wfQ.bytes >= (size_t)grid * kWgQueueF4 * sizeof(float4) &&
-                  c->wfState.bytes >= kWfStatePlanes * ids * sizeof(float4) && w.ids == ids && grid >= 1 && grid <= resident &&
-                  p->max_depth <= kWfDepthMax && p->n_samples <= kWfSampleMax && c->work.p != nullptr;
-        if (n_frames > 1) ok = ok && c->wfPlanes.bytes >= (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4) && c->wfSeeds.bytes >= (size_t)n_frames * sizeof(float2);
+                  block_paths <= kWgPathsMax && slice_f4 <= kWgQueueF4 && queueBuf.bytes >= (size_t)grid * kWgQueueF4 * sizeof(float4) &&
+                  stateBuf.bytes >= kWfStatePlanes * ids * sizeof(float4) && w.ids == ids && grid >= 1 && grid <= resident &&
+                  p->max_depth <= kWfDepthMax && p->n_samples <= kWfSampleMax && workPtr != nullptr;
+        if (n_frames > 1) ok = ok && c->wfSeeds.bytes >= (size_t)n_frames * sizeof(float2);
+        if (w.planes) ok = ok && planeBuf.bytes >= (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4);
         if (!ok) return fail(c, GLRTX_EDEVICE, "internal: wgwf launch shapes inconsistent (ids %zu, max id %zu, grid %d, block_paths %d, frames %d)", ids, max_id, grid, block_paths, n_frames);
     }
     glrtx_ctx::LaunchRec *rec = nullptr;
     if ((rc = next_launch_rec(c, rec))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
-    HIP_TRY(c, hipEventRecord(rec->ev0, c->stream));
+    // a slot's render kernel overwrites the planes its previous plane-accumulation pass (two launches ago, on the context's stream) reads
+    if (slot && slot->used) HIP_TRY(c, hipStreamWaitEvent(rstream, slot->acc_done, 0));
+    HIP_TRY(c, hipMemsetAsync(workPtr, 0, sizeof(unsigned), rstream));
+    HIP_TRY(c, hipEventRecord(rec->ev0, rstream));
     c->last_kernel = vine ? "pt_render_wgwf (list scan)" : "pt_render_wgwf";
     c->counters_stale = c->counters_stale || c->count_rays;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), lds, c->stream, a, w, (unsigned *)c->work.p, (float4 *)c->wfQ.p);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), lds, rstream, a, w, workPtr, (float4 *)queueBuf.p);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(rec->evm, c->stream));
-    if (n_frames > 1 && n_planes > 0) {
+    HIP_TRY(c, hipEventRecord(rec->evm, rstream));
+    if (slot) {  // the context's stream -- where the caller's own work, the resolve pass and the next accumulation are ordered -- takes over
+        HIP_TRY(c, hipEventRecord(slot->render_done, rstream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, slot->render_done, 0));
+        HIP_TRY(c, hipEventRecord(rec->eva, c->stream));  // (the interval evm..ev1 would include the wait for the passes queued before this one)
+    }
+    rec->has_eva = slot != nullptr;
+    if (w.planes && n_planes > 0) {
         const dim3 g((c->width + 63) / 64, (c->owned_rows + 3) / 4);
         hipLaunchKernelGGL(accumulate_planes_kernel, g, dim3(256), 0, c->stream, a.accum, a.pitch_f4, c->width, c->owned_rows,
-                           (const float4 *)c->wfPlanes.p, n_planes);
+                           (const float4 *)planeBuf.p, n_planes);
         HIP_TRY(c, hipGetLastError());
     }
+    if (slot) { HIP_TRY(c, hipEventRecord(slot->acc_done, c->stream)); slot->used = true; }
     HIP_TRY(c, hipEventRecord(rec->ev1, c->stream));
     rec->kernel = c->last_kernel; rec->frames = n_frames;
     c->ring_head++;
@@ -618,12 +666,22 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
         return GLRTX_EDEVICE;
     }
     for (auto &r : c->ring)
-        if ((e = hipEventCreate(&r.ev0)) != hipSuccess || (e = hipEventCreate(&r.evm)) != hipSuccess || (e = hipEventCreate(&r.ev1)) != hipSuccess) {
+        if ((e = hipEventCreate(&r.ev0)) != hipSuccess || (e = hipEventCreate(&r.evm)) != hipSuccess || (e = hipEventCreate(&r.eva)) != hipSuccess ||
+            (e = hipEventCreate(&r.ev1)) != hipSuccess) {
             fail(nullptr, GLRTX_EDEVICE, "context setup failed: %s", hipGetErrorString(e));
             glrtx_destroy(c);
             return GLRTX_EDEVICE;
         }
     c->stream = c->own_stream;
+    for (auto &sl : c->pipe)
+        if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreateWithFlags(&sl.render_done, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&sl.acc_done, hipEventDisableTiming)) != hipSuccess || (e = hipMalloc(&sl.work.p, 64)) != hipSuccess) {
+            fail(nullptr, GLRTX_EDEVICE, "context setup failed: %s", hipGetErrorString(e));
+            glrtx_destroy(c);
+            return GLRTX_EDEVICE;
+        }
+    c->pipeline = std::getenv("GLRTX_NO_PIPELINE") == nullptr;
+    if (const char *v = std::getenv("GLRTX_PIPE_SHARE")) c->pipe_share = std::max(1, std::min(4, std::atoi(v)));
     c->n_cu = prop.multiProcessorCount;
     if (const char *v = std::getenv("GLRTX_VARIANT")) { const int x = std::atoi(v); if (x >= 0 && x <= 2) c->variant = x; }
     *out = c;
@@ -634,6 +692,12 @@ void glrtx_destroy(glrtx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    for (auto &sl : c->pipe) {
+        if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
+        if (sl.render_done) (void)hipEventDestroy(sl.render_done);
+        if (sl.acc_done) (void)hipEventDestroy(sl.acc_done);
+        dev_free(sl.state); dev_free(sl.queues); dev_free(sl.planes); dev_free(sl.work);
+    }
     dev_free(c->spheres); dev_free(c->sphereMat); dev_free(c->forks); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights); dev_free(c->vine);
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
     dev_free(c->wfState); dev_free(c->wfQ); dev_free(c->wfSeeds); dev_free(c->wfPlanes);
@@ -642,6 +706,7 @@ void glrtx_destroy(glrtx_ctx *c) {
     for (auto &r : c->ring) {
         if (r.ev0) (void)hipEventDestroy(r.ev0);
         if (r.evm) (void)hipEventDestroy(r.evm);
+        if (r.eva) (void)hipEventDestroy(r.eva);
         if (r.ev1) (void)hipEventDestroy(r.ev1);
     }
     if (c->tm0) (void)hipEventDestroy(c->tm0);
@@ -1024,7 +1089,7 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(rec->evm, c->stream));
     HIP_TRY(c, hipEventRecord(rec->ev1, c->stream));
-    rec->kernel = c->last_kernel; rec->frames = 1;
+    rec->kernel = c->last_kernel; rec->frames = 1; rec->has_eva = false;
     c->ring_head++;
     c->counters_stale = c->counters_stale || c->count_rays;
     c->st.frames_last = 1;

@@ -1383,8 +1383,9 @@ struct WfArgs {
     // Frames in flight (glrtx_render_frames): n_frames consecutive frames that differ only in u_seed run in ONE launch.
     // Path ids are frame * total + tile-order pixel id; every finished sample is stored in its own plane
     // (frame * n_samples + sample) and accumulate_planes_kernel adds the planes to the accumulator in frame order, so
-    // the sums are formed in exactly the order consecutive launches would form them.  n_frames == 1: samples are
-    // added to the accumulator directly and seeds/planes are unused.
+    // the sums are formed in exactly the order consecutive launches would form them.  n_frames == 1: seeds are unused; with planes == nullptr
+    // the samples are added to the accumulator directly, otherwise they go to planes as well (single-frame launches that overlap:
+    // the accumulator is then only touched by the plane-accumulation pass, in launch order).
     const float2 *seeds;  // u_seed of every frame
     float4 *planes;       // [n_frames * n_samples][owned_rows][pitch_f4] of {min(L, 100), -}
     int n_frames;
@@ -1428,7 +1429,7 @@ DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, int id) {
 // A finished sample: radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609).
 // Single frame: read-modify-write of the accumulator.  Frames in flight: the value goes to the sample's plane.
 DEV void wf_add_sample(const KernelArgs &a, const WfArgs &w, int id, int lx, int lrow, unsigned sample, float Lx, float Ly, float Lz) {
-    if (w.n_frames > 1) {
+    if (w.planes != nullptr) {  // frames in flight, or a single frame whose launch overlaps its neighbours (glrtx.hip: launch_wgwf)
         int frame, pid;
         w.split(id, frame, pid);
         const size_t slot = (size_t)frame * (size_t)a.n_samples + sample;
