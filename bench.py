@@ -40,7 +40,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
   roofline_valu -- vector-ALU issue roofline of the same kernel
   roofline_aux  -- the two kernels that ARE HBM-bound: accumulate_planes_kernel and resolve_kernel, GB/s against the HBM peak
   cpu_baseline  -- the CPU restatement (oracle/, "port") timed on this box's host cores (N = 1 only)
-and in config: `strong` (N > 1: a fixed 24 frames in flight in total, the framebuffer gathered after every launch) and `predicted`
+and in config: `strong` (N > 1: a fixed --steps-per-launch (48) frames in flight in total, the framebuffer gathered after every launch) and `predicted`
 (N = 1: what rank 0's share of an N-rank step costs on this one GPU, for N = 2, 4, 8 -- the compute side of the curve, no gather).
 """
 from __future__ import annotations
@@ -68,7 +68,7 @@ VALU_PEAK_GINST = 1024 * 2.4 / 2
 # (tools/ubench/ta.hip, profiles/r03_ubench_ta.txt: 24.1 G/s with the lanes of a quad in 3-4 lines, 37.5 G/s when they share a line)
 VMEM_PEAK_GINST = 24.1
 STRIPE = 8  # rows per stripe: 1080 rows over 8 ranks = 136 / 128 rows per rank (16-row stripes: 144 / 128, 6.7 % off balance)
-STEPS_PER_LAUNCH = 24  # frames' worth of paths in flight on every GPU per launch (frames in flight; 8 / 16 / 32: 2.19 / 2.04 / 1.97 ms in round 1)
+STEPS_PER_LAUNCH = 48  # frames' worth of paths in flight on every GPU per launch (frames in flight; round 3, ms per frame: 8: 1.127, 24: 1.060, 48: 1.043; 11 GB of path state and planes at 1080p)
 
 # Test hook: tests/ replace this with a factory of CPU renderers (same interface as GpuRenderer) to rehearse the
 # N > 1 control flow under gloo.  The product path never sets it.
