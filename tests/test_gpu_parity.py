@@ -292,6 +292,31 @@ def test_forks_with_an_absent_child_match_the_oracle(gpu_device):
         d.set_variant(2)
 
 
+@pytest.mark.parametrize("n", [12, 40, 63])
+def test_deep_traversal_stacks_match_the_oracle(gpu_device, n):
+    """A comb that stacks one entry per level (every fork = a leaf as children.x, the rest of the tree as children.y): the per-lane LDS
+    stack of the hand-written step at depths up to the reference's own limit (int stack[64], raytrace.frag:284), in all three kernel forms."""
+    from oracle import pt_oracle
+    scene, params = scenes.config_c3(64, 48, max_depth=3, n=n, bvh="chain")
+    nodes = scene["bvh"].reshape(-1, 9).copy()
+    fk = nodes[:, 8] < 0
+    nodes[fk, 6], nodes[fk, 7] = nodes[fk, 7].copy(), nodes[fk, 6].copy()
+    sc = dict(scene, bvh=nodes.reshape(-1, 3))
+    ref, ref_rays = pt_oracle.render(sc, params)
+    d = gpu_device
+    try:
+        for v in (2, 1, 0):
+            d.set_variant(v)
+            for count in (True, False):
+                acc, st = gpu_render(d, sc, params, count_rays=count)
+                assert st.stack_entries == n - 2  # n - 1 forks, the last one a leaf pair
+                if count:
+                    assert st.rays == ref_rays
+                assert_bit_equal(acc, ref, f"comb of {n}, variant {v}, counting {count}")
+    finally:
+        d.set_variant(2)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_all_kernel_variants_bit_identical(gpu_device, variant):
     """The tile megakernel (0), the persistent megakernel with path regeneration (1) and the
