@@ -577,6 +577,8 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const int grid = std::max(1, (int)std::min<size_t>((size_t)resident, (work + block_paths - 1) / block_paths));
     w.gss_div = 4 * grid;
     if (const char *v = std::getenv("GLRTX_GSS_DIV")) w.gss_div = std::max(0, std::atoi(v));
+    w.suspend_max = kSuspendMax;
+    if (const char *v = std::getenv("GLRTX_SUSPEND_MAX")) w.suspend_max = std::max(0, std::min(64, std::atoi(v)));
     if ((rc = ensure(c, queueBuf, (size_t)grid * kWgQueueF4 * sizeof(float4)))) return rc;  // per-workgroup queues
     // Shape invariants of the hand-written kernel, checked on the host before every launch (an access past one of these
     // buffers is a GPU memory fault, not an error code): every path id the launch can form indexes inside the state arrays;
@@ -585,7 +587,8 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     {
         const size_t max_id = ids - 1;
         const size_t slice_f4 = 2 * (size_t)2 * 2 * block_paths /* ray records */ + (2 * (size_t)block_paths * sizeof(unsigned) + 15) / 16 /* path ids [2] */;
-        bool ok = max_id < ids && 2 * max_id + 1 < (size_t)WF_INVALID && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
+        static_assert(kWgSuspendAt + (size_t)kSuspendF4 * kBlockThreads == kWgQueueF4, "the suspend area closes a workgroup's slice");
+        bool ok = slice_f4 <= kWgSuspendAt && max_id < ids && 2 * max_id + 1 < (size_t)WF_INVALID && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
                   block_paths <= kWgPathsMax && slice_f4 <= kWgQueueF4 && queueBuf.bytes >= (size_t)grid * kWgQueueF4 * sizeof(float4) &&
                   stateBuf.bytes >= kWfStatePlanes * ids * sizeof(float4) && w.ids == ids && grid >= 1 && grid <= resident &&
                   p->max_depth <= kWfDepthMax && p->n_samples <= kWfSampleMax && workPtr != nullptr;
@@ -1180,6 +1183,12 @@ int glrtx_debug_trav_stats(unsigned long long out[8]) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return GLRTX_EDEVICE;
     unsigned long long z[8] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
+    return GLRTX_OK;
+}
+int glrtx_debug_trav_trips(unsigned long long out[4]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_trips), 4 * sizeof(unsigned long long)) != hipSuccess) return GLRTX_EDEVICE;
+    unsigned long long z[4] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_trips), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
     return GLRTX_OK;
 }
 int glrtx_debug_trav_hist(unsigned long long out[16]) {

@@ -256,6 +256,7 @@ DEV bool box_pass(float4 lo, float4 hi, float ox, float oy, float oz, float ix, 
 // iterations, [2] lanes on the fork path, [3] lanes on the leaf path, [4] iterations with both paths live
 __device__ unsigned long long g_trav_stats[8];
 __device__ unsigned long long g_trav_hist[16];  // rays by ceil(log2(iterations))
+__device__ unsigned long long g_trav_trips[4];  // [0] stepping trips, [1] lanes with a ray at their start, [2] trips after the queue ran out (drain), [3] lanes in those
 // [5] distinct 64-byte node records, [6] distinct 128-byte lines fetched by the wave (summed over iterations), [7] lanes carrying a path ray
 DEV void trav_stats_iter(int cur, const void *rec, bool path_ray) {
     const unsigned long long m = __ballot(1), mf = __ballot(cur >= 0), mp = __ballot(path_ray);
@@ -1380,6 +1381,7 @@ struct WfArgs {
     int refill_min;   // refill a traversal wave once this many lanes are idle
     int block_paths;  // paths a workgroup keeps alive (power of two, 256 .. kWgPathsMax)
     int gss_div;      // top-up requests are capped at ceil(tiles left / gss_div); 0 = uncapped
+    int suspend_max;  // a wave parks its last path rays at the end of a trip when at most this many lanes still run (0: never; kSuspendMax)
     // Frames in flight (glrtx_render_frames): n_frames consecutive frames that differ only in u_seed run in ONE launch.
     // Path ids are frame * total + tile-order pixel id; every finished sample is stored in its own plane
     // (frame * n_samples + sample) and accumulate_planes_kernel adds the planes to the accumulator in frame order, so
@@ -1403,7 +1405,18 @@ constexpr int kWfDepthMax = 255;
 constexpr int kWfSampleMax = (1 << 20) - 1;
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
 constexpr unsigned WF_FINISHING = 1u << 29;  // the path has ended; only that shadow ray is awaited
+constexpr unsigned WF_RESOLVED = 1u << 30;   // the pending shadow ray's verdict is known already (bit 31) -- set when a path is deferred (below)
+constexpr unsigned WF_ACCEPTED = 1u << 31;
 constexpr unsigned WF_INVALID = 0xFFFFFFFFu; // queue entry to skip
+// Suspended rays.  When a wave's share of the trip's ray queue is used up, its last few lanes would go on alone until their (long) rays
+// are finished -- 12 % of the stepping trips of the headline config ran that way, on 13 lanes of 64 at their start.  Instead, once only
+// PATH rays are left in at most kSuspendMax lanes, the wave parks them: the traversal state goes to the workgroup's suspend area (the
+// per-lane LDS stacks stay where they are), the path's hit record gets the marker kHitSuspended, and the shade phase defers such a
+// path to the next trip -- no shading, no new rays, the verdict of a shadow ray that did finish carried in its state word -- where
+// the same lane picks the ray up again next to a full wave of new ones.  Only scheduling changes: every ray runs the same steps.
+constexpr int kSuspendMax = 24;
+constexpr float kHitSuspended = -1.0f;       // Hit::t of a suspended path ray (a real t exceeds PT_EPS, a miss is PT_INFTY)
+constexpr int kSuspendF4 = 4;                // float4s per lane in the suspend area: {o, rid} {d, stop_d} {tHit, tri, u, v} {cur, sp, slot in use, -}
 constexpr int kRefillMin = 16;               // refill a traversal wave once this many lanes are idle
 
 DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lrow) {
@@ -1488,7 +1501,7 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam,
 // sample (and start the pixel's next one) or run shade_hit() on the new hit.  Outputs which rays to
 // queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray.
 DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, unsigned id, bool light_accepted, bool &push_ext, bool &push_sh,
-                       float4 &ray_o, float4 &ray_d, float4 &ray_sd, unsigned long long &rays) {
+                       bool &requeue, float4 &ray_o, float4 &ray_d, float4 &ray_sd, unsigned long long &rays) {
     int lx, lrow;
     wf_pixel(a, w, (int)id, lx, lrow);
     const int gy = local_row_to_y(a, lrow);
@@ -1504,6 +1517,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     P.depth = (int)(meta & 0xFFu);
     // resolve the light sample of the previous bounce (:367, :539)
     P.Lx = s3.x; P.Ly = s3.y; P.Lz = s3.z;
+    if (meta & WF_RESOLVED) light_accepted = (meta & WF_ACCEPTED) != 0u;  // the verdict was carried over a deferral
     if (meta & WF_PENDING) {
         if (!light_accepted) {  // the traversal lane's verdict on the shadow ray (nee_accepted), one bit per path
             const float4 s4 = ld_stream(w.A(4, id));
@@ -1515,6 +1529,14 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     sh.has_shadow = false;
     if (!ended) {
         const float4 hh = *w.H(id);  // (plain load and store for the hit records: -1.6 % against the non-temporal forms, profiles/r02_ab_flags.txt)
+        if (hh.x == kHitSuspended) {
+            // the path's ray is parked in a traversal lane (see kSuspendMax): nothing to shade yet.  The path stays in the queue; the verdict
+            // of its shadow ray -- which did finish this trip, and whose bit is indexed by THIS trip's queue position -- moves into the state word
+            if ((meta & WF_PENDING) && !(meta & WF_RESOLVED))
+                st_stream(w.A(2, id), make_float4(s2.x, s2.y, s2.z, __uint_as_float(meta | WF_RESOLVED | (light_accepted ? WF_ACCEPTED : 0u))));
+            requeue = true;
+            return;
+        }
         Hit h;
         h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
         shade_hit(a, lds_mats, rng, P, h, sh);
@@ -1564,7 +1586,8 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 #endif
 constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes its queues); the host picks block_paths <= this so
                                    // that the launch has that many pixels for every resident workgroup
-constexpr size_t kWgQueueF4 = 8 * (size_t)kWgPathsMax + (size_t)kWgPathsMax / 2;  // float4 units per workgroup: ray records + path ids [2]
+constexpr size_t kWgSuspendAt = 8 * (size_t)kWgPathsMax + (size_t)kWgPathsMax / 2;  // float4 offset of the suspend area in a workgroup's slice
+constexpr size_t kWgQueueF4 = kWgSuspendAt + (size_t)kSuspendF4 * kBlockThreads;   // float4 units per workgroup: ray records + path ids [2] + suspend area
 #ifndef GLRTX_WGWF_WAVES
 #define GLRTX_WGWF_WAVES 4
 #endif
@@ -1591,9 +1614,11 @@ __device__ uint4 g_trip_log[16][64];
 // (consumed + r) through a cross-lane read.  (Fetching a ray when a lane fell idle -- queue index, then path state, two
 // dependent round trips -- cost 14 % of the phase.  A second chunk fetched ahead of need was kept in round 1; measured
 // again in round 2, after the kernel had lost its spills, it bought nothing and its 8 registers were freed; that A/B table was not kept.)
+DEV int wgwf_suspend_max();  // WfArgs::suspend_max of the running pt_render_wgwf launch, from its kernarg segment (defined below)
+
 template <bool VINE>
 DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, [[maybe_unused]] const float4 *lds_top, int *stack, const float4 *rq, int n_rays,
-                           unsigned *ray_head, unsigned *light_bits, unsigned long long &rays) {
+                           unsigned *ray_head, unsigned *light_bits, unsigned long long &rays, float4 *suspend_area) {
     const int lane = threadIdx.x & 63;
     if (VINE) {  // list scan: every ray takes the same number of steps, so waves simply take 64 rays at a time
         for (;;) {
@@ -1643,6 +1668,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
     };
     cur_cnt = fetch(cur_o, cur_d);
     bool exhausted = cur_cnt == 0;
+    const bool fetched_any = cur_cnt > 0;  // this wave has new rays to run next to the ones it resumes: parking rays again can pay
     bool active = false;
     // A finished ray's hit record is kept in registers and written when the lane is refilled
     // (or at the end of the phase): a store issued inside the stepping loop would sit in vmcnt
@@ -1655,6 +1681,26 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
 #ifdef GLRTX_STEP_TIMING
     StepTiming step_timing;
 #endif
+    float4 *const susp = suspend_area + (size_t)kSuspendF4 * threadIdx.x;
+    // Rays parked at the end of the previous trip go on in the lanes -- and on the LDS stacks -- they were in.  Whether a lane holds one is
+    // read back from its slot (one load per wave and trip; a flag kept in registers across the shade phase costs the kernel its
+    // spill-free allocation).
+    {
+        const float4 s3 = susp[3];
+        if (s3.z != 0.0f) {
+            const float4 s0 = susp[0], s1 = susp[1], s2 = susp[2];
+            susp[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+            T.ox = s0.x; T.oy = s0.y; T.oz = s0.z; rid = __float_as_uint(s0.w);
+            T.dx = s1.x; T.dy = s1.y; T.dz = s1.z; T.stop_d = s1.w;
+            T.ix = 1.0f / T.dx; T.iy = 1.0f / T.dy; T.iz = 1.0f / T.dz;  // :260, as at chunk time
+            T.h.t = s2.x; T.h.tri = __float_as_int(s2.y); T.h.u = s2.z; T.h.v = s2.w;
+            T.cur = __float_as_int(s3.x); T.sp = __float_as_int(s3.y);
+#ifdef GLRTX_TRAV_STATS
+            T.iters = 0;
+#endif
+            active = true;
+        }
+    }
     auto save_hit = [&]() {
         const unsigned id = rid >> 1;  // path id (path ray) or the path's position in the workgroup's path queue (shadow ray)
         if (rid & 1u) {  // the light test of :367, decided here (T.stop_d is the light sample's distance): one bit for the shade phase
@@ -1716,8 +1762,32 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         }
         // GLRTX_STEPS_PER_TRIP traversal steps per trip through the loop: cuts the refill bookkeeping (ballots, branches) on
         // the latency-critical instruction stream; a lane that finishes on the first step idles for one step
+        if (exhausted && fetched_any) {  // (wave-uniform) nothing left to refill with: park the last few path rays
+            const unsigned long long ma = __ballot(active);
+            const int suspend_max = wgwf_suspend_max();  // (read from the kernarg segment here: not a scalar register held across the loop)
+            if (__ballot(active && (rid & 1u) != 0u) == 0ull && (int)__popcll(ma) <= suspend_max) {
+                if (active) {
+                    susp[0] = make_float4(T.ox, T.oy, T.oz, __uint_as_float(rid));
+                    susp[1] = make_float4(T.dx, T.dy, T.dz, T.stop_d);
+                    susp[2] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
+                    susp[3] = make_float4(__int_as_float(T.cur), __int_as_float(T.sp), 1.0f, 0.f);  // .z: the slot holds a ray
+                    *w.H(rid >> 1) = make_float4(kHitSuspended, 0.f, 0.f, 0.f);  // the shade phase defers this path
+                    active = false;
+                }
+                break;
+            }
+        }
 #ifdef GLRTX_PHASE_STATS
         const unsigned long long sb0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef GLRTX_TRAV_STATS
+        {
+            const unsigned long long ma = __ballot(active);
+            if (lane == 0) {
+                atomicAdd(&g_trav_trips[0], 1ull); atomicAdd(&g_trav_trips[1], (unsigned long long)__popcll(ma));
+                if (exhausted) { atomicAdd(&g_trav_trips[2], 1ull); atomicAdd(&g_trav_trips[3], (unsigned long long)__popcll(ma)); }
+            }
+        }
 #endif
         if (active) {
 #if defined(GLRTX_TRAV_STATS) || GLRTX_LDS_TOP_MAX > 0 || defined(GLRTX_CXX_STEP)  // diagnostic / experiment builds: the C++ statement of the step
@@ -1764,13 +1834,13 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int j0 = 0; j0 < n_paths; j0 += kBlockThreads) {
         const int i = j0 + (int)threadIdx.x;
-        bool push_ext = false, push_sh = false;
+        bool push_ext = false, push_sh = false, requeue = false;
         unsigned id = WF_INVALID;
         float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro, rsd = ro;
         if (i < n_paths) id = pq[i];
         const bool light_accepted = i < n_paths && ((light_bits[i >> 5] >> (i & 31)) & 1u) != 0u;
-        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, cam, id, light_accepted, push_ext, push_sh, ro, rd, rsd, rays);
-        const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms;
+        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, cam, id, light_accepted, push_ext, push_sh, requeue, ro, rd, rsd, rays);
+        const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms | __ballot(requeue);
         unsigned br = 0, bp = 0;
         if (lane == 0) {
             if (mp) {
@@ -1791,7 +1861,7 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
             r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pos_next * 2u + 1u));  // shadow ray id: queue position, odd
             r[1] = rsd;
         }
-        if (push_ext || push_sh) pq_next[pos_next] = id;
+        if (push_ext || push_sh || requeue) pq_next[pos_next] = id;
     }
 }
 
@@ -1810,6 +1880,8 @@ DEV const WgwfKernArgs *wgwf_kernargs() {
     asm volatile("" : "+s"(p));  // opaque: loads through it stay behind this point
     return (const WgwfKernArgs *)p;
 }
+
+DEV int wgwf_suspend_max() { return wgwf_kernargs()->w.suspend_max; }
 
 template <bool COUNT_RAYS, bool VINE>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues) {
@@ -1846,6 +1918,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         g_trip_log[blockIdx.x / 64][0].y = (unsigned)(__builtin_amdgcn_s_memtime() >> 4);
 #endif
     if (threadIdx.x == 0) { ctl[2] = 0u; ctl[3] = 0u; ctl[4] = 0u; ctl[5] = 0u; ctl[7] = 0u; }
+    if (!VINE) rayQ[kWgSuspendAt + (size_t)kSuspendF4 * threadIdx.x + 3] = make_float4(0.f, 0.f, 0.f, 0.f);  // no lane holds a parked ray yet (wg_traverse_phase)
     int cur = 0;
     __syncthreads();  // materials staged, ctl initialised
     for (;;) {
@@ -1902,7 +1975,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
         // their loads get going earlier (measured 1-2 %)
         __builtin_amdgcn_s_setprio(3);
-        wg_traverse_phase<VINE>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], light_bits, rays);
+        wg_traverse_phase<VINE>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
         __builtin_amdgcn_s_setprio(0);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written

@@ -292,6 +292,30 @@ def test_forks_with_an_absent_child_match_the_oracle(gpu_device):
         d.set_variant(2)
 
 
+@pytest.mark.parametrize("suspend_max", [0, 8, 24, 64])
+def test_parked_rays_do_not_change_the_image(gpu_device, monkeypatch, suspend_max):
+    """At the end of a trip a wave parks its last few path rays instead of running them alone, and the shade phase defers their paths
+    (pt_kernel.hip.h: kSuspendMax).  Only the schedule changes: never (0), rarely, by default, and whenever the queue is empty (64) give
+    the oracle's image and ray count, one launch per frame and frames in flight, in both compilations."""
+    from oracle import pt_oracle
+    monkeypatch.setenv("GLRTX_SUSPEND_MAX", str(suspend_max))
+    d = gpu_device
+    scene, params = scenes.CONFIGS["headline"](width=320, height=180)
+    seeds = _seeds(3)
+    ref, ref_rays = None, 0
+    for sd in seeds:
+        ref, n = pt_oracle.render(scene, dict(params, seed=sd), accum=ref)
+        ref_rays += n
+    for count in (True, False):
+        acc, st = gpu_render(d, scene, params, frames=seeds, count_rays=count)
+        assert_bit_equal(acc, ref, f"suspend_max {suspend_max}, consecutive launches, counting {count}")
+        assert not count or st.rays == ref_rays
+        d.clear(); d.reset_stats(); d.count_rays(count)
+        d.render_frames(params, seeds); d.sync()
+        assert_bit_equal(d.read_accum(), ref, f"suspend_max {suspend_max}, frames in flight, counting {count}")
+        assert not count or d.stats().rays == ref_rays
+
+
 @pytest.mark.parametrize("n", [12, 40, 63])
 def test_deep_traversal_stacks_match_the_oracle(gpu_device, n):
     """A comb that stacks one entry per level (every fork = a leaf as children.x, the rest of the tree as children.y): the per-lane LDS

@@ -10,9 +10,12 @@ L = device.lib()
 for v in (2,):
     d.set_variant(v); d.reset_stats()
     out = (C.c_ulonglong * 8)(); L.glrtx_debug_trav_stats(out)
+    tr = (C.c_ulonglong * 4)(); L.glrtx_debug_trav_trips(tr)
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     d.render_frames(pr, [host.frame_seed(f) for f in range(B)]); d.sync()
     L.glrtx_debug_trav_stats(out); o = list(out); rays = d.stats().rays
+    L.glrtx_debug_trav_trips(tr); t = list(tr)
+    print(f"stepping trips {t[0]}: {t[1] / max(t[0], 1):.1f} lanes with a ray at their start; {100.0 * t[2] / max(t[0], 1):.1f} % of the trips after the workgroup's queue ran out (drain), {t[3] / max(t[2], 1):.1f} lanes at their start")
     hh = (C.c_ulonglong * 16)(); L.glrtx_debug_trav_hist(hh); print("iterations histogram (<=1,2,4,8,...):", list(hh))
     print(f"rays traced {sum(hh)} of {rays} reference rays ({100.0*sum(hh)/max(rays,1):.1f} %)")
     print(f"variant {v}: rays {rays} wave_iters {o[0]} lane_iters {o[1]} simd_eff {o[1]/(64*o[0]):.3f} fork_lane {o[2]} leaf_lane {o[3]} mixed_iters {o[4]/o[0]:.3f} iters/ray {o[1]/rays:.1f} forks/ray {o[2]/rays:.1f} leaves/ray {o[3]/rays:.1f} distinct records/wave-iter {o[5]/o[0]:.1f} distinct 128B lines/wave-iter {o[6]/o[0]:.1f} (active lanes/wave-iter {o[1]/o[0]:.1f}) path-ray share of lane iters {o[7]/o[1]:.3f}")
