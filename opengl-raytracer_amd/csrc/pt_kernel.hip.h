@@ -1708,6 +1708,9 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         } else *w.H(id) = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);  // plain store: scattered 16-byte writes merge in L2 now and then, non-temporal ones never do (-1.2 %)
         unsaved = false;
     };
+#ifdef GLRTX_PHASE_STATS
+    unsigned long long ph_refill = 0ull, ph_refills = 0ull, ph_step = 0ull;
+#endif
     for (;;) {
         unsigned long long idle = __ballot(!active);
         if ((int)__popcll(idle) >= w.refill_min || idle == ~0ull) {
@@ -1753,7 +1756,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
                 idle = __ballot(!active);
             }
 #ifdef GLRTX_PHASE_STATS
-            if (threadIdx.x == 0) { atomicAdd(&g_phase_cycles[5], __builtin_amdgcn_s_memtime() - rf0); atomicAdd(&g_phase_cycles[6], 1ull); }
+            ph_refill += __builtin_amdgcn_s_memtime() - rf0; ph_refills += 1ull;
 #endif
         }
         if (!__any(active)) {
@@ -1809,10 +1812,14 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
             }
         }
 #ifdef GLRTX_PHASE_STATS
-        if (threadIdx.x == 0) { atomicAdd(&g_phase_cycles[7], __builtin_amdgcn_s_memtime() - sb0); }
+        ph_step += __builtin_amdgcn_s_memtime() - sb0;
 #endif
     }
     if (unsaved) save_hit();
+#ifdef GLRTX_PHASE_STATS
+    // one set of atomics per phase: per-trip atomics on one address (0.4 M per frame) stretched the kernel threefold
+    if (threadIdx.x == 0) { atomicAdd(&g_phase_cycles[5], ph_refill); atomicAdd(&g_phase_cycles[6], ph_refills); atomicAdd(&g_phase_cycles[7], ph_step); }
+#endif
 #ifdef GLRTX_STEP_TIMING
     atomicAdd(&g_step_timing[0], (unsigned long long)step_timing.n);
     atomicAdd(&g_step_timing[1], (unsigned long long)step_timing.t);

@@ -6,9 +6,10 @@ device.lib_path = lambda: device.LIB_DIR / "libglrtx_phase.so"
 sc, pr = scenes.config_headline()
 d = device.Device(); d.upload_scene(sc); d.resize(1920, 1080)
 L = device.lib(); out = (C.c_uint * (16 * 64 * 4))()
-d.render(dict(pr, seed=host.frame_seed(0))); d.sync(); L.glrtx_debug_trip_log(out)
-d.render(dict(pr, seed=host.frame_seed(1))); d.sync(); L.glrtx_debug_trip_log(out)
-print("ms", d.stats().kernel_ms_last)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # frames per launch
+d.render_frames(pr, [host.frame_seed(f) for f in range(B)]); d.sync(); L.glrtx_debug_trip_log(out)
+d.render_frames(pr, [host.frame_seed(B + f) for f in range(B)]); d.sync(); L.glrtx_debug_trip_log(out)
+print("frames per launch", B, "kernel ms", d.stats().kernel_ms_last)
 lg = np.array(list(out), np.int64).reshape(16, 64, 4)
 st = lg[:, 0, 1] * 16; en = lg[:, 0, 2] * 16; base = st.min()
 for g in range(16): print(f"workgroup {g*64:4d}: start +{(st[g]-base)/2400:7.1f} us  end +{(en[g]-base)/2400:7.1f} us  trips {lg[g,0,0]}")
