@@ -1507,6 +1507,10 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     const int gy = local_row_to_y(a, lrow);
     const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
     const float4 s0 = ld_stream(w.A(0, id)), s1 = ld_stream(w.A(1, id)), s2 = ld_stream(w.A(2, id)), s3 = ld_stream(w.A(3, id));
+    // the hit record is fetched with the state, not behind the meta word the state delivers: one round trip less per round of the shade loop
+    // (-0.9 % per frame, profiles/r03_ab_shade_phase.txt; unused when the path has ended).  Plain load and store for the hit records:
+    // -1.6 % against the non-temporal forms, profiles/r02_ab_flags.txt
+    const float4 hh = *w.H(id);
     const float2 sd = wf_seed(a, w, (int)id);
     Rng rng = {s0.w, s1.w, sd.x, sd.y};
     const unsigned meta = __float_as_uint(s2.w);
@@ -1528,7 +1532,6 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     Shade sh;
     sh.has_shadow = false;
     if (!ended) {
-        const float4 hh = *w.H(id);  // (plain load and store for the hit records: -1.6 % against the non-temporal forms, profiles/r02_ab_flags.txt)
         if (hh.x == kHitSuspended) {
             // the path's ray is parked in a traversal lane (see kSuspendMax): nothing to shade yet.  The path stays in the queue; the verdict
             // of its shadow ray -- which did finish this trip, and whose bit is indexed by THIS trip's queue position -- moves into the state word
