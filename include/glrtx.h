@@ -169,7 +169,7 @@ int glrtx_set_variant(glrtx_ctx *ctx, int variant);
 int glrtx_count_rays(glrtx_ctx *ctx, int enable);
 
 /* Asynchronous: accumulates n_samples new samples per owned pixel.  Returns as soon as the launch is enqueued (up to 16 launches may be
- * outstanding per context).  Consecutive calls overlap on the device: the render kernel of a call runs on one of two internal streams with
+ * outstanding per context).  Consecutive calls overlap on the device: the render kernel of a call runs on one of six internal streams with
  * buffers of its own and hands its samples over in planes; only the pass that adds them to the accumulator runs on the context's stream
  * (glrtx_set_stream), in call order -- so everything a caller orders behind the call on that stream (resolve, read-back, a collective on the
  * rows) sees the finished accumulator, and per pixel the additions happen in the order of the calls. */

@@ -31,7 +31,7 @@ constexpr int kStripeQuantum = 8;   // stripe heights are multiples of the 8x8 w
 constexpr int kGroupStripe = 8;     // stripe height glrtx_group uses: 1080 rows over 8 members = 136 / 128 rows (16-row stripes: 144 / 128)
 constexpr int kFramesBudgetGiB = 32;  // device memory one glrtx_render_frames launch may use for path state and sample planes
 constexpr float kInf = std::numeric_limits<float>::infinity();
-constexpr unsigned kPipeSlots = 4;    // single-frame launches that may render side by side (each with its own stream, state, queues, planes)
+constexpr unsigned kPipeSlots = 8;    // most single-frame launches that may be in flight at once (each with its own stream, state, queues, planes); pipe_slots are used
 constexpr unsigned kLaunchRing = 16;  // launches that may be outstanding per context before a new one waits for the oldest
 
 thread_local std::string g_create_error;
@@ -77,7 +77,8 @@ struct glrtx_ctx {
     } pipe[kPipeSlots];
     unsigned pipe_next = 0;
     bool pipeline = true;           // GLRTX_NO_PIPELINE=1 switches it off (A/B)
-    int pipe_share = 2;             // an overlapped launch issued while others still render takes 1 / pipe_share of the workgroup slots (GLRTX_PIPE_SHARE; 1: all)
+    int pipe_share = 1;             // an overlapped launch issued while others still render takes 1 / pipe_share of the workgroup slots (GLRTX_PIPE_SHARE; 1: all)
+    unsigned pipe_slots = 6;        // slots used in turn (GLRTX_PIPE_SLOTS, <= kPipeSlots)
     DevBuf bvhVert, bvhTri, bvhNodes;  // glrtx_build_lbvh staging
     lbvh::Workspace bvhWs;
     int variant = 2;          // 0 = tile megakernel, 1 = persistent megakernel with path regeneration, 2 = workgroup-local wavefront
@@ -504,7 +505,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // Per pixel the additions happen in the same order (the plane-accumulation passes run on the context's stream, in launch order).
     const size_t plane_bytes = (size_t)a.pitch_f4 * (size_t)c->owned_rows * sizeof(float4);
     const bool piped = n_frames == 1 && c->pipeline && p->n_samples >= 1 && (size_t)p->n_samples * plane_bytes <= ((size_t)1 << 30);
-    glrtx_ctx::PipeSlot *slot = piped ? &c->pipe[c->pipe_next++ % kPipeSlots] : nullptr;
+    glrtx_ctx::PipeSlot *slot = piped ? &c->pipe[c->pipe_next++ % c->pipe_slots] : nullptr;
     DevBuf &stateBuf = slot ? slot->state : c->wfState;
     DevBuf &queueBuf = slot ? slot->queues : c->wfQ;
     DevBuf &planeBuf = slot ? slot->planes : c->wfPlanes;
@@ -556,9 +557,12 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockThreads, lds));
     if (per_cu < 1) per_cu = 1;
     if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));  // occupancy experiments
-    // An overlapped single-frame launch issued while earlier ones are still rendering takes a FRACTION (half) of the CUs' workgroup slots, so
-    // that launches are resident side by side -- one in its early, dense trips, the other in its late, sparse ones -- instead of the second
-    // waiting for the first to drain (all workgroups of a launch finish together by design).  A launch that finds the device idle takes all.
+    // Overlapped single-frame launches hand the CUs' workgroup slots over PROGRESSIVELY: every launch has the full grid and takes its tiles
+    // without guided self-scheduling (gss_div = 0), so its workgroups do not finish together -- one that finds the tile counter exhausted and
+    // its paths dead leaves, and a workgroup of the next launch (queued on another stream) takes the slot.  The device then holds the sparse
+    // late trips of one frame, the dense early trips of the next and the start of a third side by side: one launch per frame 1.49 -> 1.39 ms
+    // against the earlier scheme (GLRTX_PIPE_SHARE=2: a launch that finds another one rendering takes half of the slots, and all its
+    // workgroups finish together), profiles/r03_ab_pipeline.txt.
     int share = 1;
     if (slot && c->pipe_share > 1) {
         int busy = 0;
@@ -572,10 +576,14 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const size_t work = total * (size_t)n_frames;
     int block_paths = kWgPathsMax;
     while (block_paths > 256 && work < (size_t)resident * block_paths) block_paths /= 2;
+    // ... an overlapped single-frame launch: the frame in ONE helping per workgroup, spread over all the slots (the smallest power of two that
+    // holds work / resident paths: 2048 at 1080p; with 1024 the workgroups come back for a second helping, 1.31 instead of 1.24 ms per frame,
+    // with 4096 half of them get nothing, 1.67)
+    if (slot) { block_paths = 256; while (block_paths < kWgPathsMax && (size_t)resident * block_paths < work) block_paths *= 2; }
     if (const char *v = std::getenv("GLRTX_BLOCK_PATHS")) { const int x = std::atoi(v); if (x >= 256 && x <= kWgPathsMax && (x & (x - 1)) == 0) block_paths = x; }
     w.block_paths = block_paths;
     const int grid = std::max(1, (int)std::min<size_t>((size_t)resident, (work + block_paths - 1) / block_paths));
-    w.gss_div = 4 * grid;
+    w.gss_div = slot ? 0 : 4 * grid;  // (overlapped single-frame launches: no guided self-scheduling, see `share` above)
     if (const char *v = std::getenv("GLRTX_GSS_DIV")) w.gss_div = std::max(0, std::atoi(v));
     w.suspend_max = kSuspendMax;
     if (const char *v = std::getenv("GLRTX_SUSPEND_MAX")) w.suspend_max = std::max(0, std::min(64, std::atoi(v)));
@@ -685,6 +693,7 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
         }
     c->pipeline = std::getenv("GLRTX_NO_PIPELINE") == nullptr;
     if (const char *v = std::getenv("GLRTX_PIPE_SHARE")) c->pipe_share = std::max(1, std::min(4, std::atoi(v)));
+    if (const char *v = std::getenv("GLRTX_PIPE_SLOTS")) c->pipe_slots = (unsigned)std::max(1, std::min((int)kPipeSlots, std::atoi(v)));
     c->n_cu = prop.multiProcessorCount;
     if (const char *v = std::getenv("GLRTX_VARIANT")) { const int x = std::atoi(v); if (x >= 0 && x <= 2) c->variant = x; }
     *out = c;
