@@ -67,7 +67,7 @@ struct glrtx_ctx {
     int n_spheres = 0, ext_flags = 0;
     DevBuf wfState, wfQ;      // wavefront path state (kWfStatePlanes = 6 planes of float4 x ids) + per-workgroup queues (variant 2)
     DevBuf wfSeeds, wfPlanes;       // frames in flight: per-frame seeds, per-sample planes
-    // Single-frame launches that overlap (launch_wgwf): kPipeSlots slots used in turn, each with its own stream, path state, queues, tile
+    // Single-frame launches that overlap (launch_wgwf): pipe_slots (<= kPipeSlots) slots used in turn, each with its own stream, path state, queues, tile
     // counter and sample planes; the accumulator is only touched by the plane-accumulation pass, on the context's stream, in launch order.
     struct PipeSlot {
         hipStream_t stream = nullptr;
@@ -499,7 +499,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     if (2 * ids + 1 >= (size_t)UINT32_MAX)
         return fail(c, GLRTX_EINVAL, "glrtx_render_frames: %d frames of %zu pixels exceed the 32-bit ray id space", n_frames, total);
     int rc;
-    // A single-frame launch runs on one of two side streams with buffers of its own and hands its samples over in planes, so that the
+    // A single-frame launch runs on one of pipe_slots side streams with buffers of its own and hands its samples over in planes, so that the
     // tail of one launch overlaps the head of the next (a persistent grid that holds a whole frame fills and drains slowly): what a
     // caller that renders, resolves and saves every frame -- the reference's loop, window.cpp:121-169 -- gets without batching frames.
     // Per pixel the additions happen in the same order (the plane-accumulation passes run on the context's stream, in launch order).
