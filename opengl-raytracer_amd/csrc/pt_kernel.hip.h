@@ -1591,6 +1591,10 @@ constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes 
                                    // that the launch has that many pixels for every resident workgroup
 constexpr size_t kWgSuspendAt = 8 * (size_t)kWgPathsMax + (size_t)kWgPathsMax / 2;  // float4 offset of the suspend area in a workgroup's slice
 constexpr size_t kWgQueueF4 = kWgSuspendAt + (size_t)kSuspendF4 * kBlockThreads;   // float4 units per workgroup: ray records + path ids [2] + suspend area
+#ifndef GLRTX_PRIO_TRAVERSE
+#define GLRTX_PRIO_TRAVERSE 3  // s_setprio of a wave in the traverse phase / in the rest of the trip (shade, top-up)
+#define GLRTX_PRIO_SHADE 0
+#endif
 #ifndef GLRTX_WGWF_WAVES
 #define GLRTX_WGWF_WAVES 4
 #endif
@@ -1984,9 +1988,9 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         PH_STAMP(pt0);
         // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
         // their loads get going earlier (measured 1-2 %)
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(GLRTX_PRIO_TRAVERSE);
         wg_traverse_phase<VINE>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(GLRTX_PRIO_SHADE);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written
         PH_STAMP(pt2);

@@ -690,6 +690,24 @@ def test_render_calls_return_before_the_device_is_done(gpu_device):
     assert st.kernel_launches == 40 and st.kernel_ms_total > 0.02
 
 
+@BOTH_INSTANTIATIONS
+@pytest.mark.parametrize("cfg,kw", [("c2", dict(width=320, height=200, max_depth=8, n_samples=1)), ("c2", dict(width=97, height=61, max_depth=5, n_samples=3)),
+                                    ("c5", dict(width=256, height=144, max_depth=4, n_samples=1, n=4000))])
+def test_many_overlapped_single_frame_launches_equal_one_launch_of_all_frames(gpu_device, cfg, kw, count_rays):
+    """26 back-to-back glrtx_render calls -- the internal slots (stream, path state, queues, planes, tile counter each) come round four times,
+    every launch with the full grid and without guided self-scheduling, workgroups of up to six frames resident side by side -- against the
+    same 26 frames as one glrtx_render_frames launch (itself pinned to the oracle above): accumulator and ray count, bitwise."""
+    d = gpu_device
+    scene, params = scenes.CONFIGS[cfg](**kw)
+    seeds = _seeds(26, start=3)
+    seq, st_seq = gpu_render(d, scene, params, frames=seeds, count_rays=count_rays)
+    assert st_seq.launches == 26 and st_seq.kernel_launches == 26
+    d.clear(); d.reset_stats()
+    d.render_frames(params, seeds); d.sync()
+    assert_bit_equal(seq, d.read_accum(), f"{cfg} {kw}: 26 overlapped launches vs one launch of 26 frames")
+    assert d.stats().rays == st_seq.rays and (st_seq.rays > 0) == count_rays
+
+
 def _closed_box(width, height, max_depth, n_samples):
     """A closed room of albedo-0.98 walls with a small lamp: paths end almost only through Russian roulette (survival 0.95 per
     bounce beyond depth 2), so path lengths have a long tail."""

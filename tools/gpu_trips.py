@@ -19,6 +19,10 @@ for g in (0, 5, 11):
     for t in range(1, n + 1):
         r, p, ct, cs = lg[g, t]
         print(f"  trip {t:2d}: rays {r:5d} paths {p:5d}  traverse {ct:8d} cyc ({ct/max(r,1):7.1f}/ray)  shade {cs:7d} cyc")
+print("first trips of the launch, all sampled workgroups: traverse cycles per ray (rays) | shade cycles per path")
+for g in range(16):
+    n = lg[g, 0, 0]
+    print(f"  wg {g*64:4d}: " + "  ".join(f"{lg[g,t,2]/max(lg[g,t,0],1):6.0f} ({lg[g,t,0]:4d}) | {lg[g,t,3]/max(lg[g,t,1],1):4.0f}" for t in range(1, min(n, 8) + 1)))
 tot = lg[:, 1:, :].reshape(-1, 4)
 tot = tot[tot[:, 1] > 0]
 print("all sampled: trips", len(tot), "traverse cycles", tot[:,2].sum(), "shade", tot[:,3].sum())
