@@ -83,6 +83,23 @@
 #define GLRTX_X_VALU
 #endif
 
+// The four loads of a record return in order, a gather instruction apart (~17-25 clk each on a busy CU): the slab arithmetic of each
+// 16-byte piece starts as soon as that piece is in -- left lo, left hi, right lo, right hi -- instead of behind the last one
+// (-1.1 % per frame with two stages; GLRTX_SINGLE_WAIT restores the single s_waitcnt vmcnt(0) for A/B runs).
+#if defined(GLRTX_EXPERIMENT_EXTRA_LOADS) || defined(GLRTX_STEP_TIMING)  // (more loads in flight / the tool measures the whole wait)
+#define GLRTX_SINGLE_WAIT
+#endif
+#ifndef GLRTX_SINGLE_WAIT
+#define GLRTX_W3 "s_waitcnt vmcnt(3)\n\t"
+#define GLRTX_W2 "s_waitcnt vmcnt(2)\n\t"
+#define GLRTX_W1 "s_waitcnt vmcnt(1)\n\t"
+#define GLRTX_W0 "s_waitcnt vmcnt(0)\n\t"
+#else
+#define GLRTX_W3 "s_waitcnt vmcnt(0)\n\t"
+#define GLRTX_W2
+#define GLRTX_W1
+#define GLRTX_W0
+#endif
 #define GLRTX_TRAV_STEP_ASM \
     GLRTX_TS_BEGIN \
     "v_lshl_add_u32 v[GLRTX_VB+15], %[cur], 6, %[bias]\n\t"                                                                                                      \
@@ -93,19 +110,20 @@
     GLRTX_X_LOADS                                                                                      \
     "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t"                           /* lanes at a triangle */                                                      \
     "s_andn2_b64 exec, exec, %[leaf]\n\t"                               /* ---- fork arm: exec = lanes at a fork (may be none) */                      \
-    GLRTX_TS_WAIT0 "s_waitcnt vmcnt(0)\n\t" GLRTX_TS_WAIT1 GLRTX_X_VALU                                                                                                                           \
-    "v_sub_f32 v[GLRTX_VB+4], v[GLRTX_VB+4], %[ox]\n\t"                                   /* left child: (hi - o), (lo - o) in place */                                  \
-    "v_sub_f32 v[GLRTX_VB+5], v[GLRTX_VB+5], %[oy]\n\t"                                                                                                                  \
-    "v_sub_f32 v[GLRTX_VB+6], v[GLRTX_VB+6], %[oz]\n\t"                                                                                                                  \
-    "v_sub_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ox]\n\t"                                                                                                                    \
-    "v_sub_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[oy]\n\t"                                                                                                                    \
-    "v_sub_f32 v[GLRTX_VB+2], v[GLRTX_VB+2], %[oz]\n\t"                                                                                                                    \
-    "v_mul_f32 v[GLRTX_VB+4], v[GLRTX_VB+4], %[ix]\n\t"                                   /* f = (hi - o) / d, n = (lo - o) / d */                                       \
-    "v_mul_f32 v[GLRTX_VB+5], v[GLRTX_VB+5], %[iy]\n\t"                                                                                                                  \
-    "v_mul_f32 v[GLRTX_VB+6], v[GLRTX_VB+6], %[iz]\n\t"                                                                                                                  \
-    "v_mul_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ix]\n\t"                                                                                                                    \
-    "v_mul_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[iy]\n\t"                                                                                                                    \
-    "v_mul_f32 v[GLRTX_VB+2], v[GLRTX_VB+2], %[iz]\n\t"                                                                                                                    \
+    GLRTX_TS_WAIT0 GLRTX_W3 GLRTX_TS_WAIT1 GLRTX_X_VALU                                                                                                    \
+    "v_sub_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ox]\n\t"   /* left child: (lo - o) / d as soon as the first load is in, (hi - o) / d after the second */    \
+    "v_sub_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[oy]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+2], v[GLRTX_VB+2], %[oz]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ix]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[iy]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+2], v[GLRTX_VB+2], %[iz]\n\t"                                                            \
+    GLRTX_W2                                                                                                                        \
+    "v_sub_f32 v[GLRTX_VB+4], v[GLRTX_VB+4], %[ox]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+5], v[GLRTX_VB+5], %[oy]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+6], v[GLRTX_VB+6], %[oz]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+4], v[GLRTX_VB+4], %[ix]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+5], v[GLRTX_VB+5], %[iy]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+6], v[GLRTX_VB+6], %[iz]\n\t"                                                            \
     "v_max_f32 v[GLRTX_VB+16], v[GLRTX_VB+4], v[GLRTX_VB+0]\n\t"                                                                                                                    \
     "v_min_f32 v[GLRTX_VB+0], v[GLRTX_VB+4], v[GLRTX_VB+0]\n\t"                                                                                                                     \
     "v_max_f32 v[GLRTX_VB+17], v[GLRTX_VB+5], v[GLRTX_VB+1]\n\t"                                                                                                                    \
@@ -116,18 +134,20 @@
     "v_max3_f32 v[GLRTX_VB+2], v[GLRTX_VB+0], v[GLRTX_VB+1], v[GLRTX_VB+4]\n\t"                                /* t0 of the left child, next to its ref: v[GLRTX_VB+2:GLRTX_VB+3] = {t0, ref} */              \
     "v_min_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], %[th]\n\t"                                                                                                                  \
     "v_cmp_ge_f32_e64 %[bl], v[GLRTX_VB+16], v[GLRTX_VB+2]\n\t"                             /* min(t1, tHit) >= t0 */                                                      \
-    "v_sub_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], %[ox]\n\t"                                   /* right child: lo v[GLRTX_VB+8]..106, hi v[GLRTX_VB+12]..110 */                                  \
-    "v_sub_f32 v[GLRTX_VB+13], v[GLRTX_VB+13], %[oy]\n\t"                                                                                                                  \
-    "v_sub_f32 v[GLRTX_VB+14], v[GLRTX_VB+14], %[oz]\n\t"                                                                                                                  \
-    "v_sub_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], %[ox]\n\t"                                                                                                                  \
-    "v_sub_f32 v[GLRTX_VB+9], v[GLRTX_VB+9], %[oy]\n\t"                                                                                                                  \
-    "v_sub_f32 v[GLRTX_VB+10], v[GLRTX_VB+10], %[oz]\n\t"                                                                                                                  \
-    "v_mul_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], %[ix]\n\t"                                                                                                                  \
-    "v_mul_f32 v[GLRTX_VB+13], v[GLRTX_VB+13], %[iy]\n\t"                                                                                                                  \
-    "v_mul_f32 v[GLRTX_VB+14], v[GLRTX_VB+14], %[iz]\n\t"                                                                                                                  \
-    "v_mul_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], %[ix]\n\t"                                                                                                                  \
-    "v_mul_f32 v[GLRTX_VB+9], v[GLRTX_VB+9], %[iy]\n\t"                                                                                                                  \
-    "v_mul_f32 v[GLRTX_VB+10], v[GLRTX_VB+10], %[iz]\n\t"                                                                                                                  \
+    GLRTX_W1                                                                                                                        \
+    "v_sub_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], %[ox]\n\t"   /* right child: lo v[GLRTX_VB+8..10] (third load), hi v[GLRTX_VB+12..14] (fourth) */    \
+    "v_sub_f32 v[GLRTX_VB+9], v[GLRTX_VB+9], %[oy]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+10], v[GLRTX_VB+10], %[oz]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], %[ix]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+9], v[GLRTX_VB+9], %[iy]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+10], v[GLRTX_VB+10], %[iz]\n\t"                                                            \
+    GLRTX_W0                                                                                                                        \
+    "v_sub_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], %[ox]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+13], v[GLRTX_VB+13], %[oy]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+14], v[GLRTX_VB+14], %[oz]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], %[ix]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+13], v[GLRTX_VB+13], %[iy]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+14], v[GLRTX_VB+14], %[iz]\n\t"                                                            \
     "v_max_f32 v[GLRTX_VB+16], v[GLRTX_VB+12], v[GLRTX_VB+8]\n\t"                                                                                                                   \
     "v_min_f32 v[GLRTX_VB+8], v[GLRTX_VB+12], v[GLRTX_VB+8]\n\t"                                                                                                                   \
     "v_max_f32 v[GLRTX_VB+17], v[GLRTX_VB+13], v[GLRTX_VB+9]\n\t"                                                                                                                   \
