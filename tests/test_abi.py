@@ -57,7 +57,8 @@ def test_struct_layouts_match_header():
 def test_code_object_invariants():
     """tools/isa_report.py --check on the built libglrtx.so: the render kernels spill nothing, no instruction touches the
     destination of trav_scan's s_load_dwordx16 between the load and its s_waitcnt (the load and the wait are separate asm statements),
-    and the hand-written pop loop of trav_step keeps its sentinel and the ref it overwrites in different registers."""
+    the hand-written pop loop of trav_step keeps its sentinel and the ref it overwrites in different registers, and behind every node fetch of
+    the hand-written step the waits come one load at a time (vmcnt(3) .. vmcnt(0)) with no other vector-memory instruction in between."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_report.py"), "--check"], capture_output=True, text=True, timeout=300)

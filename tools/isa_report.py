@@ -149,6 +149,50 @@ def check_pop_loop(co: pathlib.Path, ks) -> list:
     return problems
 
 
+def check_staged_waits(co: pathlib.Path, ks) -> list:
+    """The hand-written traversal step of the wavefront kernel: behind every node fetch (two dwordx4 + two dwordx3 loads) the waits come one
+    load at a time -- s_waitcnt vmcnt(3), (2), (1), (0), in that order, with no other vector-memory instruction in between (a load or store
+    slipped into the sequence would make the counts wait for the wrong thing)."""
+    problems = []
+    dis = subprocess.run([str(LLVM / "llvm-objdump"), "-d", "--no-show-raw-insn", str(co)], check=True, capture_output=True, text=True).stdout
+    body, name = {}, None
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+        if m:
+            name = m.group(1)
+            body[name] = []
+        elif name and ln.strip():
+            body[name].append(ln.split("//")[0].strip())
+    for k in ks:
+        if "pt_render_wgwf" not in k["pretty"] or k["pretty"].rstrip(">").endswith("true"):
+            continue  # (list-scan instantiations have no stepping block)
+        ins = body.get(k["name"], [])
+        fetches = 0
+        for i, s in enumerate(ins):
+            if not (s.startswith("global_load_dwordx3") and i >= 3 and ins[i - 1].startswith("global_load_dwordx3") and
+                    ins[i - 2].startswith("global_load_dwordx4") and ins[i - 3].startswith("global_load_dwordx4")):
+                continue
+            fetches += 1
+            want = 3
+            for t in ins[i + 1:i + 80]:
+                if t.startswith(("global_", "buffer_", "flat_", "scratch_")):
+                    problems.append(f"{k['pretty']}: `{t}` inside the staged waits of the node fetch at instruction {i}")
+                    break
+                m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+                if m:
+                    if int(m.group(1)) != want:
+                        problems.append(f"{k['pretty']}: node fetch at instruction {i}: expected s_waitcnt vmcnt({want}), found `{t}`")
+                        break
+                    want -= 1
+                    if want < 0:
+                        break
+            else:
+                problems.append(f"{k['pretty']}: node fetch at instruction {i}: the staged waits are incomplete")
+        if fetches == 0:
+            problems.append(f"{k['pretty']}: no node fetch (2 x dwordx4 + 2 x dwordx3) found")
+    return problems
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=str(LIB))
@@ -163,7 +207,7 @@ def main():
         if a.out:
             pathlib.Path(a.out).write_text("llvm-readelf --notes of the gfx950 code object in libglrtx.so (tools/isa_report.py)\n\n" + t + "\n")
         if a.check:
-            bad = check_scalar_prefetch(co, ks) + check_pop_loop(co, ks)
+            bad = check_scalar_prefetch(co, ks) + check_pop_loop(co, ks) + check_staged_waits(co, ks)
             for b in bad:
                 print("ISA CHECK FAILED:", b)
             sys.exit(1 if bad else 0)
