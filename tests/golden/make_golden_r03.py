@@ -7,6 +7,8 @@ a fixture is inputs and outputs only) on scenes that exercise what round 3 chang
   one_child_forks   forks that leave out children.x or children.y (raytrace.frag:299-307): the never-hit record, the stack budget
   c2_small_3frames  the headline scene at 128x64, 8 bounces, three accumulated frames: leaf pairs (two chained triangle records per fork with
                     two leaf children), parked rays, overlapped single-frame launches
+  tris2000_lbvh     2000 random triangles under the linear BVH (deep, unbalanced: BASELINE config 5's kind of tree)
+  c4_small_spp4     BASELINE config 4's scene at subdivision 2, four samples per pixel in one pass
 
 Run in the build container only:  make -C oracle && make -C opengl-raytracer_amd host && python tests/golden/make_golden_r03.py
 """
@@ -69,3 +71,12 @@ save("one_child_forks", dict(scene, bvh=np.concatenate([nodes, np.array(extra, n
 # uv = fragCoord / windowSize, which lands exactly on texel centres only then -- SURVEY.md F7; at 160x90 its own frames bleed by an ulp)
 scene, params = scenes.config_headline(width=128, height=64)
 save("c2_small_3frames", scene, params, frames=[host.frame_seed(f) for f in range(3)])
+
+# 2000 random triangles under the linear BVH (the CPU statement of the device builder: Morton order, rotations, small subtrees rebuilt) --
+# BASELINE config 5's kind of tree, deep and unbalanced, many leaf pairs
+scene, params = scenes._random_tri_scene(2000, 20260104, 1.6, 6.0, 96, 64, 4, 1, "lbvh")
+save("tris2000_lbvh", scene, dict(params, seed=host.frame_seed(7)))
+
+# BASELINE config 4's scene (eight spheres on a ground quad under a lamp, no box) at subdivision 2, 4 samples per pixel in one pass, 8 bounces
+scene, params = scenes.config_c4(width=96, height=54, n_samples=4, subdiv=2)
+save("c4_small_spp4", scene, dict(params, seed=host.frame_seed(11)))
