@@ -149,6 +149,7 @@ class GpuRenderer:
         self.params = params
         self.dev.upload_scene(self.scene)
         self.dev.set_partition(rank, world, STRIPE)
+        self._part = (rank, world)
         self.dev.resize(W, H)
         pad_rows = dist.max_owned_rows(world, STRIPE, H)
         # the accumulator lives in a torch tensor so that RCCL can gather it; the kernel writes it in place
@@ -205,6 +206,27 @@ class GpuRenderer:
         finally:
             self.dev.set_partition(0, 1, STRIPE)
         return sorted(ms[1:])[len(ms[1:]) // 2]
+
+    def render_full_reference(self, f0, n, seed_of, per_launch=16):
+        """Frames [f0, f0 + n) rendered by THIS GPU alone as a one-rank partition into a fresh full-size accumulator (untimed; what the gathered image of
+        an N-rank run of the same frames must equal bit for bit).  Leaves partition and accumulator binding as they were."""
+        torch = self.torch
+        W, H = self.params["width"], self.params["height"]
+        rank, world = self._part
+        full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        self.dev.sync()
+        self.dev.bind_accum(0, 0, 0)
+        try:
+            self.dev.set_partition(0, 1, STRIPE)
+            self.dev.bind_accum(full.data_ptr(), W * 16, H)
+            for a, k in launch_plan(n, per_launch):
+                self.render_frames(f0 + a, k, seed_of)
+            self.dev.sync()
+        finally:
+            self.dev.bind_accum(0, 0, 0)
+            self.dev.set_partition(rank, world, STRIPE)
+            self.dev.bind_accum(self.accum.data_ptr(), W * 16, self.accum.shape[0])
+        return full
 
     def resolve_ms(self):
         """Device time of one resolve pass over the owned rows (screen.frag), ms."""
@@ -375,6 +397,39 @@ def main(argv=None):
             strong_err = f"{type(e).__name__}: {e}"
             strong_s = None
 
+    # ---- self-check of what the collective delivered (N > 1, untimed): min(K, 4) of the timed steps are rendered again by all ranks into cleared
+    # accumulators and gathered over the same collective path -- once as the weak region issues them, once as the strong region does -- and rank 0
+    # compares each gathered image, bit for bit, with the same frames rendered by its own GPU alone as a one-rank partition.  (The timed regions drop
+    # their images; without this the first multi-GPU run would time a gather nobody looked at.)
+    gather_check, strong_check = None, None
+    if world > 1 and gatherer is not None and not args.no_gather:
+        def pixels_differing(img, ref):
+            return int((img.contiguous().view(torch.int32) != ref.contiguous().view(torch.int32)).any(dim=-1).sum().item())
+        try:
+            nchk = min(args.steps, 4)
+            f_lo, f_n = args.warmup * world, nchk * world
+            R.sync()
+            R.accum.zero_()
+            R.reset_stats()
+            img_w = run(args.warmup, nchk)
+            barrier()
+            img_w = img_w.clone() if img_w is not None else None
+            R.accum.zero_()
+            R.reset_stats()
+            img_s = run_strong(f_lo, f_n) if strong_err is None else None
+            barrier()
+            if rank == 0:
+                ref = R.render_full_reference(f_lo, f_n, seed)
+                d = pixels_differing(img_w, ref)
+                gather_check = "bit-identical" if d == 0 else f"{d} of {W * H} pixels differ"
+                if img_s is not None:
+                    d = pixels_differing(img_s, ref)
+                    strong_check = "bit-identical" if d == 0 else f"{d} of {W * H} pixels differ"
+                del ref
+            barrier()
+        except Exception as e:  # reported, never fatal to the contract line
+            gather_check = f"error: {type(e).__name__}: {e}"
+
     # ---- what rank 0's share of an N-rank weak step costs on this GPU, N = 2, 4, 8 (N = 1 runs on a GPU only)
     predicted, resolve_ms = None, None
     try:
@@ -521,11 +576,15 @@ def main(argv=None):
                        "mrays_per_s_reference_equivalent": round(ref_rays / elapsed_s / 1e6, 3),
                        "mpaths_per_s": round(W * H * params["n_samples"] * n_frames / elapsed_s / 1e6, 3),
                        "event_ms_per_step": round(ev_ms / args.steps, 4),
+                       # N > 1: the image RCCL gathered for min(K, 4) of the timed steps against the same frames rendered by rank 0's GPU alone
+                       "gather_check": gather_check if world > 1 else None,
+                       "gather_check_what": None if world == 1 else f"frames [{args.warmup * world}, {(args.warmup + min(args.steps, 4)) * world}) re-rendered untimed by all ranks, gathered to "
+                                                                      "rank 0 over the timed region's collective path, compared bit for bit with a one-rank render of the same frames on rank 0's GPU",
                        "timed_kernel_image_check": f"bit-identical to the counting kernel's accumulator over the {args.steps} timed steps (untimed replay)",
                        # strong scaling: the same K frames whatever N is, S frames in flight IN TOTAL per launch, framebuffer gathered after every launch
                        "strong": ({"error": strong_err} if strong_err else None) if strong_s is None else
                            {"frames": args.steps, "frames_in_flight_total": S, "gather": "none" if args.no_gather else "to rank 0 after every launch, overlapped with the next launch",
-                            "ms_per_frame": round(strong_s / args.steps * 1e3, 4),
+                            "ms_per_frame": round(strong_s / args.steps * 1e3, 4), "gather_check": strong_check,
                             "value": round(traced_rays / world / strong_s / 1e6, 3), "unit": "Mrays/s",
                             "note": "rays of K frames / elapsed; compare with the N = 1 line's value for strong-scaling efficiency"},
                        # N = 1: rank 0's share of an N-rank weak step on this GPU (kernel + plane accumulation, no gather, RCCL not involved)

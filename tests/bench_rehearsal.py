@@ -55,6 +55,14 @@ class OracleRenderer:
         self.st.kernel_launches += 1
         self.st.kernel_ms_total += (time.perf_counter() - t) * 1e3
 
+    def render_full_reference(self, f0, n, seed_of, per_launch=16):
+        import torch
+        W, H = self.params["width"], self.params["height"]
+        full = np.zeros((H, W, 4), np.float32)
+        for f in range(f0, f0 + n):
+            self.o.render(self.scene, dict(self.params, seed=seed_of(f)), accum=full, threads=1)
+        return torch.from_numpy(full)
+
     def device_sync(self):
         pass
 
@@ -111,4 +119,13 @@ if __name__ == "__main__":
                 np.save(os.path.join(OUT, "gathered.npy"), img.numpy())
             return img
         dist.RowGather.finish = keep_finish
+    if os.environ.get("GLRT_REHEARSAL_CORRUPT_GATHER"):  # negative case: a collective that delivers one wrong value must show up in config.gather_check
+        clean = dist.RowGather.gather_to_root
+
+        def corrupt(self, local, dst=0):
+            img = clean(self, local, dst)
+            if img is not None:
+                img[3, 5, 1] += 1.0
+            return img
+        dist.RowGather.gather_to_root = corrupt
     bench.main()

@@ -85,18 +85,38 @@ def test_bench_self_spawns_its_ranks_and_gathers_to_root(tmp_path):
     # (one warm launch, then `steps` FRAMES in launches of `spl` frames in total) cover these frames, in this order, on every rank
     timed = list(range(warm * 2, (warm + steps) * 2))
     strong_frames = list(range(0, min(spl, steps))) + list(range(warm * 2, warm * 2 + steps))
-    want = timed + timed + list(range(0, warm * 2)) + timed + strong_frames
+    # ... and the untimed self-check of the collective: min(steps, 4) of the timed steps once more through the weak region's gather and once
+    # through the strong region's, each from cleared accumulators (rank 0's one-rank reference render is not a rank's share and is not logged)
+    check = list(range(warm * 2, (warm + min(steps, 4)) * 2))
+    want = timed + timed + list(range(0, warm * 2)) + timed + strong_frames + check + check
+    assert out["config"]["gather_check"] == "bit-identical", out["config"]["gather_check"]
+    assert strong["gather_check"] == "bit-identical"
     for k in range(2):
         assert np.load(tmp_path / f"frames_rank{k}.npy").tolist() == want
-    # image: everything after the last clear -- warm-up, timed and strong-region frames -- accumulated from zero, gathered to rank 0
+    # image: everything after the last clear -- the self-check's frames through the strong region's gather -- accumulated from zero, gathered to rank 0
     from glrt_amd import host
     from tests.bench_rehearsal import small_config
     sc, pr = small_config()
     ref = np.zeros((pr["height"], pr["width"], 4), np.float32)
-    for f in list(range(0, warm * 2)) + timed + strong_frames:
+    for f in check:
         pt_oracle.render(sc, dict(pr, seed=host.frame_seed(f)), accum=ref, threads=2)
     got = np.load(tmp_path / "gathered.npy")
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_bench_gather_check_reports_a_corrupted_gather(tmp_path):
+    """The same rehearsal with a gather that delivers one wrong value on the weak region's path: the contract line is still printed and
+    config.gather_check names the damage; the strong region's (asynchronous) path is untouched and stays bit-identical."""
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", GLRT_REHEARSAL_CORRUPT_GATHER="1")
+    r = subprocess.run([sys.executable, str(root / "tests" / "bench_rehearsal.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--steps-per-launch", "2", "--config", "rehearsal", "--backend", "gloo", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert out["config"]["gather_check"] == f"1 of {48 * 72} pixels differ", out["config"]["gather_check"]
+    assert out["config"]["strong"]["gather_check"] == "bit-identical"
 
 
 def test_launch_plan_is_balanced():

@@ -1,7 +1,7 @@
 import sys, ctypes as C; sys.path.insert(0,'.'); sys.path.insert(0,'opengl-raytracer_amd/python')
 import numpy as np
 from glrt_amd import scenes, device, host
-import os
+import os, json
 device.lib_path = lambda: device.LIB_DIR / os.environ.get("GLRTX_STATS_LIB", "libglrtx_stats.so")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "headline"
 sc, pr = scenes.CONFIGS[cfg]()
@@ -19,3 +19,6 @@ for v in (2,):
     hh = (C.c_ulonglong * 16)(); L.glrtx_debug_trav_hist(hh); print("iterations histogram (<=1,2,4,8,...):", list(hh))
     print(f"rays traced {sum(hh)} of {rays} reference rays ({100.0*sum(hh)/max(rays,1):.1f} %)")
     print(f"variant {v}: rays {rays} wave_iters {o[0]} lane_iters {o[1]} simd_eff {o[1]/(64*o[0]):.3f} fork_lane {o[2]} leaf_lane {o[3]} mixed_iters {o[4]/o[0]:.3f} iters/ray {o[1]/rays:.1f} forks/ray {o[2]/rays:.1f} leaves/ray {o[3]/rays:.1f} distinct records/wave-iter {o[5]/o[0]:.1f} distinct 128B lines/wave-iter {o[6]/o[0]:.1f} (active lanes/wave-iter {o[1]/o[0]:.1f}) path-ray share of lane iters {o[7]/o[1]:.3f}")
+    if os.environ.get("GLRTX_TRAVSTATS_JSON"):
+        json.dump({"config": cfg, "frames": B, "rays": int(rays), "wave_iters": o[0], "lane_iters": o[1], "fork_lane": o[2], "leaf_lane": o[3], "mixed_iters": o[4], "records": o[5],
+                   "lines": o[6], "path_ray_lane_iters": o[7], "trips": t, "iters_hist_log2": list(hh)}, open(os.environ["GLRTX_TRAVSTATS_JSON"], "w"))

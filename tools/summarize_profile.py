@@ -10,6 +10,7 @@ correction is applied; the uncorrected sum is recorded next to it.
 Usage: summarize_profile.py <tag> [kernel substring] [frames per launch of the profiled command]"""
 import collections
 import csv
+import statistics
 import glob
 import json
 import pathlib
@@ -33,16 +34,48 @@ for f in glob.glob(str(src / "pmc_*" / "*" / "*_counter_collection.csv")):
         k = r["Kernel_Name"]
         if kernel_substr in k and "resolve" not in k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta[k] = dict(vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]), lds=int(r["LDS_Block_Size"]),
+            # rocprofv3's VGPR_Count is the architected half of the unified register file as the dispatch packet states it (64 for a kernel that
+            # uses 126): recorded under its own name, never as "the kernel's VGPRs" -- those come from the code object (below)
+            meta[k] = dict(rocprof_vgpr_count_field=int(r["VGPR_Count"]), rocprof_accum_vgpr_count_field=int(r.get("Accum_VGPR_Count", 0) or 0),
+                           rocprof_sgpr_count_field=int(r["SGPR_Count"]), lds=int(r["LDS_Block_Size"]),
                            scratch=int(r["Scratch_Size"]), grid=int(r["Grid_Size"]), wg=int(r["Workgroup_Size"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                # the clock the kernel ran at: GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+                dur_ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                if dur_ns > 0:
+                    agg[k]["_clock_ghz"].append(float(r["Counter_Value"]) / 8.0 / dur_ns)
+                    agg[k]["_grbm_pass_duration_ms"].append(dur_ns * 1e-6)
 out = {}
 if not agg and (dst / f"{tag}_pmc.json").exists():  # re-summarise a committed table
     out = json.loads((dst / f"{tag}_pmc.json").read_text())
 for k, cs in agg.items():
     out[k] = {"launches_sampled": max(len(v) for v in cs.values()), **meta[k],
-              "counters_avg_per_launch": {c: sum(v) / len(v) for c, v in sorted(cs.items())}}
+              "counters_avg_per_launch": {c: sum(v) / len(v) for c, v in sorted(cs.items()) if not c.startswith("_")}}
+    if "_clock_ghz" in cs:  # median over the launches of the GRBM pass (the first launch of a process runs at a lower clock)
+        out[k]["clock_ghz"] = statistics.median(cs["_clock_ghz"])
+        out[k]["clock_ghz_per_launch"] = [round(v, 4) for v in cs["_clock_ghz"]]
+        out[k]["grbm_pass_duration_ms"] = statistics.median(cs["_grbm_pass_duration_ms"])
 if agg:
     (dst / f"{tag}_pmc.json").write_text(json.dumps(out, indent=1))
+
+def code_object_registers(kernel_name):
+    """vgpr / sgpr / spills of the kernel from the gfx950 code object in the built library (tools/isa_report.py), not from rocprofv3's fields."""
+    try:
+        import importlib.util, tempfile
+        spec = importlib.util.spec_from_file_location("isa_report", root / "tools" / "isa_report.py")
+        ir = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ir)
+        with tempfile.TemporaryDirectory() as td:
+            ks = ir.kernels(ir.extract(ir.LIB, pathlib.Path(td)))
+        short = kernel_name.split("(")[0].replace("void ", "").strip()
+        for k in ks:
+            if k.get("pretty", "").strip() == short:
+                return {"vgpr": k.get("vgpr_count"), "agpr": k.get("agpr_count"), "sgpr": k.get("sgpr_count"), "vgpr_spills": k.get("vgpr_spill_count"),
+                        "sgpr_spills": k.get("sgpr_spill_count"), "scratch": k.get("private_segment_fixed_size"), "registers_from": "code object (llvm-readelf --notes)"}
+    except Exception as e:  # summaries are still written
+        return {"registers_from": f"unavailable: {type(e).__name__}: {e}"}
+    return {"registers_from": "kernel not found in the code object"}
+
 
 main = [k for k in out if "wgwf<false" in k or "wgwfILb0" in k]
 if main:
@@ -56,7 +89,22 @@ if main:
         hh.update(f.name.encode())
         hh.update(f.read_bytes())
     summ = {"kernel": main[0], "source": f"profiles/{tag}_pmc.json", "frames_per_launch": FRAMES, "kernel_source_sha16": hh.hexdigest()[:16],
-            "vgpr": m["vgpr"], "sgpr": m["sgpr"], "scratch": m["scratch"]}
+            **code_object_registers(main[0])}
+    if "clock_ghz" in m:
+        summ["clock_ghz"] = m["clock_ghz"]
+        summ["clock_note"] = ("GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same dispatch (rocprofv3 --pmc GRBM_GUI_ACTIVE pass, median over its launches): the clock the "
+                              "issue rooflines of bench.py are priced at")
+    # node fetches of the traverse phase: wave-steps x 4 load instructions, from the traversal-statistics build run by tools/profile.sh
+    ts = src / "travstats.json"
+    if not ts.exists() and (dst / f"{tag}_travstats.json").exists():
+        ts = dst / f"{tag}_travstats.json"
+    if ts.exists():
+        t = json.loads(ts.read_text())
+        shutil.copy(ts, dst / f"{tag}_travstats.json") if ts.parent != dst else None
+        summ["wave_steps_per_frame"] = t["wave_iters"] / t["frames"]
+        summ["node_fetch_insts_per_frame"] = 4.0 * t["wave_iters"] / t["frames"]
+        summ["lanes_per_wave_step"] = t["lane_iters"] / t["wave_iters"]
+        summ["lines_per_wave_step"] = t["lines"] / t["wave_iters"]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
         summ.update(fetch_bytes_per_frame_raw=fetch / FRAMES, write_bytes_per_frame=write / FRAMES,

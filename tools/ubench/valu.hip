@@ -41,7 +41,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define R32(M) R8(M) R8(M) R8(M) R8(M)
 
 #define KERNEL(NAME, HALF, BODY)                                                                                                   \
-    __global__ __launch_bounds__(1024) void NAME(float *out, unsigned long long *cyc, int iters, float seed) {                     \
+    __global__ __launch_bounds__(1024) void NAME(float *out, unsigned long long *cyc, unsigned long long *rt, int iters, float seed) {                     \
         __shared__ float lds[2 * 1024 + 64];                                                                                       \
         const float fx = seed + (float)threadIdx.x * 1e-9f, fy = 1.0f - seed * 1e-7f;                                              \
         float a[8];                                                                                                                \
@@ -56,14 +56,17 @@ typedef float v2f __attribute__((ext_vector_type(2)));
         __syncthreads();                                                                                                           \
         unsigned long long save_exec = 0;                                                                                          \
         if (HALF) asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffffffff" : "=s"(save_exec));                             \
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                                                            \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                                \
         for (int it = 0; it < iters; it++) asm volatile(BODY OPERANDS);                                                            \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                                \
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                                            \
         if (HALF) asm volatile("s_mov_b64 exec, %0" : : "s"(save_exec));                                                           \
         float s = (float)(smask & 1ull) + (float)(stmp & 1ull);                                                                    \
         for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;                                                                   \
         out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                                            \
-        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;                           \
+        if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;                         \
+                                       rt[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = r1 - r0; }                        \
     }
 
 // ---- vector ALU, independent (instruction j works on accumulator j mod 8) and dependent (all on accumulator 0)
@@ -195,7 +198,7 @@ KERNEL(k_v_s, false, R64(I_V_S))
 KERNEL(k_v_s_s, false, R64(I_V_S_S))
 KERNEL(k_mul_max, false, R32(I_MUL_MAX))
 
-typedef void (*Kern)(float *, unsigned long long *, int, float);
+typedef void (*Kern)(float *, unsigned long long *, unsigned long long *, int, float);
 struct Entry { const char *key, *what; Kern k; int insts; };  // insts: instructions per loop trip
 static const Entry kTable[] = {
     {"fma", "v_fma_f32", k_fma, 64}, {"fma_dep", "v_fma_f32, dependent chain", k_fma_dep, 64}, {"fma_half", "v_fma_f32, 32 of 64 lanes enabled", k_fma_half, 64},
@@ -223,45 +226,62 @@ static const Entry kTable[] = {
     {"mul_max", "v_mul_f32 + v_max_f32 alternating: per instruction", k_mul_max, 64},
 };
 
+// Round 4: every (op, k) runs as a train of back-to-back launches (no host sync in between) lasting >= `sustain` seconds -- 2 s for the
+// instructions the VALU roofline rests on (fma / add / mul and what the traversal step is made of), 0.5 s for the rest; --sustain S overrides --
+// and the clock the chip holds under that load is measured IN the kernel: delta s_memtime / delta s_memrealtime x 100 MHz, median over the
+// waves of the last launch (MI355X_MICROARCH.md, DVFS item 6).  G/s is at that clock; clk per instruction is the clock-free figure.
 int main(int argc, char **argv) {
     FILE *js = nullptr;
     std::string only;
+    double sustain = -1.0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--only") && i + 1 < argc) only = argv[++i];
+        else if (!strcmp(argv[i], "--sustain") && i + 1 < argc) sustain = atof(argv[++i]);
         else js = fopen(argv[i], "a");
     }
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int n_cu = prop.multiProcessorCount;
     const int iters = 2048;
-    float *out; unsigned long long *cyc;
-    CK(hipMalloc(&out, (size_t)n_cu * 1024 * 4)); CK(hipMalloc(&cyc, (size_t)n_cu * 16 * 8));
+    float *out; unsigned long long *cyc, *rt;
+    CK(hipMalloc(&out, (size_t)n_cu * 1024 * 4)); CK(hipMalloc(&cyc, (size_t)n_cu * 16 * 8)); CK(hipMalloc(&rt, (size_t)n_cu * 16 * 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    printf("%d CUs, clock %.0f MHz\n", n_cu, prop.clockRate / 1000.0);
+    printf("%d CUs, nominal clock %.0f MHz (device property); in-kernel clock measured per case\n", n_cu, prop.clockRate / 1000.0);
+    static const char *kKey[] = {"fma", "fma_half", "add", "mul", "max", "min3", "cmp_sgpr", "cndmask_sgpr", "lshl_add", "mul_max", "s_and", "v_s"};
     for (const Entry &e : kTable) {
         if (!only.empty() && only != e.key) continue;
+        bool key = false;
+        for (const char *kk : kKey) key = key || !strcmp(kk, e.key);
+        const double T = sustain >= 0 ? sustain : (key ? 2.0 : 0.5);
         for (int k = 1; k <= 4; k *= 2) {
             const int threads = 256 * k;
-            float best = 1e9f;
-            std::vector<unsigned long long> h((size_t)n_cu * 4 * k);
-            double clk_wave = 0.0;
-            for (int rep = 0; rep < 3; rep++) {
-                CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(e.k, dim3(n_cu), dim3(threads), 0, 0, out, cyc, iters, 0.37f);
-                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-                if (ms < best) {
-                    best = ms;
-                    CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
-                    std::sort(h.begin(), h.end());
-                    clk_wave = (double)h[h.size() / 2] / ((double)iters * e.insts);  // median wave
-                }
-            }
+            std::vector<unsigned long long> h((size_t)n_cu * 4 * k), hr((size_t)n_cu * 4 * k);
+            float ms1;
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(e.k, dim3(n_cu), dim3(threads), 0, 0, out, cyc, rt, iters, 0.37f);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms1, e0, e1));
+            const int n = std::max(3, (int)(T * 1e3 / std::max(ms1, 0.05f)) + 1);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < n; i++) hipLaunchKernelGGL(e.k, dim3(n_cu), dim3(threads), 0, 0, out, cyc, rt, iters, 0.37f);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms_all; CK(hipEventElapsedTime(&ms_all, e0, e1));
+            const double ms = ms_all / n;
+            CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hr.data(), rt, hr.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> mhz(h.size());
+            for (size_t i = 0; i < h.size(); i++) mhz[i] = hr[i] ? (double)h[i] / (double)hr[i] * 100.0 : 0.0;
+            std::sort(mhz.begin(), mhz.end());
+            const double clock_mhz = mhz[mhz.size() / 2];
+            std::sort(h.begin(), h.end());
+            const double clk_wave = (double)h[h.size() / 2] / ((double)iters * e.insts);  // median wave
             const double insts = (double)n_cu * 4 * k * iters * e.insts;
-            printf("%-72s %d wave(s)/SIMD: %6.2f clk per wave, %6.2f clk per SIMD, %7.1f G/s chip-wide (%.3f ms)\n", e.what, k, clk_wave, clk_wave / k,
-                   insts / (best * 1e-3) * 1e-9, best);
-            if (js) fprintf(js, "{\"op\": \"%s\", \"what\": \"%s\", \"waves_per_simd\": %d, \"clk_per_inst_wave\": %.3f, \"clk_per_inst_simd\": %.3f, \"g_wave_inst_per_s\": %.2f, \"ms\": %.4f, \"simds\": %d}\n",
-                            e.key, e.what, k, clk_wave, clk_wave / k, insts / (best * 1e-3) * 1e-9, best, n_cu * 4);
+            printf("%-72s %d wave(s)/SIMD: %6.2f clk per wave, %6.2f clk per SIMD, in-kernel clock %6.0f MHz, %7.1f G/s chip-wide at that clock (%.3f ms x %d)\n", e.what, k,
+                   clk_wave, clk_wave / k, clock_mhz, insts / (ms * 1e-3) * 1e-9, ms, n);
+            fflush(stdout);
+            if (js) fprintf(js, "{\"op\": \"%s\", \"what\": \"%s\", \"waves_per_simd\": %d, \"clk_per_inst_wave\": %.3f, \"clk_per_inst_simd\": %.3f, \"clock_mhz_in_kernel\": %.1f, "
+                                "\"g_wave_inst_per_s\": %.2f, \"ms_per_launch\": %.4f, \"launches\": %d, \"simds\": %d}\n",
+                            e.key, e.what, k, clk_wave, clk_wave / k, clock_mhz, insts / (ms * 1e-3) * 1e-9, ms, n, n_cu * 4);
         }
     }
     if (js) fclose(js);
