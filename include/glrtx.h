@@ -125,7 +125,10 @@ int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t
 
 /* Host-only test hook (no device, no ctx): the repacked fork records as the kernels read them -- 16 floats per fork
  * {child L box min, ref L} {child L box max, ref R} {child R box min, -} {child R box max, -}, refs as int bit patterns
- * (>= 0 fork index, < 0 ~triangle; ~n_tri = the never-hit record that stands for an absent child) -- so that a test can replay
+ * (>= 0 fork index; < 0 the record ~id of a LEAF of the tree, ids numbered from 1 in the order the traversal meets the leaves -- a hit carries this id,
+ * not the wire triangle index; ref -1 = id 0 = the all-zero never-hit record that stands for an absent child).  A fork whose two children are both leaves
+ * has no fork record: its triangle records are chained (children.y's names children.x's) and its parent refers to the first of them, so n_fork_out counts
+ * only the forks that remain -- so that a test can replay
  * the traversal step's push/pop rules on the packed tree and check stack_entries against the deepest stack it reaches.
  * forks_out may be NULL (counts only).  No reference counterpart (the reference's stack is a fixed int[64], raytrace.frag:284). */
 int glrtx_debug_pack_forks(const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat, size_t n_mat,

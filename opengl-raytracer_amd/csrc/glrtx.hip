@@ -155,6 +155,9 @@ int fold_launches(glrtx_ctx *c, bool block, unsigned keep = 0) {
         glrtx_ctx::LaunchRec &r = c->ring[c->ring_tail % kLaunchRing];
         hipError_t e = block ? hipEventSynchronize(r.ev1) : hipEventQuery(r.ev1);
         if (e == hipErrorNotReady) { (void)hipGetLastError(); return GLRTX_OK; }
+        // a polling caller (glrtx_get_stats) must not swallow a device error: the record stays in the ring, and the next blocking fold -- glrtx_sync,
+        // or a launch that needs the slot -- reports it with the launch it belongs to
+        if (e != hipSuccess && !block) { (void)hipGetLastError(); return GLRTX_OK; }
         c->ring_tail++;
         if (e != hipSuccess)
             return fail(c, GLRTX_EDEVICE, "render launch failed on the device (%s): %s, %dx%d (%d owned rows), %d frame(s), device %d", hipGetErrorString(e),
@@ -486,6 +489,11 @@ int ensure(glrtx_ctx *c, DevBuf &b, size_t bytes) {
     return GLRTX_OK;
 }
 
+#ifdef GLRTX_RAY_LOG
+struct DbgLastLaunch { KernelArgs a; WfArgs w; int lds, grid; float4 *queues; } g_dbg_last;  // what the last pt_render_wgwf launch was given (replay)
+DevBuf g_dbg_log_rays, g_dbg_log_trips;
+#endif
+
 // Variant 2: one persistent launch; every workgroup runs the wavefront trips of the pixels it takes from the frame's tile counter.
 // n_frames > 1 ("frames in flight"): the launch covers n_frames consecutive frames that differ only in u_seed (seeds_xy);
 // the per-sample planes are added to the accumulator in frame order afterwards, so the result is bit-identical to
@@ -614,6 +622,9 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     c->counters_stale = c->counters_stale || c->count_rays;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), lds, rstream, a, w, workPtr, (float4 *)queueBuf.p);
     HIP_TRY(c, hipGetLastError());
+#ifdef GLRTX_RAY_LOG
+    g_dbg_last = {a, w, lds, grid, (float4 *)queueBuf.p};
+#endif
     HIP_TRY(c, hipEventRecord(rec->evm, rstream));
     if (slot) {  // the context's stream -- where the caller's own work, the resolve pass and the next accumulation are ordered -- takes over
         HIP_TRY(c, hipEventRecord(slot->render_done, rstream));
@@ -795,7 +806,8 @@ int glrtx_check_scene(const float *vert, size_t n_vert, const float *tri, size_t
 }
 
 // Host-only: the fork records as the device will see them (16 floats each: {minL, refL} {maxL, refR} {minR, -} {maxR, -}; refs as
-// int bit patterns, a ref < 0 is ~triangle and ~n_tri the never-hit record an absent child refers to), for tests that replay
+// int bit patterns: a ref < 0 is the record ~id of a leaf, ids from 1 in traversal order, ref -1 = id 0 the never-hit record an absent child refers to;
+// leaf pairs have no fork record -- include/glrtx.h), for tests that replay
 // trav_step's push / pop rules on the packed tree and compare the deepest stack they reach with stack_entries.
 int glrtx_debug_pack_forks(const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat, size_t n_mat, const float *light,
                            size_t n_light, const float *bvh, size_t n_nodes, float *forks_out, size_t capacity_forks, int *n_fork_out,
@@ -1165,7 +1177,10 @@ int glrtx_resolve_rgba8(glrtx_ctx *c, uint8_t *dst, size_t dst_pitch_bytes, floa
 
 int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
     if (!c || !out) return GLRTX_EINVAL;
-    if (hipSetDevice(c->device) == hipSuccess) (void)fold_launches(const_cast<glrtx_ctx *>(c), false);  // launches that have finished; never waits
+    // a getter leaves the calling thread's current device as it found it
+    int dev_before = -1;
+    const bool have_dev = hipGetDevice(&dev_before) == hipSuccess;
+    if (hipSetDevice(c->device) == hipSuccess) (void)fold_launches(const_cast<glrtx_ctx *>(c), false);  // launches that have finished; never waits, never consumes a failed one
     *out = c->st;
     // the ray counters live on the device; glrtx_sync brings them over, so after a sync this call touches nothing.  Only when a
     // counting launch was issued since the last sync / read are they fetched here (a blocking copy); polling the stats of a
@@ -1174,6 +1189,7 @@ int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
         hipMemcpy(c->counters_host, c->counter.p, sizeof c->counters_host, hipMemcpyDeviceToHost) == hipSuccess)
         c->counters_stale = false;
     out->rays = c->counters_host[0]; out->rays_untraced = c->counters_host[1];
+    if (have_dev && dev_before != c->device) (void)hipSetDevice(dev_before);
     return GLRTX_OK;
 }
 
@@ -1200,10 +1216,81 @@ int glrtx_debug_trav_trips(unsigned long long out[4]) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_trips), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
     return GLRTX_OK;
 }
+int glrtx_debug_trav_sp_hist(unsigned long long out[16]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_sp_hist), 16 * sizeof(unsigned long long)) != hipSuccess) return GLRTX_EDEVICE;
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_sp_hist), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
+    return GLRTX_OK;
+}
 int glrtx_debug_trav_hist(unsigned long long out[16]) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_hist), 16 * sizeof(unsigned long long)) != hipSuccess) return GLRTX_EDEVICE;
     unsigned long long z[16] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_hist), z, sizeof z) != hipSuccess) return GLRTX_EDEVICE;
+    return GLRTX_OK;
+}
+#endif
+
+#ifdef GLRTX_RAY_LOG
+// diagnostic build only (tools/gpu_replay.py): record the ray queues of the following launches / replay their traverse phases alone
+int glrtx_debug_ray_log_begin(glrtx_ctx *c, unsigned long long max_rays, unsigned max_trips) {
+    if (!c) return GLRTX_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, g_dbg_log_rays, (size_t)max_rays * 2 * sizeof(float4)))) return rc;
+    if ((rc = ensure(c, g_dbg_log_trips, (size_t)max_trips * sizeof(uint2)))) return rc;
+    RayLog lg{(float4 *)g_dbg_log_rays.p, (uint2 *)g_dbg_log_trips.p, max_rays, max_trips, max_rays > 0 ? 1u : 0u};
+    unsigned long long z = 0; unsigned zt = 0;
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_ray_log), &lg, sizeof lg));
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_ray_log_n), &z, sizeof z));
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_ray_log_trips), &zt, sizeof zt));
+    return GLRTX_OK;
+}
+// the log's ray records (2 float4 each) and trips to / from the host: reordering experiments (tools/gpu_replay.py)
+int glrtx_debug_ray_log_copy(glrtx_ctx *c, float *rays_host, unsigned long long n_records, unsigned *trips_host, unsigned n_trips, int to_device) {
+    if (!c) return GLRTX_EINVAL;
+    if (int rc = glrtx_sync(c)) return rc;
+    if ((size_t)n_records * 32 > g_dbg_log_rays.bytes || (size_t)n_trips * 8 > g_dbg_log_trips.bytes) return fail(c, GLRTX_EINVAL, "ray log: copy larger than the log");
+    if (rays_host) HIP_TRY(c, to_device ? hipMemcpy(g_dbg_log_rays.p, rays_host, (size_t)n_records * 32, hipMemcpyHostToDevice)
+                                        : hipMemcpy(rays_host, g_dbg_log_rays.p, (size_t)n_records * 32, hipMemcpyDeviceToHost));
+    if (trips_host) HIP_TRY(c, to_device ? hipMemcpy(g_dbg_log_trips.p, trips_host, (size_t)n_trips * 8, hipMemcpyHostToDevice)
+                                         : hipMemcpy(trips_host, g_dbg_log_trips.p, (size_t)n_trips * 8, hipMemcpyDeviceToHost));
+    return GLRTX_OK;
+}
+// stops recording and runs the traverse phase alone over the log `reps` times; out: {ms of the last replay, rays logged, trips logged, rays offered}
+int glrtx_debug_ray_log_replay(glrtx_ctx *c, int reps, double out[4]) {
+    if (!c) return GLRTX_EINVAL;
+    if (int rc = glrtx_sync(c)) return rc;
+    RayLog lg{};
+    unsigned long long n = 0; unsigned nt = 0;
+    HIP_TRY(c, hipMemcpyFromSymbol(&lg, HIP_SYMBOL(g_ray_log), sizeof lg));
+    HIP_TRY(c, hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ray_log_n), sizeof n));
+    HIP_TRY(c, hipMemcpyFromSymbol(&nt, HIP_SYMBOL(g_ray_log_trips), sizeof nt));
+    lg.on = 0u;
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_ray_log), &lg, sizeof lg));
+    nt = std::min(nt, lg.cap_trips);
+    std::vector<uint2> tr(nt);
+    HIP_TRY(c, hipMemcpy(tr.data(), lg.trips, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost));
+    unsigned long long logged = 0;
+    for (const uint2 &t : tr) logged += t.y;
+    DbgLastLaunch L = g_dbg_last;
+    L.w.suspend_max = 0;
+    if (L.lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)pt_replay_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
+    int per_cu = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_replay_traverse, kBlockThreads, L.lds));
+    if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));
+    const int grid = std::max(1, std::min(L.grid, per_cu * c->n_cu));
+    float ms = 0.f;
+    for (int r = 0; r < reps; r++) {
+        HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
+        HIP_TRY(c, hipEventRecord(c->tm0, c->stream));
+        hipLaunchKernelGGL(pt_replay_traverse, dim3(grid), dim3(kBlockThreads), L.lds, c->stream, L.a, L.w, (unsigned *)c->work.p, L.queues,
+                           (const float4 *)lg.rays, (const uint2 *)lg.trips, (int)nt);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->tm1, c->stream));
+        HIP_TRY(c, hipEventSynchronize(c->tm1));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->tm0, c->tm1));
+    }
+    out[0] = ms; out[1] = (double)logged; out[2] = (double)nt; out[3] = (double)n;
     return GLRTX_OK;
 }
 #endif

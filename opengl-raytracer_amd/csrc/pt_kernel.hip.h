@@ -256,9 +256,14 @@ DEV bool box_pass(float4 lo, float4 hi, float ox, float oy, float oz, float ix, 
 // iterations, [2] lanes on the fork path, [3] lanes on the leaf path, [4] iterations with both paths live
 __device__ unsigned long long g_trav_stats[8];
 __device__ unsigned long long g_trav_hist[16];  // rays by ceil(log2(iterations))
+__device__ unsigned long long g_trav_sp_hist[16];  // lane-steps by the stack pointer at the step's start (15: 15 or more) -- sizes a short LDS stack
 __device__ unsigned long long g_trav_trips[4];  // [0] stepping trips, [1] lanes with a ray at their start, [2] trips after the queue ran out (drain), [3] lanes in those
 // [5] distinct 64-byte node records, [6] distinct 128-byte lines fetched by the wave (summed over iterations), [7] lanes carrying a path ray
-DEV void trav_stats_iter(int cur, const void *rec, bool path_ray) {
+DEV void trav_stats_iter(int cur, const void *rec, bool path_ray, int sp) {
+    for (int d = 0; d < 16; d++) {
+        const unsigned long long md = __ballot(d < 15 ? sp == d : sp >= 15);
+        if (md != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)md) - 1) atomicAdd(&g_trav_sp_hist[d], (unsigned long long)__popcll(md));
+    }
     const unsigned long long m = __ballot(1), mf = __ballot(cur >= 0), mp = __ballot(path_ray);
     int n_rec = 0, n_line = 0;
     const unsigned lo = (unsigned)((uintptr_t)rec >> 6), hi = (unsigned)((uintptr_t)rec >> 38);
@@ -349,7 +354,7 @@ DEV bool trav_init(const DevScene &sc, const float4 *root, Trav &T, float ox, fl
 template <bool CLOSEST>
 DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] const float4 *lds_top = nullptr, [[maybe_unused]] int n_top = 0) {
 #ifdef GLRTX_TRAV_STATS
-    trav_stats_iter(T.cur, (const void *)(sc.forks + 4 * (ptrdiff_t)T.cur), T.stop_d == -__builtin_inff());
+    trav_stats_iter(T.cur, (const void *)(sc.forks + 4 * (ptrdiff_t)T.cur), T.stop_d == -__builtin_inff(), T.sp);
     T.iters++;
 #define TS_DONE atomicAdd(&g_trav_hist[T.iters <= 1 ? 0 : (32 - __clz((int)T.iters - 1)) > 15 ? 15 : (32 - __clz((int)T.iters - 1))], 1ull)
 #else
@@ -1613,6 +1618,17 @@ __device__ uint4 g_trip_log[16][64];
 #define PH_ADD(i, t0, t1)
 #endif
 
+#ifdef GLRTX_RAY_LOG
+// Diagnostic build only (-DGLRTX_RAY_LOG, tools/gpu_replay.py): every traverse phase of pt_render_wgwf appends its workgroup's ray queue to a
+// global log -- the records as the phase reads them, one (offset, count) pair per trip -- and pt_replay_traverse runs the traverse phase ALONE over
+// that log: the same rays in the same grouping, no path state, no shade phase, no top-up.  What it answers: the L2 hit
+// rate of the node fetches by themselves, and what a wave-step costs when nothing else streams through the caches.
+struct RayLog { float4 *rays; uint2 *trips; unsigned long long cap_rays; unsigned cap_trips; unsigned on; };
+__device__ RayLog g_ray_log;
+__device__ unsigned long long g_ray_log_n;  // ray records appended (including the ones that did not fit)
+__device__ unsigned g_ray_log_trips;        // trips appended
+#endif
+
 // Traverse phase of one trip, run by a whole workgroup: lanes pull the workgroup's queued rays and a lane whose ray
 // is finished takes the next one once refill_min lanes of its wave are idle.  Path-ray hits go to w.H, shadow-ray verdicts to light_bits.
 // The queue holds the rays themselves (32-byte records {origin, ray id} {direction, -}); every wave keeps one chunk of 64
@@ -1984,6 +2000,24 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         const float4 *rq = rayQ + 2 * ((size_t)cur * 2 * kWgPaths);
         const unsigned *pq = pathQ + cur * kWgPaths;
 
+#ifdef GLRTX_RAY_LOG
+        if (g_ray_log.on) {  // (wave-uniform) append this trip's ray queue to the log
+            if (threadIdx.x == 0) {
+                const unsigned long long base = atomicAdd(&g_ray_log_n, (unsigned long long)n_rays);
+                ctl[9] = 0u;
+                if (base + (unsigned long long)n_rays <= g_ray_log.cap_rays) {
+                    const unsigned t = atomicAdd(&g_ray_log_trips, 1u);
+                    if (t < g_ray_log.cap_trips) { g_ray_log.trips[t] = make_uint2((unsigned)base, (unsigned)n_rays); ctl[8] = (unsigned)base; ctl[9] = 1u; }
+                }
+            }
+            __syncthreads();
+            if (ctl[9]) {
+                float4 *dst = g_ray_log.rays + 2 * (size_t)ctl[8];
+                for (int i = threadIdx.x; i < 2 * n_rays; i += kBlockThreads) dst[i] = rq[i];
+            }
+            __syncthreads();
+        }
+#endif
         // ---- traverse phase: lanes pull rays; a lane whose ray is finished takes the next one
         PH_STAMP(pt0);
         // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
@@ -2022,6 +2056,43 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 #endif
     flush_rays<COUNT_RAYS>(a, rays);
 }
+
+#ifdef GLRTX_RAY_LOG
+// The traverse phase alone over a recorded log (see RayLog).  Same LDS layout, launch bounds and kernarg prefix as pt_render_wgwf (wgwf_kernargs()
+// reads WfArgs::suspend_max from the kernarg segment; the host passes 0: nothing is parked in a replay).  Hit records go where the recorded ray
+// ids point (state plane 5), shadow-ray verdicts into the LDS bits, exactly as in the render kernel; nobody reads them.
+__global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_traverse(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues,
+                                                                                      const float4 *log, const uint2 *trips, int n_trips) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    unsigned char *pl = lds_raw + (size_t)mat_f4 * sizeof(float4);
+    int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
+    pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
+    unsigned *ctl = reinterpret_cast<unsigned *>(pl);
+    float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));
+    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
+    float4 *lds_top = reinterpret_cast<float4 *>(light_bits + kWgPathsMax / 32);
+    if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
+    if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
+    float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
+    rayQ[kWgSuspendAt + (size_t)kSuspendF4 * threadIdx.x + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned long long rays = 0;
+    __syncthreads();
+    for (;;) {
+        if (threadIdx.x == 0) { ctl[0] = atomicAdd(work_counter, 1u); ctl[1] = 0u; }
+        if (threadIdx.x < kWgPathsMax / 32) light_bits[threadIdx.x] = 0u;
+        __syncthreads();
+        const unsigned t = ctl[0];
+        if (t >= (unsigned)n_trips) break;
+        const uint2 tr = trips[t];
+        __builtin_amdgcn_s_setprio(GLRTX_PRIO_TRAVERSE);
+        wg_traverse_phase<false>(a, w, lds_root, lds_top, stack, log + 2 * (size_t)tr.x, (int)tr.y, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
+        __builtin_amdgcn_s_setprio(GLRTX_PRIO_SHADE);
+        __syncthreads();
+    }
+    flush_rays<true>(a, rays);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------ frames in flight
 // Adds the sample planes of one glrtx_render_frames launch to the accumulator, plane by plane in frame (and sample)

@@ -1,3 +1,4 @@
+#!/bin/bash
 # Experiment driver (GPU box): bench.py's one-launch-per-frame figure under launch-shape settings of the overlapped single-frame path.
 run() { echo "== $1"; env $1 timeout -k 10 200 python bench.py --no-cpu-baseline --steps 48 --warmup 8 2>/dev/null | python -c "
 import json,sys

@@ -17,8 +17,11 @@ for v in (2,):
     L.glrtx_debug_trav_trips(tr); t = list(tr)
     print(f"stepping trips {t[0]}: {t[1] / max(t[0], 1):.1f} lanes with a ray at their start; {100.0 * t[2] / max(t[0], 1):.1f} % of the trips after the workgroup's queue ran out (drain), {t[3] / max(t[2], 1):.1f} lanes at their start")
     hh = (C.c_ulonglong * 16)(); L.glrtx_debug_trav_hist(hh); print("iterations histogram (<=1,2,4,8,...):", list(hh))
+    sph = (C.c_ulonglong * 16)(); L.glrtx_debug_trav_sp_hist(sph); sph = list(sph); tot = max(sum(sph), 1)
+    print("lane-steps by stack pointer at the step's start (0..14, 15+):", sph)
+    print("  share of lane-steps with sp >= k: " + ", ".join(f"{k}: {100.0 * sum(sph[k:]) / tot:.3f} %" for k in range(4, 16)))
     print(f"rays traced {sum(hh)} of {rays} reference rays ({100.0*sum(hh)/max(rays,1):.1f} %)")
     print(f"variant {v}: rays {rays} wave_iters {o[0]} lane_iters {o[1]} simd_eff {o[1]/(64*o[0]):.3f} fork_lane {o[2]} leaf_lane {o[3]} mixed_iters {o[4]/o[0]:.3f} iters/ray {o[1]/rays:.1f} forks/ray {o[2]/rays:.1f} leaves/ray {o[3]/rays:.1f} distinct records/wave-iter {o[5]/o[0]:.1f} distinct 128B lines/wave-iter {o[6]/o[0]:.1f} (active lanes/wave-iter {o[1]/o[0]:.1f}) path-ray share of lane iters {o[7]/o[1]:.3f}")
     if os.environ.get("GLRTX_TRAVSTATS_JSON"):
         json.dump({"config": cfg, "frames": B, "rays": int(rays), "wave_iters": o[0], "lane_iters": o[1], "fork_lane": o[2], "leaf_lane": o[3], "mixed_iters": o[4], "records": o[5],
-                   "lines": o[6], "path_ray_lane_iters": o[7], "trips": t, "iters_hist_log2": list(hh)}, open(os.environ["GLRTX_TRAVSTATS_JSON"], "w"))
+                   "lines": o[6], "path_ray_lane_iters": o[7], "trips": t, "iters_hist_log2": list(hh), "sp_hist": sph}, open(os.environ["GLRTX_TRAVSTATS_JSON"], "w"))

@@ -32,7 +32,7 @@ template <class V> static __device__ __forceinline__ float first(V v) { return v
 // WIDTH: dwords per lane (1, 2, 3 = dwordx3, 4).  The address of a lane is base + line_of_lane * 128 + (lane & 7) * 16: `lines` distinct
 // lines per wave instruction (1, 8, 16, 64); all addresses stay inside a 64 x 128 B = 8 KiB window per wave -> L1-resident after the first touch.
 template <int WIDTH>
-__global__ __launch_bounds__(256, 4) void ta_kernel(const char *table, int rounds, int lines, unsigned long long exec_mask, float *out, unsigned long long *cyc, unsigned long long *rt) {
+__global__ __launch_bounds__(256, 4) void ta_kernel(const char *table, int rounds, int lines, unsigned long long exec_mask, float *out, unsigned long long *cyc, unsigned long long *rt, unsigned long long *where) {
     const int lane = threadIdx.x & 63, wave = (blockIdx.x * 4 + (threadIdx.x >> 6)) & 63;
     // lines = 23 (what a traversal wave-step of the render kernel touches: ~24 records in ~23 lines, tools/gpu_travstats.py): lanes spread over the lines in a
     // scrambled order, so that the lanes of a quad fall into different lines as they do there
@@ -61,18 +61,28 @@ __global__ __launch_bounds__(256, 4) void ta_kernel(const char *table, int round
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * 256 + threadIdx.x] = acc;
-    if (lane == 0) { cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0; rt[blockIdx.x * 4 + (threadIdx.x >> 6)] = r1 - r0; }
+    if (lane == 0) {
+        const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+        cyc[wv] = t1 - t0; rt[wv] = r1 - r0;
+        // where and when the wave ran: {start, end} in s_memrealtime ticks (100 MHz), HW_ID and XCC_ID -- the residency report at the end of main()
+        where[4 * wv] = r0; where[4 * wv + 1] = r1;
+        where[4 * wv + 2] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        where[4 * wv + 3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    }
 }
 
 int main(int argc, char **argv) {
     FILE *js = argc > 1 && argv[1][0] != '-' ? fopen(argv[1], "a") : nullptr;
     const double sustain_s = argc > 2 ? atof(argv[2]) : 2.0;
+    // optional filter (counter-calibration runs under rocprofv3): argv[3] = "width:mask index:lines", e.g. 4:0:64 = dwordx4, all lanes, 64 lines
+    int f_width = 0, f_mask = -1, f_lines = 0;
+    if (argc > 3) sscanf(argv[3], "%d:%d:%d", &f_width, &f_mask, &f_lines);
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int n_cu = prop.multiProcessorCount, blocks = n_cu * 4, rounds = 512;
-    char *table; float *out; unsigned long long *cyc, *rt;
+    char *table; float *out; unsigned long long *cyc, *rt, *where;
     CK(hipMalloc(&table, 64 * 8192 + 4096)); CK(hipMemset(table, 0, 64 * 8192 + 4096));
-    CK(hipMalloc(&out, (size_t)blocks * 256 * 4)); CK(hipMalloc(&cyc, (size_t)blocks * 4 * 8)); CK(hipMalloc(&rt, (size_t)blocks * 4 * 8));
+    CK(hipMalloc(&out, (size_t)blocks * 256 * 4)); CK(hipMalloc(&cyc, (size_t)blocks * 4 * 8)); CK(hipMalloc(&rt, (size_t)blocks * 4 * 8)); CK(hipMalloc(&where, (size_t)blocks * 4 * 4 * 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct Mask { const char *name; unsigned long long m; int active; };
     const Mask masks[] = {{"all 64 lanes", ~0ull, 64}, {"lanes 0-47", 0x0000FFFFFFFFFFFFull, 48}, {"lanes 0-31", 0x00000000FFFFFFFFull, 32}, {"lanes 0-15", 0xFFFFull, 16},
@@ -81,16 +91,17 @@ int main(int argc, char **argv) {
     const int line_counts[] = {1, 16, 23, 64};
     printf("%d CUs; 4 workgroups x 4 waves per CU; every case: back-to-back launches for >= %.1f s, clock measured in the kernel (s_memtime / s_memrealtime)\n", n_cu, sustain_s);
     auto launch = [&](int width, int lines, unsigned long long m) {
-        if (width == 4) ta_kernel<4><<<blocks, 256>>>(table, rounds, lines, m, out, cyc, rt);
-        if (width == 3) ta_kernel<3><<<blocks, 256>>>(table, rounds, lines, m, out, cyc, rt);
-        if (width == 2) ta_kernel<2><<<blocks, 256>>>(table, rounds, lines, m, out, cyc, rt);
-        if (width == 1) ta_kernel<1><<<blocks, 256>>>(table, rounds, lines, m, out, cyc, rt);
+        if (width == 4) ta_kernel<4><<<blocks, 256>>>(table, rounds, lines, m, out, cyc, rt, where);
+        if (width == 3) ta_kernel<3><<<blocks, 256>>>(table, rounds, lines, m, out, cyc, rt, where);
+        if (width == 2) ta_kernel<2><<<blocks, 256>>>(table, rounds, lines, m, out, cyc, rt, where);
+        if (width == 1) ta_kernel<1><<<blocks, 256>>>(table, rounds, lines, m, out, cyc, rt, where);
     };
     for (int width = 1; width <= 4; width++)
         for (const Mask &mk : masks)
             for (int lines : line_counts) {
                 if (mk.active != 64 && lines == 16) continue;
                 if (lines == 23 && mk.active != 64 && mk.active != 52 && mk.active != 48) continue;
+                if (f_width && (width != f_width || (int)(&mk - masks) != f_mask || lines != f_lines)) continue;
                 // one launch to size the train, then n launches back to back (no host sync in between), one sync at the end
                 float ms1;
                 CK(hipEventRecord(e0)); launch(width, lines, mk.m); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -115,6 +126,29 @@ int main(int argc, char **argv) {
                 printf("dwordx%d  %-24s %2d line(s): %6.2f clk per wave-instruction per CU, in-kernel clock %6.0f MHz, %7.1f G wave-inst/s chip-wide at that clock (%.3f ms x %d launches)\n",
                        width, mk.name, lines, cpi, clock_mhz, gps, ms, n);
                 fflush(stdout);
+                if (f_width) {
+                    // residency report of the last launch (one case selected): on how many CUs did the 4 n_cu workgroups run, how many waves shared a CU,
+                    // and how much of the kernel's span was a wave's loop -- what "clk per wave-instruction per CU" (which assumes 16 waves side by side
+                    // on every CU for the whole kernel) rests on
+                    std::vector<unsigned long long> w((size_t)blocks * 16);
+                    CK(hipMemcpy(w.data(), where, w.size() * 8, hipMemcpyDeviceToHost));
+                    unsigned long long lo = ~0ull, hi = 0; double loop_sum = 0;
+                    std::vector<int> per_cu(8 * 8 * 16 * 2, 0);
+                    for (int i = 0; i < blocks * 4; i++) {
+                        lo = std::min(lo, w[4 * i]); hi = std::max(hi, w[4 * i + 1]); loop_sum += (double)(w[4 * i + 1] - w[4 * i]);
+                        const unsigned hw = (unsigned)w[4 * i + 2], xcc = (unsigned)w[4 * i + 3] & 15u;
+                        const unsigned cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+                        per_cu[((xcc * 8 + se) * 2 + sh) * 16 + cu]++;
+                    }
+                    int used = 0, mx = 0, mn = 1 << 30; std::vector<int> hist(65, 0);
+                    for (int v : per_cu) if (v) { used++; mx = std::max(mx, v); mn = std::min(mn, v); hist[std::min(v, 64)]++; }
+                    printf("  residency: %d waves ran on %d distinct CUs (waves per CU: min %d, max %d); kernel span %.3f ms, mean wave loop %.3f ms (%.1f %% of the span)\n",
+                           blocks * 4, used, mn, mx, (double)(hi - lo) * 1e-5, loop_sum / (blocks * 4) * 1e-5, 100.0 * loop_sum / (blocks * 4) / (double)(hi - lo));
+                    printf("  CUs by number of waves they ran:");
+                    for (int v = 0; v <= 64; v++) if (hist[v]) printf(" %d waves: %d CUs;", v, hist[v]);
+                    printf("\n  => per CU the kernel issued %.0f wave-instructions in %.0f clk: %.2f clk per wave-instruction per CU from the kernel's span\n",
+                           (double)blocks * 4 * rounds * 16 / std::max(used, 1), (double)(hi - lo) * clock_mhz / 100.0, (double)(hi - lo) * clock_mhz / 100.0 / ((double)blocks * 4 * rounds * 16 / std::max(used, 1)));
+                }
                 if (js) fprintf(js, "{\"width_dwords\": %d, \"lanes\": \"%s\", \"active_lanes\": %d, \"distinct_lines\": %d, \"clk_per_wave_inst_per_cu\": %.3f, \"clock_mhz_in_kernel\": %.1f, "
                                     "\"g_wave_inst_per_s\": %.2f, \"ms_per_launch\": %.4f, \"launches\": %d}\n",
                                 width, mk.name, mk.active, lines, cpi, clock_mhz, gps, ms, n);
