@@ -1941,7 +1941,6 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
 
     const int kWgPaths = w.block_paths;
-    const int n_tiles = w.tiles_per_frame * w.n_frames;  // 8x8-pixel tiles (64 consecutive tile-order ids each), frame-major
     unsigned long long rays = 0;  // low half: reference rays, high half: those resolved without a traversal
 #ifdef GLRTX_PHASE_STATS
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.x / 64 < 16)
@@ -1957,13 +1956,19 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // (nearly) full set of rays, and workgroups finish together when the counter runs out.
         PH_STAMP(pg0);
         if (threadIdx.x == 0) {
+            // 8x8-pixel tiles (64 consecutive tile-order ids each), frame-major; formed here from the kernarg segment, not once in front of the persistent
+            // loop, for the same reason as gss_div below
+            const int n_tiles = wgwf_kernargs()->w.tiles_per_frame * wgwf_kernargs()->w.n_frames;
             int want = (kWgPaths - (int)ctl[4 + cur]) >> 6;
             int base = 0, got = 0;
-            if (want > 0 && ctl[7] == 0u && w.gss_div > 0) {
+            // (gss_div is read from the kernarg segment HERE: taken from the by-value argument the compiler hoists the division's reciprocal and sign
+            //  words out of the persistent loop, four scalar registers that the list-scan instantiations then spill around their 32 record registers)
+            const int gss_div = wgwf_kernargs()->w.gss_div;
+            if (want > 0 && ctl[7] == 0u && gss_div > 0) {
                 // guided self-scheduling: towards the end of the frame take smaller helpings, so that the last tiles are
                 // spread over all workgroups and they finish together (the peek is racy; it only sizes the request)
                 const int left = n_tiles - (int)__hip_atomic_load(work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int share = left > 0 ? (left + w.gss_div - 1) / w.gss_div : 1;
+                const int share = left > 0 ? (left + gss_div - 1) / gss_div : 1;
                 want = want < share ? want : share;
             }
             if (want > 0 && ctl[7] == 0u) {
@@ -1976,7 +1981,11 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         __syncthreads();
         {
             const int got = (int)ctl[6] * 64, tile0 = (int)ctl[0];
-            if (threadIdx.x < kWgPathsMax / 32) light_bits[threadIdx.x] = 0u;  // last read by the previous shade phase (a barrier ago)
+            {   // (an opaque copy of the thread index: the compare is then formed here, not kept as a lane mask in two scalar registers across the whole loop)
+                unsigned tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                if (tid < kWgPathsMax / 32) light_bits[tid] = 0u;  // last read by the previous shade phase (a barrier ago)
+            }
             const int nr = (int)ctl[2 + cur], np = (int)ctl[4 + cur];
             float4 *rq_w = rayQ + 2 * ((size_t)cur * 2 * kWgPaths + nr);
             unsigned *pq_w = pathQ + cur * kWgPaths + np;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -37,7 +38,20 @@ __global__ __launch_bounds__(256, 4) void ta_kernel(const char *table, int round
     // lines = 23 (what a traversal wave-step of the render kernel touches: ~24 records in ~23 lines, tools/gpu_travstats.py): lanes spread over the lines in a
     // scrambled order, so that the lanes of a quad fall into different lines as they do there
     const int line = lines >= 64 ? lane : (lines <= 1 ? 0 : (lines == 23 ? (lane * 7 + 3 + wave) % 23 : lane % lines));
-    const char *p = table + (size_t)wave * 8192 + (size_t)line * 128 + (lane & 7) * 16;
+    const char *p0 = table + (size_t)wave * 8192 + (size_t)line * 128 + (lane & 7) * 16;
+    const char *p = p0;
+    // Record patterns (round 4; `lines` >= 1000 selects them): what a traversal step's node fetch looks like to the pipe, and what it would look like if the
+    // lanes of a pair / of a quad fetched ONE lane's 64-byte record between them.  G = lanes that share a record (1, 2 or 4), N = distinct records drawn
+    // pseudo-randomly (a hash of wave and group) from the wave's 128 record slots of 64 bytes; lane j of a group reads the j-th 16-byte piece of the record:
+    //   lines = 1000 * G + N, e.g. 1025 = every lane its own record among 25 (today's step: ~52 lanes in ~25 records), 2016 = pairs, 16 records, 4008 = quads
+    if (lines >= 1000) {
+        const int G = lines / 1000, N = lines % 1000;
+        const unsigned grp = (unsigned)lane / (unsigned)G;
+        unsigned h = (grp * 2654435761u) ^ ((unsigned)wave * 40503u + 0x9E3779B9u);
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const unsigned slot = ((h % (unsigned)N) * 37u + (unsigned)wave * 11u) & 127u;  // N distinct slots, spread over the 128
+        p = table + (size_t)wave * 8192 + (size_t)slot * 64 + (size_t)((unsigned)lane % (unsigned)G) * 16;
+    }
     float acc = 0.f;
     const bool on = (exec_mask >> lane) & 1ull;
     __syncthreads();
@@ -76,7 +90,8 @@ int main(int argc, char **argv) {
     const double sustain_s = argc > 2 ? atof(argv[2]) : 2.0;
     // optional filter (counter-calibration runs under rocprofv3): argv[3] = "width:mask index:lines", e.g. 4:0:64 = dwordx4, all lanes, 64 lines
     int f_width = 0, f_mask = -1, f_lines = 0;
-    if (argc > 3) sscanf(argv[3], "%d:%d:%d", &f_width, &f_mask, &f_lines);
+    const bool only_records = argc > 3 && !strcmp(argv[3], "records");  // the record-pattern rows and their two reference rows only
+    if (argc > 3 && !only_records) sscanf(argv[3], "%d:%d:%d", &f_width, &f_mask, &f_lines);
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int n_cu = prop.multiProcessorCount, blocks = n_cu * 4, rounds = 512;
@@ -88,7 +103,7 @@ int main(int argc, char **argv) {
     const Mask masks[] = {{"all 64 lanes", ~0ull, 64}, {"lanes 0-47", 0x0000FFFFFFFFFFFFull, 48}, {"lanes 0-31", 0x00000000FFFFFFFFull, 32}, {"lanes 0-15", 0xFFFFull, 16},
                           {"every other lane (32)", 0x5555555555555555ull, 32}, {"every other quad (32)", 0x0F0F0F0F0F0F0F0Full, 32}, {"one lane per quad (16)", 0x1111111111111111ull, 16},
                           {"52 lanes, scattered holes", 0x77FFBFF7BDF7FD8Dull, 52}};
-    const int line_counts[] = {1, 16, 23, 64};
+    const int line_counts[] = {1, 16, 23, 64, 1025, 1052, 2013, 2016, 2026, 4008, 4013};
     printf("%d CUs; 4 workgroups x 4 waves per CU; every case: back-to-back launches for >= %.1f s, clock measured in the kernel (s_memtime / s_memrealtime)\n", n_cu, sustain_s);
     auto launch = [&](int width, int lines, unsigned long long m) {
         if (width == 4) ta_kernel<4><<<blocks, 256>>>(table, rounds, lines, m, out, cyc, rt, where);
@@ -101,6 +116,8 @@ int main(int argc, char **argv) {
             for (int lines : line_counts) {
                 if (mk.active != 64 && lines == 16) continue;
                 if (lines == 23 && mk.active != 64 && mk.active != 52 && mk.active != 48) continue;
+                if (lines >= 1000 && (width != 4 || (mk.active != 64 && mk.active != 52))) continue;
+                if (only_records && !(width == 4 && (lines >= 1000 || (mk.active == 64 && (lines == 1 || lines == 64)) || (mk.active == 32 && lines == 64)))) continue;
                 if (f_width && (width != f_width || (int)(&mk - masks) != f_mask || lines != f_lines)) continue;
                 // one launch to size the train, then n launches back to back (no host sync in between), one sync at the end
                 float ms1;
@@ -126,32 +143,29 @@ int main(int argc, char **argv) {
                 printf("dwordx%d  %-24s %2d line(s): %6.2f clk per wave-instruction per CU, in-kernel clock %6.0f MHz, %7.1f G wave-inst/s chip-wide at that clock (%.3f ms x %d launches)\n",
                        width, mk.name, lines, cpi, clock_mhz, gps, ms, n);
                 fflush(stdout);
-                if (f_width) {
-                    // residency report of the last launch (one case selected): on how many CUs did the 4 n_cu workgroups run, how many waves shared a CU,
-                    // and how much of the kernel's span was a wave's loop -- what "clk per wave-instruction per CU" (which assumes 16 waves side by side
-                    // on every CU for the whole kernel) rests on
-                    std::vector<unsigned long long> w((size_t)blocks * 16);
-                    CK(hipMemcpy(w.data(), where, w.size() * 8, hipMemcpyDeviceToHost));
-                    unsigned long long lo = ~0ull, hi = 0; double loop_sum = 0;
-                    std::vector<int> per_cu(8 * 8 * 16 * 2, 0);
-                    for (int i = 0; i < blocks * 4; i++) {
-                        lo = std::min(lo, w[4 * i]); hi = std::max(hi, w[4 * i + 1]); loop_sum += (double)(w[4 * i + 1] - w[4 * i]);
-                        const unsigned hw = (unsigned)w[4 * i + 2], xcc = (unsigned)w[4 * i + 3] & 15u;
-                        const unsigned cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
-                        per_cu[((xcc * 8 + se) * 2 + sh) * 16 + cu]++;
-                    }
-                    int used = 0, mx = 0, mn = 1 << 30; std::vector<int> hist(65, 0);
-                    for (int v : per_cu) if (v) { used++; mx = std::max(mx, v); mn = std::min(mn, v); hist[std::min(v, 64)]++; }
-                    printf("  residency: %d waves ran on %d distinct CUs (waves per CU: min %d, max %d); kernel span %.3f ms, mean wave loop %.3f ms (%.1f %% of the span)\n",
-                           blocks * 4, used, mn, mx, (double)(hi - lo) * 1e-5, loop_sum / (blocks * 4) * 1e-5, 100.0 * loop_sum / (blocks * 4) / (double)(hi - lo));
-                    printf("  CUs by number of waves they ran:");
-                    for (int v = 0; v <= 64; v++) if (hist[v]) printf(" %d waves: %d CUs;", v, hist[v]);
-                    printf("\n  => per CU the kernel issued %.0f wave-instructions in %.0f clk: %.2f clk per wave-instruction per CU from the kernel's span\n",
-                           (double)blocks * 4 * rounds * 16 / std::max(used, 1), (double)(hi - lo) * clock_mhz / 100.0, (double)(hi - lo) * clock_mhz / 100.0 / ((double)blocks * 4 * rounds * 16 / std::max(used, 1)));
+                // Residency of the last launch: on how many CUs the 4 n_cu workgroups ran, how many waves shared a CU, and how much of the kernel's span a wave's
+                // loop covered.  "clk per wave-instruction per CU" above assumes 16 waves side by side on every CU for the whole kernel; the waves of a launch
+                // do NOT run side by side for its whole span (a wave's loop covers ~2/3 of it), so the pipe's capacity is the SPAN figure: wave-instructions
+                // issued per CU / span.  (TA_TA_BUSY reads 96-98 % over that span: profiles/r04_ta_counters.json.)
+                std::vector<unsigned long long> w((size_t)blocks * 16);
+                CK(hipMemcpy(w.data(), where, w.size() * 8, hipMemcpyDeviceToHost));
+                unsigned long long lo = ~0ull, hi = 0; double loop_sum = 0;
+                std::vector<int> per_cu(16 * 8 * 2 * 16, 0);
+                for (int i = 0; i < blocks * 4; i++) {
+                    lo = std::min(lo, w[4 * i]); hi = std::max(hi, w[4 * i + 1]); loop_sum += (double)(w[4 * i + 1] - w[4 * i]);
+                    const unsigned hw = (unsigned)w[4 * i + 2], xcc = (unsigned)w[4 * i + 3] & 15u;
+                    const unsigned cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+                    per_cu[((xcc * 8 + se) * 2 + sh) * 16 + cu]++;
                 }
+                int used = 0, mx = 0, mn = 1 << 30;
+                for (int v : per_cu) if (v) { used++; mx = std::max(mx, v); mn = std::min(mn, v); }
+                const double span_clk = (double)(hi - lo) * clock_mhz / 100.0;
+                const double cpi_span = span_clk / ((double)blocks * 4 * rounds * 16 / std::max(used, 1));
+                printf("    span: %d waves on %d CUs (%d..%d per CU), kernel span %.3f ms, a wave's loop %.1f %% of it => %6.2f clk per wave-instruction per CU from the span = %.1f G/s at %.0f MHz\n",
+                       blocks * 4, used, mn, mx, (double)(hi - lo) * 1e-5, 100.0 * loop_sum / (blocks * 4) / (double)(hi - lo), cpi_span, n_cu * clock_mhz * 1e-3 / cpi_span, clock_mhz);
                 if (js) fprintf(js, "{\"width_dwords\": %d, \"lanes\": \"%s\", \"active_lanes\": %d, \"distinct_lines\": %d, \"clk_per_wave_inst_per_cu\": %.3f, \"clock_mhz_in_kernel\": %.1f, "
-                                    "\"g_wave_inst_per_s\": %.2f, \"ms_per_launch\": %.4f, \"launches\": %d}\n",
-                                width, mk.name, mk.active, lines, cpi, clock_mhz, gps, ms, n);
+                                    "\"g_wave_inst_per_s\": %.2f, \"ms_per_launch\": %.4f, \"launches\": %d, \"clk_per_wave_inst_per_cu_from_span\": %.3f, \"wave_loop_share_of_span\": %.3f}\n",
+                                width, mk.name, mk.active, lines, cpi, clock_mhz, gps, ms, n, cpi_span, loop_sum / (blocks * 4) / (double)(hi - lo));
             }
     if (js) fclose(js);
     return 0;
