@@ -29,6 +29,7 @@ namespace {
 
 constexpr int kStripeQuantum = 8;   // stripe heights are multiples of the 8x8 work tile
 constexpr int kGroupStripe = 8;     // stripe height glrtx_group uses: 1080 rows over 8 members = 136 / 128 rows (16-row stripes: 144 / 128)
+constexpr int kPairFetchMinRecords = 32768;  // forks + triangles (2 MiB of 64-byte records) from which the wavefront kernel fetches nodes pair-cooperatively
 constexpr int kFramesBudgetGiB = 32;  // device memory one glrtx_render_frames launch may use for path state and sample planes
 constexpr float kInf = std::numeric_limits<float>::infinity();
 constexpr unsigned kPipeSlots = 8;    // most single-frame launches that may be in flight at once (each with its own stream, state, queues, planes); pipe_slots are used
@@ -490,7 +491,7 @@ int ensure(glrtx_ctx *c, DevBuf &b, size_t bytes) {
 }
 
 #ifdef GLRTX_RAY_LOG
-struct DbgLastLaunch { KernelArgs a; WfArgs w; int lds, grid; float4 *queues; } g_dbg_last;  // what the last pt_render_wgwf launch was given (replay)
+struct DbgLastLaunch { KernelArgs a; WfArgs w; int lds, grid; float4 *queues; bool pair; } g_dbg_last;  // what the last pt_render_wgwf launch was given (replay)
 DevBuf g_dbg_log_rays, g_dbg_log_trips;
 #endif
 
@@ -555,11 +556,18 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const int lds = lds_base + n_top * 64;
     a.sc.n_top = n_top;
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
-    // four instantiations: ray counting on/off x generic tree traversal / list scan of a vine (brute-force) tree
+    // six instantiations: ray counting on/off x (list scan of a vine (brute-force) tree | tree traversal with one record per lane | tree traversal with the
+    // pair-cooperative node fetch).  The pair fetch trades 25 vector-ALU instructions per step for a third less time in the CU's vector-memory pipe
+    // (trav_asm.hip.h): it pays where a wave's lanes are spread over many records -- large trees, incoherent rays: config 5 (100 k triangles) -9 % per frame --
+    // and costs ~1 % where they share the top of a small tree (headline, 10 k triangles: the step is paced by instruction issue there), profiles/r04_ab_pair_fetch.txt.
+    // Picked by the size of the record array; GLRTX_PAIR_FETCH=0/1 overrides.  Both forms are bit-identical (same IEEE operations on the same record).
     using Kernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *);
     const bool vine = c->sc.n_vine > 0;
-    const Kernel kernel = c->count_rays ? (vine ? (Kernel)pt_render_wgwf<true, true> : (Kernel)pt_render_wgwf<true, false>)
-                                        : (vine ? (Kernel)pt_render_wgwf<false, true> : (Kernel)pt_render_wgwf<false, false>);
+    bool pair = !vine && (size_t)c->n_fork + (size_t)c->st.n_tri >= (size_t)kPairFetchMinRecords;
+    if (const char *v = std::getenv("GLRTX_PAIR_FETCH")) pair = !vine && std::atoi(v) != 0;
+    c->st.node_fetch_last = pair ? 1 : 0;
+    const Kernel kernel = c->count_rays ? (vine ? (Kernel)pt_render_wgwf<true, true> : pair ? (Kernel)pt_render_wgwf<true, false, true> : (Kernel)pt_render_wgwf<true, false>)
+                                        : (vine ? (Kernel)pt_render_wgwf<false, true> : pair ? (Kernel)pt_render_wgwf<false, false, true> : (Kernel)pt_render_wgwf<false, false>);
     if (lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     int per_cu = 0;
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockThreads, lds));
@@ -623,7 +631,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), lds, rstream, a, w, workPtr, (float4 *)queueBuf.p);
     HIP_TRY(c, hipGetLastError());
 #ifdef GLRTX_RAY_LOG
-    g_dbg_last = {a, w, lds, grid, (float4 *)queueBuf.p};
+    g_dbg_last = {a, w, lds, grid, (float4 *)queueBuf.p, pair};
 #endif
     HIP_TRY(c, hipEventRecord(rec->evm, rstream));
     if (slot) {  // the context's stream -- where the caller's own work, the resolve pass and the next accumulation are ordered -- takes over
@@ -1274,16 +1282,20 @@ int glrtx_debug_ray_log_replay(glrtx_ctx *c, int reps, double out[4]) {
     for (const uint2 &t : tr) logged += t.y;
     DbgLastLaunch L = g_dbg_last;
     L.w.suspend_max = 0;
-    if (L.lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)pt_replay_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
+    using RKernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *, const float4 *, const uint2 *, int);
+    bool pair = L.pair;
+    if (const char *v = std::getenv("GLRTX_REPLAY_PAIR_FETCH")) pair = std::atoi(v) != 0;  // the same log through the other form of the node fetch
+    const RKernel rk = pair ? (RKernel)pt_replay_traverse<true> : (RKernel)pt_replay_traverse<false>;
+    if (L.lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
     int per_cu = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_replay_traverse, kBlockThreads, L.lds));
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rk, kBlockThreads, L.lds));
     if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));
     const int grid = std::max(1, std::min(L.grid, per_cu * c->n_cu));
     float ms = 0.f;
     for (int r = 0; r < reps; r++) {
         HIP_TRY(c, hipMemsetAsync(c->work.p, 0, sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(c->tm0, c->stream));
-        hipLaunchKernelGGL(pt_replay_traverse, dim3(grid), dim3(kBlockThreads), L.lds, c->stream, L.a, L.w, (unsigned *)c->work.p, L.queues,
+        hipLaunchKernelGGL(rk, dim3(grid), dim3(kBlockThreads), L.lds, c->stream, L.a, L.w, (unsigned *)c->work.p, L.queues,
                            (const float4 *)lg.rays, (const uint2 *)lg.trips, (int)nt);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->tm1, c->stream));

@@ -506,17 +506,38 @@ struct StepTiming { unsigned t = 0, w = 0, n = 0; };
 #define GLRTX_TS_OPERANDS
 #define GLRTX_TS_CLOBBERS
 #endif
+template <bool PAIR>
 DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) {
     unsigned long long s_entry, s_act, s_leaf, s_bl, s_br, s_pop, s_tmp;
     const unsigned stk = (unsigned)(uintptr_t)stack;
     static_assert(kBlockThreads * 8 == 1 << 11, "trav_asm.hip.h shifts the stack index by 11: entry e of lane l at byte (e * kBlockThreads + l) * 8");
     static_assert(REF_FIN == INT32_MIN, "trav_asm.hip.h materialises REF_FIN with v_bfrev_b32 v, 1");
+    // pair-cooperative fetch: which 16-byte pieces a lane reads of the even lane's record (0 and 2, odd lanes 1 and 3) and of the odd lane's (1 and 3, odd lanes 0 and 2)
+    const unsigned par16 = (threadIdx.x & 1u) << 4;
+    const unsigned bias_e = sc.node_bias + par16, bias_o = sc.node_bias + 16u - par16;
+    if (PAIR) {
+        asm volatile(
+            "s_mov_b64 %[entry], exec\n\t"
+            "s_mov_b64 %[act], exec\n\t"
+            GLRTX_ASM_SET_VBASE
+            "v_bfrev_b32 v[GLRTX_VB+11], 1\n\t"
+            GLRTX_REP(GLRTX_STEPS_PER_TRIP, GLRTX_TRAV_STEP_ASM_PAIR)
+            "99:\n\t"
+            "s_mov_b64 exec, %[entry]"
+            : [th] "+&v"(T.h.t), [tri] "+&v"(T.h.tri), [hu] "+&v"(T.h.u), [hv] "+&v"(T.h.v), [cur] "+&v"(T.cur), [sp] "+&v"(T.sp),
+              [entry] "=&s"(s_entry), [act] "=&s"(s_act), [leaf] "=&s"(s_leaf), [bl] "=&s"(s_bl), [br] "=&s"(s_br), [pop] "=&s"(s_pop), [tmp] "=&s"(s_tmp) GLRTX_TS_OPERANDS
+            : [ox] "v"(T.ox), [oy] "v"(T.oy), [oz] "v"(T.oz), [dx] "v"(T.dx), [dy] "v"(T.dy), [dz] "v"(T.dz), [ix] "v"(T.ix), [iy] "v"(T.iy), [iz] "v"(T.iz),
+              [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [eps] "s"(PT_EPS), [big] "s"(0x1p126f),
+              [odd] "s"(0xAAAAAAAAAAAAAAAAull), [biase] "v"(bias_e), [biaso] "v"(bias_o)
+            : "vcc", "scc", "memory", GLRTX_ASM_VCLOBBERS_PAIR GLRTX_TS_CLOBBERS);
+        return;
+    }
     asm volatile(
         "s_mov_b64 %[entry], exec\n\t"
         "s_mov_b64 %[act], exec\n\t"
         GLRTX_ASM_SET_VBASE
         "v_bfrev_b32 v[GLRTX_VB+11], 1\n\t"
-        GLRTX_REP(GLRTX_STEPS_PER_TRIP, GLRTX_TRAV_STEP_ASM)
+        GLRTX_REP(GLRTX_STEPS_PER_TRIP, GLRTX_TRAV_STEP_ASM_LANE)
         "99:\n\t"
         "s_mov_b64 exec, %[entry]"
         : [th] "+&v"(T.h.t), [tri] "+&v"(T.h.tri), [hu] "+&v"(T.h.u), [hv] "+&v"(T.h.v), [cur] "+&v"(T.cur), [sp] "+&v"(T.sp),
@@ -1639,7 +1660,7 @@ __device__ unsigned g_ray_log_trips;        // trips appended
 // again in round 2, after the kernel had lost its spills, it bought nothing and its 8 registers were freed; that A/B table was not kept.)
 DEV int wgwf_suspend_max();  // WfArgs::suspend_max of the running pt_render_wgwf launch, from its kernarg segment (defined below)
 
-template <bool VINE>
+template <bool VINE, bool PAIR>
 DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, [[maybe_unused]] const float4 *lds_top, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned *light_bits, unsigned long long &rays, float4 *suspend_area) {
     const int lane = threadIdx.x & 63;
@@ -1823,9 +1844,9 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
                 if (!fin) fin = trav_step<true>(a.sc, stack, T, lds_top, n_top);
 #else
 #ifdef GLRTX_STEP_TIMING
-            trav_steps_asm(a.sc, stack, T, step_timing);
+            trav_steps_asm<PAIR>(a.sc, stack, T, step_timing);
 #else
-            trav_steps_asm(a.sc, stack, T);
+            trav_steps_asm<PAIR>(a.sc, stack, T);
 #endif
             const bool fin = T.cur == REF_FIN;
 #endif
@@ -1913,7 +1934,7 @@ DEV const WgwfKernArgs *wgwf_kernargs() {
 
 DEV int wgwf_suspend_max() { return wgwf_kernargs()->w.suspend_max; }
 
-template <bool COUNT_RAYS, bool VINE>
+template <bool COUNT_RAYS, bool VINE, bool PAIR = false>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // LDS: materials | stack | ctl[16].  The workgroup's ray/path queues live in its private slice of a
@@ -2032,7 +2053,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
         // their loads get going earlier (measured 1-2 %)
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_TRAVERSE);
-        wg_traverse_phase<VINE>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
+        wg_traverse_phase<VINE, PAIR>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_SHADE);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written
@@ -2070,6 +2091,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 // The traverse phase alone over a recorded log (see RayLog).  Same LDS layout, launch bounds and kernarg prefix as pt_render_wgwf (wgwf_kernargs()
 // reads WfArgs::suspend_max from the kernarg segment; the host passes 0: nothing is parked in a replay).  Hit records go where the recorded ray
 // ids point (state plane 5), shadow-ray verdicts into the LDS bits, exactly as in the render kernel; nobody reads them.
+template <bool PAIR>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_traverse(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues,
                                                                                       const float4 *log, const uint2 *trips, int n_trips) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -2095,7 +2117,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_tra
         if (t >= (unsigned)n_trips) break;
         const uint2 tr = trips[t];
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_TRAVERSE);
-        wg_traverse_phase<false>(a, w, lds_root, lds_top, stack, log + 2 * (size_t)tr.x, (int)tr.y, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
+        wg_traverse_phase<false, PAIR>(a, w, lds_root, lds_top, stack, log + 2 * (size_t)tr.x, (int)tr.y, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_SHADE);
         __syncthreads();
     }

@@ -19,9 +19,17 @@
 //     hands a lane on to it without a fork fetch, a push and a pop in between;
 //   * leaf (and absent) children carry an INFINITE box in the packed fork record (pack_scene), so "a leaf child is never box-tested"
 //     (raytrace.frag:310-331) needs no test of the ref's sign: the slab test passes by itself and yields t0 = -inf.
-// ~122 vector + ~13 scalar + ~8 branch instructions per step.
+//   * round 4 -- a PAIR-COOPERATIVE node fetch (GLRTX_TRAV_STEP_ASM_PAIR; the host selects it for large trees).  What paces the traverse phase is the CU's vector-memory pipe, and what that
+//     pipe charges for a gather instruction is set by how many different records the lanes of a quad touch: 37 clk per wave-instruction when every lane reads
+//     its own record (today's pattern: ~52 lanes in ~25 records), 24.5 when the two lanes of a pair read ONE record, 16 -- the pipe's floor -- when a quad does
+//     (tools/ubench/ta.hip, record patterns; profiles/r04_ubench_ta.txt).  So the two lanes of a pair fetch the EVEN lane's 64-byte record between them with
+//     two instructions (each lane two of its four 16-byte pieces), then the ODD lane's record with two more -- still four instructions per step, each touching
+//     half as many records -- and exchange what the other one needs with one DPP move per dword: 21 selects / moves and 4 address instructions more per step
+//     for a third less time in the pipe.  The arms below run unchanged on the assembled record.
+// ~147 vector + ~22 scalar + ~8 branch instructions per step (pair fetch; ~122 + ~13 without).
 //
-// Register use: 22 scratch registers v[GLRTX_VB .. GLRTX_VB+21] (GLRTX_ASM_VBASE, default 96; clobbered), written below relative to the
+// Register use: 24 scratch registers v[GLRTX_VB .. GLRTX_VB+23] with the pair fetch (v96-v119: +16..+22 the partner's pieces in flight, +23 the second
+// address), 22 without.  Of those: 22 scratch registers v[GLRTX_VB .. GLRTX_VB+21] (GLRTX_ASM_VBASE, default 96; clobbered), written below relative to the
 // assembler symbol GLRTX_VB; in the default build they are v96-v117: v96-v99 A, v100-v103 B, v104-v106 C, v108-v110 D (the 56-byte record; the arms
 // compute in place in it), v107 = REF_FIN, v111 an address / u, v112-v117 temporaries.  gfx950 hazards handled by hand (the assembler does not insert wait
 // states into inline asm): one independent instruction between v_rcp_f32 and the first use of its result (trans forwarding);
@@ -39,10 +47,13 @@
 #define GLRTX_STR_(x) #x
 #define GLRTX_STR(x) GLRTX_STR_(x)
 #define GLRTX_ASM_SET_VBASE ".set GLRTX_VB, " GLRTX_STR(GLRTX_ASM_VBASE) "\n\t"
+// Both forms of the node fetch are compiled (pt_render_wgwf<*, false, PAIR>); the host picks one per scene (glrtx.hip: launch_wgwf, GLRTX_PAIR_FETCH=0/1 overrides).
 #if GLRTX_ASM_VBASE == 96
 #define GLRTX_ASM_VCLOBBERS "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117"
+#define GLRTX_ASM_VCLOBBERS_PAIR GLRTX_ASM_VCLOBBERS, "v118", "v119"
 #elif GLRTX_ASM_VBASE == 72
 #define GLRTX_ASM_VCLOBBERS "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93"
+#define GLRTX_ASM_VCLOBBERS_PAIR GLRTX_ASM_VCLOBBERS, "v94", "v95"
 #else
 #error "GLRTX_ASM_VBASE: add the clobber list for this base"
 #endif
@@ -100,7 +111,99 @@
 #define GLRTX_W1
 #define GLRTX_W0
 #endif
-#define GLRTX_TRAV_STEP_ASM \
+#define GLRTX_TRAV_STEP_ASM_PAIR \
+    GLRTX_TS_BEGIN \
+    "s_andn2_b64 %[tmp], %[act], %[odd]\n\t"   /* ---- pair-cooperative fetch: exec = the running lanes and their pair partners */ \
+    "s_lshl_b64 %[tmp], %[tmp], 1\n\t" \
+    "s_and_b64 %[pop], %[act], %[odd]\n\t" \
+    "s_lshr_b64 %[pop], %[pop], 1\n\t" \
+    "s_or_b64 %[tmp], %[tmp], %[pop]\n\t" \
+    "s_or_b64 %[pop], %[tmp], %[act]\n\t"   /* (%[pop] holds the pair mask until the fork arm assigns it) */ \
+    "s_mov_b64 exec, %[pop]\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+4], 0, %[cur], %[act]\n\t"   /* a partner that is not running fetches record 0 for itself (its cur is REF_FIN: not an address) */ \
+    "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t"   /* lanes at a triangle (only ever used under %[act]) */ \
+    "s_nop 0\n\t"   /* (a DPP source written by the vector ALU needs two wait states) */ \
+    "v_mov_b32_dpp v[GLRTX_VB+15], v[GLRTX_VB+4] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"   /* the even lane's ref in both lanes of the pair */ \
+    "v_mov_b32_dpp v[GLRTX_VB+23], v[GLRTX_VB+4] quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"   /* the odd lane's */ \
+    "v_lshl_add_u32 v[GLRTX_VB+15], v[GLRTX_VB+15], 6, %[biase]\n\t"   /* even lanes: pieces 0 and 2 of the even record, odd lanes: 1 and 3 (+16) */ \
+    "v_lshl_add_u32 v[GLRTX_VB+23], v[GLRTX_VB+23], 6, %[biaso]\n\t"   /* even lanes: pieces 1 and 3 of the odd record (+16), odd lanes: 0 and 2 */ \
+    "global_load_dwordx4 v[GLRTX_VB+0:GLRTX_VB+3], v[GLRTX_VB+15], %[base]\n\t" \
+    "global_load_dwordx4 v[GLRTX_VB+16:GLRTX_VB+19], v[GLRTX_VB+23], %[base]\n\t" \
+    "global_load_dwordx3 v[GLRTX_VB+8:GLRTX_VB+10], v[GLRTX_VB+15], %[base] offset:32\n\t" \
+    "global_load_dwordx3 v[GLRTX_VB+20:GLRTX_VB+22], v[GLRTX_VB+23], %[base] offset:32\n\t" \
+    GLRTX_TS_WAIT0 "s_waitcnt vmcnt(2)\n\t" GLRTX_TS_WAIT1 \
+    "v_cndmask_b32_e64 v[GLRTX_VB+4], v[GLRTX_VB+16], v[GLRTX_VB+0], %[odd]\n\t"   /* what the partner needs: piece 1 of ITS record */ \
+    "v_cndmask_b32_e64 v[GLRTX_VB+5], v[GLRTX_VB+17], v[GLRTX_VB+1], %[odd]\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+6], v[GLRTX_VB+18], v[GLRTX_VB+2], %[odd]\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+7], v[GLRTX_VB+19], v[GLRTX_VB+3], %[odd]\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+0], v[GLRTX_VB+0], v[GLRTX_VB+16], %[odd]\n\t"   /* A = piece 0 of the lane's own record */ \
+    "v_cndmask_b32_e64 v[GLRTX_VB+1], v[GLRTX_VB+1], v[GLRTX_VB+17], %[odd]\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+2], v[GLRTX_VB+2], v[GLRTX_VB+18], %[odd]\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+3], v[GLRTX_VB+3], v[GLRTX_VB+19], %[odd]\n\t" \
+    "v_mov_b32_dpp v[GLRTX_VB+4], v[GLRTX_VB+4] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   /* B = piece 1, from the partner */ \
+    "v_mov_b32_dpp v[GLRTX_VB+5], v[GLRTX_VB+5] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mov_b32_dpp v[GLRTX_VB+6], v[GLRTX_VB+6] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mov_b32_dpp v[GLRTX_VB+7], v[GLRTX_VB+7] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "s_andn2_b64 exec, %[act], %[leaf]\n\t"   /* ---- fork arm: exec = lanes at a fork (may be none) */ \
+    "v_sub_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ox]\n\t"   /* left child: (lo - o) / d, (hi - o) / d */    \
+    "v_sub_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[oy]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+2], v[GLRTX_VB+2], %[oz]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ix]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[iy]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+2], v[GLRTX_VB+2], %[iz]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+4], v[GLRTX_VB+4], %[ox]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+5], v[GLRTX_VB+5], %[oy]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+6], v[GLRTX_VB+6], %[oz]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+4], v[GLRTX_VB+4], %[ix]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+5], v[GLRTX_VB+5], %[iy]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+6], v[GLRTX_VB+6], %[iz]\n\t"                                                            \
+    "v_max_f32 v[GLRTX_VB+16], v[GLRTX_VB+4], v[GLRTX_VB+0]\n\t"                                                                                                                    \
+    "v_min_f32 v[GLRTX_VB+0], v[GLRTX_VB+4], v[GLRTX_VB+0]\n\t"                                                                                                                     \
+    "v_max_f32 v[GLRTX_VB+17], v[GLRTX_VB+5], v[GLRTX_VB+1]\n\t"                                                                                                                    \
+    "v_min_f32 v[GLRTX_VB+1], v[GLRTX_VB+5], v[GLRTX_VB+1]\n\t"                                                                                                                     \
+    "v_max_f32 v[GLRTX_VB+18], v[GLRTX_VB+6], v[GLRTX_VB+2]\n\t"                                                                                                                    \
+    "v_min_f32 v[GLRTX_VB+4], v[GLRTX_VB+6], v[GLRTX_VB+2]\n\t"                                                                                                                    \
+    "v_min3_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+17], v[GLRTX_VB+18]\n\t"                             /* t1 */                                                                       \
+    "v_max3_f32 v[GLRTX_VB+2], v[GLRTX_VB+0], v[GLRTX_VB+1], v[GLRTX_VB+4]\n\t"                                /* t0 of the left child, next to its ref: v[GLRTX_VB+2:GLRTX_VB+3] = {t0, ref} */              \
+    "v_min_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], %[th]\n\t"                                                                                                                  \
+    "v_cmp_ge_f32_e64 %[bl], v[GLRTX_VB+16], v[GLRTX_VB+2]\n\t"                             /* min(t1, tHit) >= t0 */                                                      \
+    "s_mov_b64 exec, %[pop]\n\t"   /* the pairs again */ \
+    "s_waitcnt vmcnt(0)\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+12], v[GLRTX_VB+20], v[GLRTX_VB+8], %[odd]\n\t"   /* what the partner needs: piece 3 of its record */ \
+    "v_cndmask_b32_e64 v[GLRTX_VB+13], v[GLRTX_VB+21], v[GLRTX_VB+9], %[odd]\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+14], v[GLRTX_VB+22], v[GLRTX_VB+10], %[odd]\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+8], v[GLRTX_VB+8], v[GLRTX_VB+20], %[odd]\n\t"   /* C = piece 2 of the lane's own record */ \
+    "v_cndmask_b32_e64 v[GLRTX_VB+9], v[GLRTX_VB+9], v[GLRTX_VB+21], %[odd]\n\t" \
+    "v_cndmask_b32_e64 v[GLRTX_VB+10], v[GLRTX_VB+10], v[GLRTX_VB+22], %[odd]\n\t" \
+    "v_mov_b32_dpp v[GLRTX_VB+12], v[GLRTX_VB+12] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   /* D = piece 3, from the partner */ \
+    "v_mov_b32_dpp v[GLRTX_VB+13], v[GLRTX_VB+13] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mov_b32_dpp v[GLRTX_VB+14], v[GLRTX_VB+14] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    GLRTX_X_VALU \
+    "s_andn2_b64 exec, %[act], %[leaf]\n\t"   /* fork lanes again */ \
+    "v_sub_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], %[ox]\n\t"   /* right child: lo v[GLRTX_VB+8..10], hi v[GLRTX_VB+12..14] */    \
+    "v_sub_f32 v[GLRTX_VB+9], v[GLRTX_VB+9], %[oy]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+10], v[GLRTX_VB+10], %[oz]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], %[ix]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+9], v[GLRTX_VB+9], %[iy]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+10], v[GLRTX_VB+10], %[iz]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], %[ox]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+13], v[GLRTX_VB+13], %[oy]\n\t"                                                            \
+    "v_sub_f32 v[GLRTX_VB+14], v[GLRTX_VB+14], %[oz]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], %[ix]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+13], v[GLRTX_VB+13], %[iy]\n\t"                                                            \
+    "v_mul_f32 v[GLRTX_VB+14], v[GLRTX_VB+14], %[iz]\n\t"                                                            \
+    "v_max_f32 v[GLRTX_VB+16], v[GLRTX_VB+12], v[GLRTX_VB+8]\n\t"                                                                                                                   \
+    "v_min_f32 v[GLRTX_VB+8], v[GLRTX_VB+12], v[GLRTX_VB+8]\n\t"                                                                                                                   \
+    "v_max_f32 v[GLRTX_VB+17], v[GLRTX_VB+13], v[GLRTX_VB+9]\n\t"                                                                                                                   \
+    "v_min_f32 v[GLRTX_VB+9], v[GLRTX_VB+13], v[GLRTX_VB+9]\n\t"                                                                                                                   \
+    "v_max_f32 v[GLRTX_VB+18], v[GLRTX_VB+14], v[GLRTX_VB+10]\n\t"                                                                                                                   \
+    "v_min_f32 v[GLRTX_VB+10], v[GLRTX_VB+14], v[GLRTX_VB+10]\n\t"                                                                                                                   \
+    "v_min3_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+17], v[GLRTX_VB+18]\n\t"                                                                                                            \
+    "v_max3_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], v[GLRTX_VB+9], v[GLRTX_VB+10]\n\t"                                                                                                            \
+    "v_min_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], %[th]\n\t"                                                                                                                  \
+    "v_cmp_ge_f32_e64 %[br], v[GLRTX_VB+16], v[GLRTX_VB+8]\n\t" \
+    GLRTX_TRAV_STEP_TAIL
+#define GLRTX_TRAV_STEP_ASM_LANE \
     GLRTX_TS_BEGIN \
     "v_lshl_add_u32 v[GLRTX_VB+15], %[cur], 6, %[bias]\n\t"                                                                                                      \
     "global_load_dwordx4 v[GLRTX_VB+0:GLRTX_VB+3], v[GLRTX_VB+15], %[base]\n\t"                                                                                                  \
@@ -157,7 +260,9 @@
     "v_min3_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+17], v[GLRTX_VB+18]\n\t"                                                                                                            \
     "v_max3_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], v[GLRTX_VB+9], v[GLRTX_VB+10]\n\t"                                                                                                            \
     "v_min_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], %[th]\n\t"                                                                                                                  \
-    "v_cmp_ge_f32_e64 %[br], v[GLRTX_VB+16], v[GLRTX_VB+8]\n\t"                                                                                                           \
+    "v_cmp_ge_f32_e64 %[br], v[GLRTX_VB+16], v[GLRTX_VB+8]\n\t" \
+    GLRTX_TRAV_STEP_TAIL
+#define GLRTX_TRAV_STEP_TAIL \
     "v_cndmask_b32_e64 %[cur], v[GLRTX_VB+3], v[GLRTX_VB+7], %[br]\n\t"                    /* go on with the right child if it passed, else with the left */              \
     "s_or_b64 %[tmp], %[bl], %[br]\n\t"                                                                                                                \
     "s_andn2_b64 %[pop], exec, %[tmp]\n\t"                              /* fork lanes with neither child: pop */                                       \

@@ -16,6 +16,9 @@ TOL = 1e-4  # north_star: "pixels within 1e-4 of the GL reference"
 # The render kernels exist in two compilations: with ray counting (what the ray-count assertions need) and without (what bench.py
 # TIMES: pt_render_wgwf<false, *>, its own register allocation around the hand-written inline asm).  The image tests run on both.
 BOTH_INSTANTIATIONS = pytest.mark.parametrize("count_rays", [True, False], ids=["counting", "timed"])
+# ... and, since round 4, with two forms of the traversal step's node fetch: one record per lane, and pair-cooperative (the two lanes of a pair fetch one
+# lane's record between them and exchange the pieces; the host picks it for large trees).  GLRTX_PAIR_FETCH forces either; the image tests run on both.
+BOTH_NODE_FETCHES = pytest.mark.parametrize("pair_fetch", ["0", "1"], ids=["lane-fetch", "pair-fetch"])
 
 
 def gpu_render(d, scene, params, frames=None, count_rays=True):
@@ -30,9 +33,11 @@ def gpu_render(d, scene, params, frames=None, count_rays=True):
     return d.read_accum(), d.stats()
 
 
+@BOTH_NODE_FETCHES
 @BOTH_INSTANTIATIONS
 @pytest.mark.parametrize("name", golden_names())
-def test_hip_matches_reference_golden(gpu_device, name, count_rays):
+def test_hip_matches_reference_golden(gpu_device, monkeypatch, name, count_rays, pair_fetch):
+    monkeypatch.setenv("GLRTX_PAIR_FETCH", pair_fetch)
     scene, params, rows, frames, rgb, cnt = load_golden(name)
     acc, st = gpu_render(gpu_device, scene, params, frames, count_rays=count_rays)
     acc = acc[rows[0]:rows[1]]
@@ -54,16 +59,29 @@ ORACLE_CASES = [
 
 
 @pytest.mark.parametrize("cfg,kw", ORACLE_CASES)
-def test_hip_bit_exact_vs_oracle(gpu_device, cfg, kw):
+def test_hip_bit_exact_vs_oracle(gpu_device, monkeypatch, cfg, kw):
     from oracle import pt_oracle
     scene, params = scenes.CONFIGS[cfg](**kw)
     ref, ref_rays = pt_oracle.render(scene, params)
-    acc, st = gpu_render(gpu_device, scene, params)
-    assert st.rays == ref_rays
-    assert_bit_equal(acc, ref, f"{cfg} {kw}")
-    acc, st = gpu_render(gpu_device, scene, params, count_rays=False)  # the instantiation bench.py times
-    assert st.rays == 0
-    assert_bit_equal(acc, ref, f"{cfg} {kw}, kernel without ray counting")
+    fetches = set()
+    for pair_fetch in ("0", "1", None):  # both forms of the node fetch forced, then the host's own choice
+        if pair_fetch is None:
+            monkeypatch.delenv("GLRTX_PAIR_FETCH")
+        else:
+            monkeypatch.setenv("GLRTX_PAIR_FETCH", pair_fetch)
+        acc, st = gpu_render(gpu_device, scene, params)
+        fetches.add(st.node_fetch_last)
+        assert st.rays == ref_rays
+        assert_bit_equal(acc, ref, f"{cfg} {kw} pair_fetch={pair_fetch}")
+        acc, st = gpu_render(gpu_device, scene, params, count_rays=False)  # the instantiation bench.py times
+        assert st.rays == 0
+        assert_bit_equal(acc, ref, f"{cfg} {kw}, kernel without ray counting, pair_fetch={pair_fetch}")
+    if "chain" not in str(scene.get("bvh_kind", "")):
+        assert fetches == {0, 1}, "both forms of the node fetch ran"
+    if cfg == "c5":
+        assert st.node_fetch_last == 1, "100 k triangles: the host picks the pair-cooperative fetch by itself"
+    if cfg == "headline":
+        assert st.node_fetch_last == 0
 
 
 def test_dof_and_seed_sweep_vs_oracle(gpu_device):

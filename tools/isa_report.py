@@ -72,6 +72,15 @@ def table(ks) -> str:
     return "\n".join(rows)
 
 
+def is_list_scan(pretty: str) -> bool:
+    """pt_render_wgwf<COUNT_RAYS, VINE, PAIR>: the second template argument selects the list scan of a vine tree."""
+    m = re.search(r"pt_render_wgwf<([^>]*)>", pretty)
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(1).split(",")]
+    return len(args) > 1 and args[1] == "true"
+
+
 def sreg_set(tok: str):
     m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
     if m:
@@ -93,7 +102,7 @@ def check_scalar_prefetch(co: pathlib.Path, ks) -> list:
         elif name and ln.strip():
             body[name].append(ln.split("//")[0].strip())
     for k in ks:
-        if "pt_render_wgwf" not in k["pretty"] or "true>" not in k["pretty"].split(",")[-1]:
+        if not is_list_scan(k["pretty"]):
             continue
         ins = body.get(k["name"], [])
         n_loads = 0
@@ -133,7 +142,7 @@ def check_pop_loop(co: pathlib.Path, ks) -> list:
     for k in ks:
         if not any(t in k["pretty"] for t in ("pt_render_wgwf", "pt_render_persistent", "pt_render_kernel")):
             continue
-        if "pt_render_wgwf" in k["pretty"] and k["pretty"].rstrip(">").endswith("true"):
+        if is_list_scan(k["pretty"]):
             continue  # list-scan instantiations never pop
         ins = body.get(k["name"], [])
         n = 0
@@ -150,9 +159,11 @@ def check_pop_loop(co: pathlib.Path, ks) -> list:
 
 
 def check_staged_waits(co: pathlib.Path, ks) -> list:
-    """The hand-written traversal step of the wavefront kernel: behind every node fetch (two dwordx4 + two dwordx3 loads) the waits come one
-    load at a time -- s_waitcnt vmcnt(3), (2), (1), (0), in that order, with no other vector-memory instruction in between (a load or store
-    slipped into the sequence would make the counts wait for the wrong thing)."""
+    """The hand-written traversal step of the wavefront kernel.  Behind every node fetch (two dwordx4 + two dwordx3 loads, in either order) the waits come in
+    stages -- pair-cooperative fetch (round 4): s_waitcnt vmcnt(2) then vmcnt(0); one record per lane (rounds 2-3): vmcnt(3), (2), (1), (0) -- with no other
+    vector-memory instruction in between (a load or store slipped into the sequence would make the counts wait for the wrong thing).  And the DPP moves of the
+    pair exchange keep gfx950's manual hazards: a DPP source register is not written by the two instructions in front of it, and no v_cmpx (a vector write
+    of exec) sits in the five instructions in front of a DPP instruction (the assembler inserts no wait states into inline asm)."""
     problems = []
     dis = subprocess.run([str(LLVM / "llvm-objdump"), "-d", "--no-show-raw-insn", str(co)], check=True, capture_output=True, text=True).stdout
     body, name = {}, None
@@ -163,33 +174,58 @@ def check_staged_waits(co: pathlib.Path, ks) -> list:
             body[name] = []
         elif name and ln.strip():
             body[name].append(ln.split("//")[0].strip())
+
+    def vregs(tok):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", tok)
+        return {int(m.group(1))} if m else set()
+
     for k in ks:
-        if "pt_render_wgwf" not in k["pretty"] or k["pretty"].rstrip(">").endswith("true"):
+        if "pt_render_wgwf" not in k["pretty"] or is_list_scan(k["pretty"]):
             continue  # (list-scan instantiations have no stepping block)
         ins = body.get(k["name"], [])
         fetches = 0
         for i, s in enumerate(ins):
-            if not (s.startswith("global_load_dwordx3") and i >= 3 and ins[i - 1].startswith("global_load_dwordx3") and
-                    ins[i - 2].startswith("global_load_dwordx4") and ins[i - 3].startswith("global_load_dwordx4")):
+            if i < 3 or not all(t.startswith("global_load_dwordx") for t in ins[i - 3:i + 1]):
+                continue
+            widths = sorted(t.split()[0][-1] for t in ins[i - 3:i + 1])
+            if widths != ["3", "3", "4", "4"] or (i + 1 < len(ins) and ins[i + 1].startswith("global_load")):
                 continue
             fetches += 1
-            want = 3
-            for t in ins[i + 1:i + 80]:
+            pair = ins[i - 2].startswith("global_load_dwordx4")  # x4, x4, x3, x3: pair-cooperative; x4, x4, x3, x3 with one address register: per lane
+            pair = pair and len({t.split(",")[1].strip() for t in ins[i - 3:i + 1]}) == 2  # two address registers
+            stages = [2, 0] if pair else [3, 2, 1, 0]
+            for t in ins[i + 1:i + 120]:
                 if t.startswith(("global_", "buffer_", "flat_", "scratch_")):
                     problems.append(f"{k['pretty']}: `{t}` inside the staged waits of the node fetch at instruction {i}")
                     break
                 m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
                 if m:
-                    if int(m.group(1)) != want:
-                        problems.append(f"{k['pretty']}: node fetch at instruction {i}: expected s_waitcnt vmcnt({want}), found `{t}`")
+                    if int(m.group(1)) != stages[0]:
+                        problems.append(f"{k['pretty']}: node fetch at instruction {i}: expected s_waitcnt vmcnt({stages[0]}), found `{t}`")
                         break
-                    want -= 1
-                    if want < 0:
+                    stages.pop(0)
+                    if not stages:
                         break
             else:
                 problems.append(f"{k['pretty']}: node fetch at instruction {i}: the staged waits are incomplete")
         if fetches == 0:
             problems.append(f"{k['pretty']}: no node fetch (2 x dwordx4 + 2 x dwordx3) found")
+        for i, s in enumerate(ins):
+            if "quad_perm" not in s:
+                continue
+            ops = [t.strip().rstrip(",") for t in s.split()[1:3]]
+            src = vregs(ops[1]) if len(ops) > 1 else set()
+            for t in ins[max(0, i - 2):i]:
+                if t.startswith("v_") and not t.startswith("v_cmp"):
+                    dst = vregs(t.split()[1].rstrip(","))
+                    if dst & src:
+                        problems.append(f"{k['pretty']}: `{s}` at instruction {i} reads a register `{t}` wrote fewer than two wait states earlier")
+            for t in ins[max(0, i - 5):i]:
+                if t.startswith("v_cmpx"):
+                    problems.append(f"{k['pretty']}: `{s}` at instruction {i} follows `{t}` (a vector write of exec) by fewer than five wait states")
     return problems
 
 
