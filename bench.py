@@ -36,8 +36,8 @@ same steps by the kernel that is timed (the compilation without ray counting): a
 
 Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
   roofline      -- HBM roofline of the render kernel from ALGORITHMIC bytes / measured launch time (what north_star asks for)
-  roofline_vmem -- vector-memory INSTRUCTION roofline of the same kernel: the bound that applies (profiles/r03_traverse_bound.txt)
-  roofline_valu -- vector-ALU issue roofline of the same kernel
+  roofline_vmem -- what the CUs' vector-memory pipes can take of this kernel's instruction mix at the kernel's own clock, and the TA busy counter
+  roofline_valu -- vector-ALU issue roofline of the same kernel at the same clock, with an estimate of the SIMDs' whole issue time
   roofline_aux  -- the two kernels that ARE HBM-bound: accumulate_planes_kernel and resolve_kernel, GB/s against the HBM peak
   cpu_baseline  -- the CPU restatement (oracle/, "port") timed on this box's host cores (N = 1 only)
 and in config: `strong` (N > 1: a fixed --steps-per-launch (48) frames in flight in total, the framebuffer gathered after every launch) and `predicted`
@@ -61,12 +61,22 @@ sys.path.insert(0, str(ROOT / "opengl-raytracer_amd" / "python"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# wave64 VALU instructions/ns the chip can issue: 1024 SIMDs x 2.4 GHz / 2 clk.  Measured (profiles/r03_ubench_valu.json): a SIMD with two or
-# more resident waves issues one v_fma / v_add / v_mul per 1.97 clk (157 TF FP32 is this rate, not a packed one); 1050 G/s sustained chip-wide.
-VALU_PEAK_GINST = 1024 * 2.4 / 2
-# wave-level vector-memory instructions/ns: measured chip-wide rate of scattered dwordx4 gathers on L1-resident data, 16 waves per CU
-# (tools/ubench/ta.hip, profiles/r03_ubench_ta.txt: 24.1 G/s with the lanes of a quad in 3-4 lines, 37.5 G/s when they share a line)
-VMEM_PEAK_GINST = 24.1
+N_CU, N_SIMD = 256, 1024
+# The two issue rooflines of the render kernel are priced PER CLOCK and multiplied by the clock the render kernel itself ran at -- GRBM_GUI_ACTIVE / 8 / duration
+# of the profiled dispatches (profiles/r04_pmc_summary.json: clock_ghz), NOT the nominal 2.4 GHz and not a wall-clock rate of another kernel (round 3 did both).
+# The micro-benchmarks behind the per-clock figures run as >= 2 s trains and print the clock measured IN their kernels (s_memtime / s_memrealtime):
+# 2.36-2.41 GHz, the clock the render kernel holds too (2.38), so their wall-clock rates are directly comparable as well.
+# A SIMD with two or more resident waves issues one wave64 v_fma / v_add / v_mul per 1.96-1.98 clk (profiles/r04_ubench_valu.txt; min/max/compare/select/DPP
+# forms 3.15 as a pure stream, a scalar ALU instruction 3.2, a taken branch 5.9).
+VALU_CLK_PER_INST = 1.97
+# What a CU's vector-memory pipe (address unit + L1 front end) takes per wave-level load, clk per instruction per CU from the SPAN of a saturated kernel
+# (tools/ubench/ta.hip; profiles/r04_ubench_ta_records.txt, r04_ubench_ta_sustained.txt; TA_TA_BUSY reads 0.965-0.98 over that span):
+#   every lane its own 64-byte record, 52 lanes in ~25 records -- the node fetch of a traversal step with one record per lane: 37.0
+#   the two lanes of a pair share a record -- the pair-cooperative node fetch:                                               24.5
+#   unit-stride / one line per quad -- the state, ray-record and plane streams:                                               16.1 (the pipe's floor)
+# (Round 3's 16.8 / 11 clk were in-wave timings that assumed all 16 waves of a CU run side by side for the whole kernel; a wave's loop covers two thirds of
+#  the kernel's span, so the pipe's capacity is the span figure: 25.4 clk for 64 lanes in 64 lines, 24.1 G/s chip-wide at 2.38 GHz, as the wall clock says.)
+VMEM_CLK_NODE_LANE, VMEM_CLK_NODE_PAIR, VMEM_CLK_STREAM = 37.0, 24.5, 16.1
 STRIPE = 8  # rows per stripe: 1080 rows over 8 ranks = 136 / 128 rows per rank (16-row stripes: 144 / 128, 6.7 % off balance)
 STEPS_PER_LAUNCH = 48  # frames' worth of paths in flight on every GPU per launch (frames in flight; round 3, ms per frame: 8: 1.127, 24: 1.060, 48: 1.043; 11 GB of path state and planes at 1080p)
 
@@ -462,50 +472,82 @@ def main(argv=None):
     algo_bytes = int(len(ys) * W * 32 * frames_per_launch) + scene_b
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     # PMC counters cannot be collected inside this run (rocprofv3 wraps the process): the per-frame instruction counts and HBM-side bytes
-    # come from the committed profile of this same command (tools/profile.sh -> profiles/r03_pmc_summary.json) and are scaled to the
+    # come from the committed profile of this same command (tools/profile.sh + tools/summarize_profile.py -> profiles/rNN[_config]_pmc_summary.json) and are scaled to the
     # frames' worth of pixels a launch covers on this GPU.  The summary records a hash of the kernel sources it was taken from; if the
     # sources have changed since, the derived figures are reported as null ("stale_profile") instead of looking measured.
     traffic, valu, vmem, prof, stale = None, None, None, None, None
-    for name in ("r03_pmc_summary.json",):
-        if (ROOT / "profiles" / name).exists():
-            try:
-                prof = json.loads((ROOT / "profiles" / name).read_text())
-                prof["file"] = f"profiles/{name}"
-            except Exception:
-                prof = None
-    if prof is not None and prof.get("kernel_source_sha16") != kernel_source_sha16():
-        stale = f"{prof['file']} was taken from kernel sources {prof.get('kernel_source_sha16')}, this build is {kernel_source_sha16()}"
-        prof = None
-    if prof is not None and args.config == "headline":
+    # the newest committed summary of this config whose kernel-source hash matches this build (profiles/rNN[_cfg]_pmc_summary.json)
+    import re
+    cands = []
+    for f in (ROOT / "profiles").glob("r*_pmc_summary.json"):
+        m = re.fullmatch(r"r(\d+)([a-z]?)(?:_(c\d|headline))?_pmc_summary\.json", f.name)
+        if m and (m.group(3) or "headline") == args.config:
+            cands.append(((int(m.group(1)), m.group(2)), f))
+    for _, f in sorted(cands, reverse=True):
+        try:
+            pj = json.loads(f.read_text())
+        except Exception:
+            continue
+        pj["file"] = f"profiles/{f.name}"
+        if pj.get("kernel_source_sha16") == kernel_source_sha16():
+            prof, stale = pj, None
+            break
+        if stale is None:
+            stale = f"{pj['file']} was taken from kernel sources {pj.get('kernel_source_sha16')}, this build is {kernel_source_sha16()}"
+    if prof is not None and prof.get("clock_ghz"):
         frames_equiv = frames_per_launch * len(ys) / H
         sec = kernel_ms * 1e-3
+        clock = float(prof["clock_ghz"])
         traffic = prof["hbm_bytes_per_frame"] * frames_equiv
         vi = prof["valu_insts_per_frame"] * frames_equiv
         rate = vi / sec / 1e9 if sec > 0 else 0.0
-        valu = {"bound": "valu-issue", "achieved": round(rate, 2), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                "frac": round(rate / VALU_PEAK_GINST, 4), "lane_util": prof.get("lane_util"),
-                "effective_fp32_lane_frac": None if prof.get("lane_util") is None else round(rate / VALU_PEAK_GINST * prof["lane_util"], 4),
-                "valu_insts_per_launch": int(vi), "salu_insts_per_launch": int(prof.get("salu_insts_per_frame", 0) * frames_equiv), "source": prof["file"],
-                "note": "SQ_INSTS_VALU per frame from the committed rocprofv3 --pmc pass of this command / kernel time measured in this run; peak = 1024 SIMDs x "
-                        "2.4 GHz / 2 clk per wave64 v_fma/v_add/v_mul, as measured (profiles/r03_ubench_valu.json: 1.97 clk per instruction per SIMD with 2+ waves; "
-                        "SQ_ACTIVE_INST_VALU counts instructions, not busy time); lane_util = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64, calibrated 1.000 / 0.500 "
-                        "on full / half exec masks"}
+        valu_peak = N_SIMD * clock / VALU_CLK_PER_INST
+        si = prof.get("salu_insts_per_frame", 0.0) * frames_equiv
+        bi = prof.get("branch_insts_per_frame", 0.0) * frames_equiv
+        # issue time of everything a SIMD issues besides vector memory: vector 1.97 clk (a floor: a third of the step's vector instructions are 3.15-clk forms),
+        # scalar 3.2, branches 3.2 (not taken) .. 5.9 (taken)
+        issue_lo = (vi * VALU_CLK_PER_INST + si * 3.2 + bi * 3.2) / (N_SIMD * clock * 1e9 * sec) if sec > 0 else 0.0
+        issue_hi = (vi * 2.4 + si * 3.2 + bi * 5.9) / (N_SIMD * clock * 1e9 * sec) if sec > 0 else 0.0
+        valu = {"bound": "valu-issue", "achieved": round(rate, 2), "peak": round(valu_peak, 1), "unit": "G wave-instructions/s",
+                "frac": round(rate / valu_peak, 4), "clock_ghz": round(clock, 4), "lane_util": prof.get("lane_util"),
+                "effective_fp32_lane_frac": None if prof.get("lane_util") is None else round(rate / valu_peak * prof["lane_util"], 4),
+                "simd_issue_busy_estimate": [round(issue_lo, 3), round(issue_hi, 3)],
+                "wave_cycles_waiting_frac": prof.get("wave_cycles_waiting_frac"),
+                "valu_insts_per_launch": int(vi), "salu_insts_per_launch": int(si), "branch_insts_per_launch": int(bi), "source": prof["file"],
+                "note": "SQ_INSTS_VALU per frame from the committed rocprofv3 --pmc pass of this command / kernel time measured in this run; peak = 1024 SIMDs x the clock "
+                        "the profiled kernel ran at (GRBM_GUI_ACTIVE / 8 / duration) / 1.97 clk per wave64 v_fma/v_add/v_mul (profiles/r04_ubench_valu.txt, measured at "
+                        "the same in-kernel clock); simd_issue_busy_estimate adds the scalar and branch instructions the SIMDs issue beside them; lane_util = "
+                        "SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64, calibrated 1.000 / 0.500 on full / half exec masks"}
         if prof.get("vmem_insts_per_frame"):
             mi = prof["vmem_insts_per_frame"] * frames_equiv
             mrate = mi / sec / 1e9 if sec > 0 else 0.0
-            vmem = {"bound": "vmem-issue", "achieved": round(mrate, 3), "peak": VMEM_PEAK_GINST, "unit": "G wave-level vector-memory instructions/s",
-                    "frac": round(mrate / VMEM_PEAK_GINST, 4), "vmem_insts_per_launch": int(mi), "source": prof["file"],
-                    "note": "SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR per frame from the committed --pmc pass / kernel time measured in this run; peak = measured chip-wide "
-                            "rate of scattered dwordx4 gathers on L1-resident data (tools/ubench/ta.hip).  The traverse phase issues four such loads per step and the frame "
-                            "time moves +9.7 % per load added to the step against +0.13 % per vector-ALU instruction (profiles/r03_traverse_bound.txt): this is the roof the "
-                            "kernel sits under; L1 misses (~1.3 clk per line) come on top of the instruction rate"}
+            pair = bool(getattr(st, "node_fetch_last", 0))
+            node = min(prof.get("node_fetch_insts_per_frame", 0.0), prof["vmem_insts_per_frame"]) * frames_equiv
+            share = node / mi if mi > 0 else 0.0
+            clk_node = VMEM_CLK_NODE_PAIR if pair else VMEM_CLK_NODE_LANE
+            clk_mix = share * clk_node + (1.0 - share) * VMEM_CLK_STREAM   # clk of the pipe per instruction of this kernel's mix
+            vmem_peak = N_CU * clock / clk_mix
+            vmem = {"bound": "vmem-issue", "achieved": round(mrate, 3), "peak": round(vmem_peak, 2), "unit": "G wave-level vector-memory instructions/s",
+                    "frac": round(mrate / vmem_peak, 4), "clock_ghz": round(clock, 4), "node_fetch": "pair-cooperative" if pair else "one record per lane",
+                    "node_fetch_share_of_insts": round(share, 4), "clk_per_inst_of_the_mix": round(clk_mix, 2),
+                    "clk_per_inst": {"node fetch": clk_node, "streams": VMEM_CLK_STREAM},
+                    "ta_busy_counter": None if prof.get("ta_busy_frac") is None else round(prof["ta_busy_frac"], 4),
+                    "vmem_insts_per_launch": int(mi), "source": prof["file"],
+                    "note": "SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR per frame (committed --pmc pass) / kernel time of this run, against what a CU's vector-memory pipe takes for "
+                            "this mix: node fetches (4 per wave-step, tools/gpu_travstats.py) at the span-measured cost of their access pattern, everything else at the pipe's "
+                            "floor, times the kernel's own clock.  ta_busy_counter = TA_TA_BUSY_sum / 256 / (GRBM_GUI_ACTIVE / 8) of the profiled dispatches (0.965-0.98 on the "
+                            "saturated micro-benchmark).  Reading (DESIGN.md section 6): with one record per lane the pipe is the busiest unit of the chip, ~0.8; the "
+                            "SIMDs' issue is ~0.7-0.8 beside it; waves spend half their cycles in s_waitcnt.  Neither is saturated: a wave's step is a serial chain of "
+                            "fetch, wait and ~160 instructions at >= 4.5 clk each, and four waves per SIMD overlap those chains to ~80 % of the busier unit"}
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_measured_in_run": False,
                 "traffic_source": None if traffic is None else f"{prof['file']} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled by this run's launch; {prof.get('traffic_note', '')})",
                 "stale_profile": stale,
-                "kernel": "pt_render_wgwf<false, false>", "kernel_ms_avg": round(kernel_ms, 4),
+                "kernel": "pt_render_wgwf<false, %s, %s>" % ("true" if scene.get("bvh_kind", "").startswith("chain") else "false", "true" if getattr(st, "node_fetch_last", 0) else "false"),
+                "kernel_ms_avg": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes, "frames_per_launch": round(frames_per_launch, 3),
-                "note": "a per-lane BVH gather: bound by the CUs' vector-memory instruction rate, not by HBM (DESIGN.md section 6); see roofline_vmem"}
+                "note": "a per-lane BVH gather with branchy scalar FP32: not HBM-bound (DESIGN.md section 6); the units that are busy are the CUs' vector-memory "
+                        "pipes and the SIMDs' instruction issue: roofline_vmem, roofline_valu"}
     # the two kernels of the path that ARE HBM-bound, timed in this run by HIP events on the launch stream
     aux = None
     if world == 1 and RENDERER_FACTORY is None:

@@ -3,7 +3,7 @@
 # Outputs land in gpurun_out/prof_<tag>/; tools/summarize_profile.py turns them into profiles/<tag>_*.
 # Counters are collected in their own runs (never together with --sys-trace etc.), as the pool requires.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
@@ -19,6 +19,11 @@ echo "pmc sq2 done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -- $CMD > $OUT/pmc_tcc.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- $CMD > $OUT/pmc_grbm.log 2>&1
+# the clock the kernel ran at (GRBM_GUI_ACTIVE / 8 / duration) and how long its CUs' vector-memory pipes had work (TA_TA_BUSY, summed over the 256 TAs), one pass
+rocprofv3 --pmc GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum --output-format csv -d $OUT/pmc_grbm -- $CMD > $OUT/pmc_grbm.log 2>&1
 echo "pmc mem done"
+# traversal statistics of the same config (wave-steps = node fetches / 4, lanes and lines per step): the -DGLRTX_TRAV_STATS build, 8 frames in one launch
+if [ -f opengl-raytracer_amd/lib/libglrtx_stats.so ]; then
+  GLRTX_TRAVSTATS_JSON=$OUT/travstats.json timeout -k 10 300 python3 tools/gpu_travstats.py $CFG 8 > $OUT/travstats.txt 2>&1 || echo "travstats failed"
+fi
 find $OUT -name "*.csv" | head -50

@@ -90,6 +90,9 @@ if main:
         hh.update(f.read_bytes())
     summ = {"kernel": main[0], "source": f"profiles/{tag}_pmc.json", "frames_per_launch": FRAMES, "kernel_source_sha16": hh.hexdigest()[:16],
             **code_object_registers(main[0])}
+    if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
+        # cycles the 256 CUs' address / L1 front ends had work, over the kernel's cycles: reads 0.965-0.98 on the saturated micro-benchmark (profiles/r04_ta_counters.json)
+        summ["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / 256.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
     if "clock_ghz" in m:
         summ["clock_ghz"] = m["clock_ghz"]
         summ["clock_note"] = ("GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same dispatch (rocprofv3 --pmc GRBM_GUI_ACTIVE pass, median over its launches): the clock the "
