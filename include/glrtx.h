@@ -55,7 +55,7 @@ extern "C" {
 #define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
 #define GLRTX_ENOMEM (-5)
 
-#define GLRTX_ABI_VERSION 7
+#define GLRTX_ABI_VERSION 8
 
 typedef struct glrtx_ctx glrtx_ctx;
 
@@ -95,6 +95,10 @@ typedef struct glrtx_stats {
     int32_t node_fetch_last; /* wavefront kernel, last launch: 1 = pair-cooperative node fetch (large trees), 0 = one record per lane (was reserved0) */
     uint64_t fallback_launches; /* launches since reset_stats that ran on the persistent megakernel although variant 2 was selected:
                                    ~2x slower per ray and without frames in flight -- visible here instead of silent */
+    int32_t pipe_slots;         /* overlapped single-frame launches (glrtx_render): internal slots the last such launch could choose from -- GLRTX_PIPE_SLOTS
+                                   (default 6), less when the memory budget or a failed allocation says so, 0 when such launches run un-piped */
+    int32_t pipe_resident_max;  /* ... and the most of them that had a render kernel on the device at once (counted when a launch is issued) since
+                                   reset_stats: 1 means consecutive launches did not overlap, whatever the reason (queue mapping, a caller that syncs) */
 } glrtx_stats;
 
 /* glrtx_stats.fallback_last: the wavefront kernel packs depth and sample index into one word of its path state */

@@ -514,7 +514,49 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // Per pixel the additions happen in the same order (the plane-accumulation passes run on the context's stream, in launch order).
     const size_t plane_bytes = (size_t)a.pitch_f4 * (size_t)c->owned_rows * sizeof(float4);
     const bool piped = n_frames == 1 && c->pipeline && p->n_samples >= 1 && (size_t)p->n_samples * plane_bytes <= ((size_t)1 << 30);
-    glrtx_ctx::PipeSlot *slot = piped ? &c->pipe[c->pipe_next++ % c->pipe_slots] : nullptr;
+    // Which slot, and how many there may be.  A slot owns path state, per-workgroup queues and sample planes of its own (~0.8 GB at 1080p): the slots are charged to
+    // the same memory budget as the frames in flight (kFramesBudgetGiB, split between the members of a group that share this GPU), a slot whose buffers cannot
+    // be allocated is given up -- the launch then runs un-piped on the context's stream instead of failing -- and among the slots in use the next one whose
+    // previous launch has completed is taken (round robin only when none has), so that a launch never queues behind a busy slot while an idle one exists.
+    glrtx_ctx::PipeSlot *slot = nullptr;
+    int pipe_busy = 0;
+    if (piped) {
+        const size_t per_slot = kWfStatePlanes * ids * sizeof(float4) + (size_t)c->n_cu * GLRTX_WGWF_WAVES * kWgQueueF4 * sizeof(float4) + (size_t)p->n_samples * plane_bytes;
+        size_t budget = (size_t)kFramesBudgetGiB << 30;
+        if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
+        budget /= (size_t)std::max(c->budget_share, 1);
+        const unsigned allowed = (unsigned)std::min<size_t>(c->pipe_slots, budget / std::max<size_t>(per_slot, 1));
+        c->st.pipe_slots = (int32_t)allowed;
+        if (allowed >= 1) {
+            unsigned pick = c->pipe_next % allowed;
+            for (unsigned k = 0; k < allowed; k++) {
+                glrtx_ctx::PipeSlot &o = c->pipe[(c->pipe_next + k) % allowed];
+                if (!o.used || hipEventQuery(o.acc_done) == hipSuccess) { pick = (c->pipe_next + k) % allowed; break; }
+            }
+            (void)hipGetLastError();
+            c->pipe_next = pick + 1;
+            slot = &c->pipe[pick];
+            for (unsigned k = 0; k < allowed; k++)
+                if (k != pick && c->pipe[k].used && hipEventQuery(c->pipe[k].render_done) == hipErrorNotReady) pipe_busy++;
+            (void)hipGetLastError();
+            // the slot's buffers, before anything depends on them
+            if (ensure(c, slot->state, kWfStatePlanes * ids * sizeof(float4)) != GLRTX_OK ||
+                ensure(c, slot->planes, (size_t)std::max(p->n_samples, 1) * plane_bytes) != GLRTX_OK ||
+                ensure(c, slot->queues, (size_t)c->n_cu * GLRTX_WGWF_WAVES * kWgQueueF4 * sizeof(float4)) != GLRTX_OK) {
+                (void)hipGetLastError();
+                c->err.clear();
+                if (slot->used) (void)hipEventSynchronize(slot->acc_done);
+                dev_free(slot->state); dev_free(slot->planes); dev_free(slot->queues);
+                slot->used = false;
+                c->pipe_slots = pick;            // the slots in front of this one keep their buffers and stay in use
+                if (pick == 0) c->pipeline = false;
+                c->st.pipe_slots = (int32_t)pick;
+                slot = nullptr;
+                pipe_busy = 0;
+            }
+        }
+    }
+    if (slot) c->st.pipe_resident_max = std::max<int32_t>(c->st.pipe_resident_max, pipe_busy + 1);
     DevBuf &stateBuf = slot ? slot->state : c->wfState;
     DevBuf &queueBuf = slot ? slot->queues : c->wfQ;
     DevBuf &planeBuf = slot ? slot->planes : c->wfPlanes;
@@ -580,13 +622,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // against the earlier scheme (GLRTX_PIPE_SHARE=2: a launch that finds another one rendering takes half of the slots, and all its
     // workgroups finish together), profiles/r03_ab_pipeline.txt.
     int share = 1;
-    if (slot && c->pipe_share > 1) {
-        int busy = 0;
-        for (auto &o : c->pipe)
-            if (&o != slot && o.used && hipEventQuery(o.render_done) == hipErrorNotReady) busy++;
-        (void)hipGetLastError();
-        if (busy > 0) share = c->pipe_share;
-    }
+    if (slot && c->pipe_share > 1 && pipe_busy > 0) share = c->pipe_share;
     // paths kept alive per workgroup: 1024, less when the launch cannot give every resident workgroup that many pixels
     const int resident = std::max(1, per_cu / share) * c->n_cu;
     const size_t work = total * (size_t)n_frames;
@@ -703,8 +739,19 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
             return GLRTX_EDEVICE;
         }
     c->stream = c->own_stream;
+    // The slots' streams are created at a priority of their own (GLRTX_PIPE_PRIORITY: high (default) | normal | low).  The runtime maps the streams of a process onto a
+    // few hardware queues PER PRIORITY LEVEL, and streams that share a queue run one after the other: at the default priority the slots share those queues with
+    // whatever streams the host application creates, and two caller streams kept busy with small kernels took one launch per frame from 1.25 to 2.7 ms
+    // (tests/test_gpu_parity.py::test_overlapped_launches_next_to_a_callers_own_streams).  At a priority of their own the slots are mapped among themselves.
+    int prio_least = 0, prio_greatest = 0, prio = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    {
+        const char *v = std::getenv("GLRTX_PIPE_PRIORITY");
+        const std::string m = v ? v : "high";
+        prio = m == "low" ? prio_least : (m == "normal" ? 0 : prio_greatest);
+    }
     for (auto &sl : c->pipe)
-        if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreateWithFlags(&sl.render_done, hipEventDisableTiming)) != hipSuccess ||
+        if ((e = hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio)) != hipSuccess || (e = hipEventCreateWithFlags(&sl.render_done, hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&sl.acc_done, hipEventDisableTiming)) != hipSuccess || (e = hipMalloc(&sl.work.p, 64)) != hipSuccess) {
             fail(nullptr, GLRTX_EDEVICE, "context setup failed: %s", hipGetErrorString(e));
             glrtx_destroy(c);
@@ -1206,7 +1253,7 @@ int glrtx_reset_stats(glrtx_ctx *c) {
     if (int rc = glrtx_sync(c)) return rc;
     HIP_TRY(c, hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long)));
     c->counters_host[0] = c->counters_host[1] = 0; c->counters_stale = false;
-    c->st.rays = 0; c->st.rays_untraced = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f; c->st.fallback_launches = 0;
+    c->st.rays = 0; c->st.rays_untraced = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f; c->st.fallback_launches = 0; c->st.pipe_resident_max = 0;
     return GLRTX_OK;
 }
 

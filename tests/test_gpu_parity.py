@@ -708,6 +708,56 @@ def test_render_calls_return_before_the_device_is_done(gpu_device):
     assert st.kernel_launches == 40 and st.kernel_ms_total > 0.02
 
 
+def test_overlapped_launches_next_to_a_callers_own_streams(gpu_device, monkeypatch):
+    """One launch per frame (the reference's cadence) while the caller keeps two more streams of its own busy with small kernels between the render calls: the
+    image is the quiet run's bit for bit, consecutive launches still overlap on the device (glrtx_stats.pipe_resident_max: how many internal slots had a render
+    kernel running at once), and the time per frame stays within 15 % of the quiet run's.  Then the slots are squeezed by the memory budget: fewer slots,
+    none at all (un-piped launches on the context's stream) -- the same image every time, never a failed render."""
+    import time
+    import torch
+    d = gpu_device
+    scene, params = scenes.config_headline()
+    d.upload_scene(scene); d.set_partition(0, 1, 16); d.resize(params["width"], params["height"]); d.count_rays(False)
+
+    caller_streams = [torch.cuda.Stream() for _ in range(2)]
+    caller_data = [torch.zeros(1 << 16, device="cuda") for _ in caller_streams]
+
+    def run(n, busy):
+        d.clear(); d.reset_stats()
+        streams, xs = (caller_streams, caller_data) if busy else ([], [])
+        d.sync(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for f in range(n):
+            d.render(dict(params, seed=host.frame_seed(f)))
+            for st_, x in zip(streams, xs):
+                with torch.cuda.stream(st_):
+                    x.add_(1.0)
+        d.sync(); torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3, d.read_accum(), d.stats()
+
+    run(8, False)  # every slot has its buffers
+    run(8, True)   # ... and the caller's kernel is loaded (loading a code object stalls the device once: not what is measured)
+    ms_q, img_q, st_q = run(40, False)
+    ms_b, img_b, st_b = run(40, True)
+    assert_bit_equal(img_b, img_q, "busy caller streams")
+    assert st_q.pipe_slots == 6 and st_q.pipe_resident_max >= 2, (st_q.pipe_slots, st_q.pipe_resident_max)
+    assert st_b.pipe_resident_max >= 2, st_b.pipe_resident_max
+    assert ms_b <= 1.15 * ms_q, (ms_b, ms_q)
+    # ~0.8 GB per slot at 1080p: a 2 GiB budget leaves two slots, 512 MiB none
+    monkeypatch.setenv("GLRTX_FRAMES_BUDGET_MB", "2048")
+    _, img2, st2 = run(12, False)
+    assert_bit_equal(img2, run(12, False)[1], "two slots, repeated")
+    assert st2.pipe_slots == 2 and st2.pipe_resident_max <= 2
+    monkeypatch.setenv("GLRTX_FRAMES_BUDGET_MB", "512")
+    _, img0, st0 = run(12, False)
+    assert st0.pipe_slots == 0 and st0.pipe_resident_max == 0 and st0.kernel_launches == 12
+    monkeypatch.delenv("GLRTX_FRAMES_BUDGET_MB")
+    _, img6, st6 = run(12, False)
+    assert st6.pipe_slots == 6
+    assert_bit_equal(img0, img6, "un-piped launches")
+    assert_bit_equal(img2, img6, "two slots")
+
+
 @BOTH_INSTANTIATIONS
 @pytest.mark.parametrize("cfg,kw", [("c2", dict(width=320, height=200, max_depth=8, n_samples=1)), ("c2", dict(width=97, height=61, max_depth=5, n_samples=3)),
                                     ("c5", dict(width=256, height=144, max_depth=4, n_samples=1, n=4000))])

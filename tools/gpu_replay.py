@@ -70,6 +70,13 @@ if os.environ.get("GLRTX_REPLAY_ORDERS", "1") != "0":
         "direction octant, then origin cell 16^3": octant * (1 << 12) + morton(16, 4),
         "direction octant, then origin cell 64^3": octant * (1 << 18) + morton(64, 6),
     }
+    # the two rays of one bounce -- the path's next ray and its shadow ray -- leave from the same point: put them next to each other (groups in recorded order)
+    ob = np.ascontiguousarray(rays[:, 0:3]).view(np.uint32).astype(np.uint64)
+    okey = (ob[:, 0] * np.uint64(0x9E3779B97F4A7C15) ^ ob[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) ^ ob[:, 2] * np.uint64(0x165667B19E3779F9))
+    _, first, inv = np.unique(okey, return_index=True, return_inverse=True)
+    keys["rays of one origin adjacent (a path's next ray and its shadow ray), groups as recorded"] = first[inv].astype(np.int64)
+    if os.environ.get("GLRTX_REPLAY_ONLY_ORIGIN"):
+        keys = {k: v for k, v in keys.items() if k.startswith("as recorded") or k.startswith("rays of one origin")}
     base_ms = None
     for name, key in keys.items():
         # stable sort by (trip, key); invalid records (skip markers) keep their relative place at the end of their trip
