@@ -521,14 +521,14 @@ def main(argv=None):
         if prof.get("vmem_insts_per_frame"):
             mi = prof["vmem_insts_per_frame"] * frames_equiv
             mrate = mi / sec / 1e9 if sec > 0 else 0.0
-            pair = bool(getattr(st, "node_fetch_last", 0))
+            nf = int(getattr(st, "node_fetch_last", 0))  # 0 one record per lane, 1 pair-cooperative, 2 the two in alternate steps
             node = min(prof.get("node_fetch_insts_per_frame", 0.0), prof["vmem_insts_per_frame"]) * frames_equiv
             share = node / mi if mi > 0 else 0.0
-            clk_node = VMEM_CLK_NODE_PAIR if pair else VMEM_CLK_NODE_LANE
+            clk_node = (VMEM_CLK_NODE_LANE, VMEM_CLK_NODE_PAIR, 0.5 * (VMEM_CLK_NODE_LANE + VMEM_CLK_NODE_PAIR))[nf]
             clk_mix = share * clk_node + (1.0 - share) * VMEM_CLK_STREAM   # clk of the pipe per instruction of this kernel's mix
             vmem_peak = N_CU * clock / clk_mix
             vmem = {"bound": "vmem-issue", "achieved": round(mrate, 3), "peak": round(vmem_peak, 2), "unit": "G wave-level vector-memory instructions/s",
-                    "frac": round(mrate / vmem_peak, 4), "clock_ghz": round(clock, 4), "node_fetch": "pair-cooperative" if pair else "one record per lane",
+                    "frac": round(mrate / vmem_peak, 4), "clock_ghz": round(clock, 4), "node_fetch": ("one record per lane", "pair-cooperative", "pair-cooperative and one record per lane in alternate steps")[nf],
                     "node_fetch_share_of_insts": round(share, 4), "clk_per_inst_of_the_mix": round(clk_mix, 2),
                     "clk_per_inst": {"node fetch": clk_node, "streams": VMEM_CLK_STREAM},
                     "ta_busy_counter": None if prof.get("ta_busy_frac") is None else round(prof["ta_busy_frac"], 4),
@@ -543,7 +543,7 @@ def main(argv=None):
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_measured_in_run": False,
                 "traffic_source": None if traffic is None else f"{prof['file']} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled by this run's launch; {prof.get('traffic_note', '')})",
                 "stale_profile": stale,
-                "kernel": "pt_render_wgwf<false, %s, %s>" % ("true" if scene.get("bvh_kind", "").startswith("chain") else "false", "true" if getattr(st, "node_fetch_last", 0) else "false"),
+                "kernel": "pt_render_wgwf<false, %s, %d>" % ("true" if scene.get("bvh_kind", "").startswith("chain") else "false", int(getattr(st, "node_fetch_last", 0))),
                 "kernel_ms_avg": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes, "frames_per_launch": round(frames_per_launch, 3),
                 "note": "a per-lane BVH gather with branchy scalar FP32: not HBM-bound (DESIGN.md section 6); the units that are busy are the CUs' vector-memory "

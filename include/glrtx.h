@@ -92,7 +92,8 @@ typedef struct glrtx_stats {
     int32_t variant_last;   /* kernel the last launch actually ran: 2 workgroup-local wavefront, 1 persistent megakernel, 0 tile megakernel */
     int32_t fallback_last;  /* 0, or why the last launch left the selected wavefront kernel (GLRTX_FALLBACK_* bits) */
     float resolve_ms_last;  /* device time of the last resolve kernel (glrtx_resolve_rgba8), without the copy to the host */
-    int32_t node_fetch_last; /* wavefront kernel, last launch: 1 = pair-cooperative node fetch (large trees), 0 = one record per lane (was reserved0) */
+    int32_t node_fetch_last; /* wavefront kernel, last launch: 0 = one record per lane, 1 = pair-cooperative node fetch (large trees), 2 = the two in alternate
+                                steps (small trees) -- all bit-identical; GLRTX_PAIR_FETCH=0/1/2 forces one (was reserved0) */
     uint64_t fallback_launches; /* launches since reset_stats that ran on the persistent megakernel although variant 2 was selected:
                                    ~2x slower per ray and without frames in flight -- visible here instead of silent */
     int32_t pipe_slots;         /* overlapped single-frame launches (glrtx_render): internal slots the last such launch could choose from -- GLRTX_PIPE_SLOTS

@@ -491,7 +491,7 @@ int ensure(glrtx_ctx *c, DevBuf &b, size_t bytes) {
 }
 
 #ifdef GLRTX_RAY_LOG
-struct DbgLastLaunch { KernelArgs a; WfArgs w; int lds, grid; float4 *queues; bool pair; } g_dbg_last;  // what the last pt_render_wgwf launch was given (replay)
+struct DbgLastLaunch { KernelArgs a; WfArgs w; int lds, grid; float4 *queues; int fetch; } g_dbg_last;  // what the last pt_render_wgwf launch was given (replay)
 DevBuf g_dbg_log_rays, g_dbg_log_trips;
 #endif
 
@@ -598,18 +598,23 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const int lds = lds_base + n_top * 64;
     a.sc.n_top = n_top;
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
-    // six instantiations: ray counting on/off x (list scan of a vine (brute-force) tree | tree traversal with one record per lane | tree traversal with the
-    // pair-cooperative node fetch).  The pair fetch trades 25 vector-ALU instructions per step for a third less time in the CU's vector-memory pipe
+    // eight instantiations: ray counting on/off x (list scan of a vine (brute-force) tree | tree traversal with one record per lane | with the pair-cooperative
+    // node fetch | with the two in alternate steps).  The pair fetch trades 25 vector-ALU instructions per step for a third less time in the CU's vector-memory pipe
     // (trav_asm.hip.h): it pays where a wave's lanes are spread over many records -- large trees, incoherent rays: config 5 (100 k triangles) -9 % per frame --
     // and costs ~1 % where they share the top of a small tree (headline, 10 k triangles: the step is paced by instruction issue there), profiles/r04_ab_pair_fetch.txt.
     // Picked by the size of the record array; GLRTX_PAIR_FETCH=0/1 overrides.  Both forms are bit-identical (same IEEE operations on the same record).
     using Kernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *);
     const bool vine = c->sc.n_vine > 0;
-    bool pair = !vine && (size_t)c->n_fork + (size_t)c->st.n_tri >= (size_t)kPairFetchMinRecords;
-    if (const char *v = std::getenv("GLRTX_PAIR_FETCH")) pair = !vine && std::atoi(v) != 0;
-    c->st.node_fetch_last = pair ? 1 : 0;
-    const Kernel kernel = c->count_rays ? (vine ? (Kernel)pt_render_wgwf<true, true> : pair ? (Kernel)pt_render_wgwf<true, false, true> : (Kernel)pt_render_wgwf<true, false>)
-                                        : (vine ? (Kernel)pt_render_wgwf<false, true> : pair ? (Kernel)pt_render_wgwf<false, false, true> : (Kernel)pt_render_wgwf<false, false>);
+    // ... and on small trees, where neither form wins, the two in alternate steps: the pipe is the busier unit in one step, the SIMDs in the next: -1.0 .. -1.3 %
+    // (every mix tried: pair-lane, lane-pair, 2:1, 1:2; config 5 prefers the pure pair form by 3-5 %).
+    int fetch = vine ? 0 : ((size_t)c->n_fork + (size_t)c->st.n_tri >= (size_t)kPairFetchMinRecords ? 1 : 2);
+    if (const char *v = std::getenv("GLRTX_PAIR_FETCH")) fetch = vine ? 0 : std::max(0, std::min(2, std::atoi(v)));
+    c->st.node_fetch_last = fetch;
+    const bool cr = c->count_rays;
+    const Kernel kernel = vine ? (cr ? (Kernel)pt_render_wgwf<true, true> : (Kernel)pt_render_wgwf<false, true>)
+                        : fetch == 2 ? (cr ? (Kernel)pt_render_wgwf<true, false, 2> : (Kernel)pt_render_wgwf<false, false, 2>)
+                        : fetch == 1 ? (cr ? (Kernel)pt_render_wgwf<true, false, 1> : (Kernel)pt_render_wgwf<false, false, 1>)
+                                     : (cr ? (Kernel)pt_render_wgwf<true, false, 0> : (Kernel)pt_render_wgwf<false, false, 0>);
     if (lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     int per_cu = 0;
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockThreads, lds));
@@ -667,7 +672,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), lds, rstream, a, w, workPtr, (float4 *)queueBuf.p);
     HIP_TRY(c, hipGetLastError());
 #ifdef GLRTX_RAY_LOG
-    g_dbg_last = {a, w, lds, grid, (float4 *)queueBuf.p, pair};
+    g_dbg_last = {a, w, lds, grid, (float4 *)queueBuf.p, fetch};
 #endif
     HIP_TRY(c, hipEventRecord(rec->evm, rstream));
     if (slot) {  // the context's stream -- where the caller's own work, the resolve pass and the next accumulation are ordered -- takes over
@@ -1330,9 +1335,9 @@ int glrtx_debug_ray_log_replay(glrtx_ctx *c, int reps, double out[4]) {
     DbgLastLaunch L = g_dbg_last;
     L.w.suspend_max = 0;
     using RKernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *, const float4 *, const uint2 *, int);
-    bool pair = L.pair;
-    if (const char *v = std::getenv("GLRTX_REPLAY_PAIR_FETCH")) pair = std::atoi(v) != 0;  // the same log through the other form of the node fetch
-    const RKernel rk = pair ? (RKernel)pt_replay_traverse<true> : (RKernel)pt_replay_traverse<false>;
+    int fetch = L.fetch;
+    if (const char *v = std::getenv("GLRTX_REPLAY_PAIR_FETCH")) fetch = std::max(0, std::min(2, std::atoi(v)));  // the same log through another form of the node fetch
+    const RKernel rk = fetch == 2 ? (RKernel)pt_replay_traverse<2> : fetch == 1 ? (RKernel)pt_replay_traverse<1> : (RKernel)pt_replay_traverse<0>;
     if (L.lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
     int per_cu = 0;
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rk, kBlockThreads, L.lds));

@@ -506,7 +506,8 @@ struct StepTiming { unsigned t = 0, w = 0, n = 0; };
 #define GLRTX_TS_OPERANDS
 #define GLRTX_TS_CLOBBERS
 #endif
-template <bool PAIR>
+// FETCH: 0 one record per lane, 1 pair-cooperative, 2 the two forms in alternate steps (pair first) -- see trav_asm.hip.h and launch_wgwf (glrtx.hip)
+template <int FETCH>
 DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) {
     unsigned long long s_entry, s_act, s_leaf, s_bl, s_br, s_pop, s_tmp;
     const unsigned stk = (unsigned)(uintptr_t)stack;
@@ -515,7 +516,24 @@ DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) 
     // pair-cooperative fetch: which 16-byte pieces a lane reads of the even lane's record (0 and 2, odd lanes 1 and 3) and of the odd lane's (1 and 3, odd lanes 0 and 2)
     const unsigned par16 = (threadIdx.x & 1u) << 4;
     const unsigned bias_e = sc.node_bias + par16, bias_o = sc.node_bias + 16u - par16;
-    if (PAIR) {
+    if (FETCH == 2) {  // pair, lane, pair, lane, ...: the pipe and the SIMDs take turns at being the busier unit (-1.3 % on the 10 k-triangle tree)
+        asm volatile(
+            "s_mov_b64 %[entry], exec\n\t"
+            "s_mov_b64 %[act], exec\n\t"
+            GLRTX_ASM_SET_VBASE
+            "v_bfrev_b32 v[GLRTX_VB+11], 1\n\t"
+            GLRTX_REP(GLRTX_STEPS_PER_TRIP_HALF, GLRTX_TRAV_STEP_ASM_PAIR GLRTX_TRAV_STEP_ASM_LANE)
+            "99:\n\t"
+            "s_mov_b64 exec, %[entry]"
+            : [th] "+&v"(T.h.t), [tri] "+&v"(T.h.tri), [hu] "+&v"(T.h.u), [hv] "+&v"(T.h.v), [cur] "+&v"(T.cur), [sp] "+&v"(T.sp),
+              [entry] "=&s"(s_entry), [act] "=&s"(s_act), [leaf] "=&s"(s_leaf), [bl] "=&s"(s_bl), [br] "=&s"(s_br), [pop] "=&s"(s_pop), [tmp] "=&s"(s_tmp) GLRTX_TS_OPERANDS
+            : [ox] "v"(T.ox), [oy] "v"(T.oy), [oz] "v"(T.oz), [dx] "v"(T.dx), [dy] "v"(T.dy), [dz] "v"(T.dz), [ix] "v"(T.ix), [iy] "v"(T.iy), [iz] "v"(T.iz),
+              [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [bias] "s"(sc.node_bias), [eps] "s"(PT_EPS), [big] "s"(0x1p126f),
+              [odd] "s"(0xAAAAAAAAAAAAAAAAull), [biase] "v"(bias_e), [biaso] "v"(bias_o)
+            : "vcc", "scc", "memory", GLRTX_ASM_VCLOBBERS_PAIR GLRTX_TS_CLOBBERS);
+        return;
+    }
+    if (FETCH == 1) {
         asm volatile(
             "s_mov_b64 %[entry], exec\n\t"
             "s_mov_b64 %[act], exec\n\t"
@@ -1660,7 +1678,7 @@ __device__ unsigned g_ray_log_trips;        // trips appended
 // again in round 2, after the kernel had lost its spills, it bought nothing and its 8 registers were freed; that A/B table was not kept.)
 DEV int wgwf_suspend_max();  // WfArgs::suspend_max of the running pt_render_wgwf launch, from its kernarg segment (defined below)
 
-template <bool VINE, bool PAIR>
+template <bool VINE, int FETCH>
 DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, [[maybe_unused]] const float4 *lds_top, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned *light_bits, unsigned long long &rays, float4 *suspend_area) {
     const int lane = threadIdx.x & 63;
@@ -1844,9 +1862,9 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
                 if (!fin) fin = trav_step<true>(a.sc, stack, T, lds_top, n_top);
 #else
 #ifdef GLRTX_STEP_TIMING
-            trav_steps_asm<PAIR>(a.sc, stack, T, step_timing);
+            trav_steps_asm<FETCH>(a.sc, stack, T, step_timing);
 #else
-            trav_steps_asm<PAIR>(a.sc, stack, T);
+            trav_steps_asm<FETCH>(a.sc, stack, T);
 #endif
             const bool fin = T.cur == REF_FIN;
 #endif
@@ -1934,7 +1952,7 @@ DEV const WgwfKernArgs *wgwf_kernargs() {
 
 DEV int wgwf_suspend_max() { return wgwf_kernargs()->w.suspend_max; }
 
-template <bool COUNT_RAYS, bool VINE, bool PAIR = false>
+template <bool COUNT_RAYS, bool VINE, int FETCH = 0>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // LDS: materials | stack | ctl[16].  The workgroup's ray/path queues live in its private slice of a
@@ -2053,7 +2071,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
         // their loads get going earlier (measured 1-2 %)
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_TRAVERSE);
-        wg_traverse_phase<VINE, PAIR>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
+        wg_traverse_phase<VINE, FETCH>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_SHADE);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written
@@ -2091,7 +2109,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 // The traverse phase alone over a recorded log (see RayLog).  Same LDS layout, launch bounds and kernarg prefix as pt_render_wgwf (wgwf_kernargs()
 // reads WfArgs::suspend_max from the kernarg segment; the host passes 0: nothing is parked in a replay).  Hit records go where the recorded ray
 // ids point (state plane 5), shadow-ray verdicts into the LDS bits, exactly as in the render kernel; nobody reads them.
-template <bool PAIR>
+template <int FETCH>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_traverse(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues,
                                                                                       const float4 *log, const uint2 *trips, int n_trips) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -2117,7 +2135,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_tra
         if (t >= (unsigned)n_trips) break;
         const uint2 tr = trips[t];
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_TRAVERSE);
-        wg_traverse_phase<false, PAIR>(a, w, lds_root, lds_top, stack, log + 2 * (size_t)tr.x, (int)tr.y, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
+        wg_traverse_phase<false, FETCH>(a, w, lds_root, lds_top, stack, log + 2 * (size_t)tr.x, (int)tr.y, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_SHADE);
         __syncthreads();
     }

@@ -44,10 +44,19 @@
 #ifndef GLRTX_ASM_VBASE
 #define GLRTX_ASM_VBASE 96
 #endif
+static_assert(GLRTX_STEPS_PER_TRIP % 2 == 0, "the alternating form of the node fetch unrolls steps in pairs");
+#define GLRTX_STEPS_PER_TRIP_HALF_(n) GLRTX_HALF_##n
+#define GLRTX_HALF_2 1
+#define GLRTX_HALF_4 2
+#define GLRTX_HALF_6 3
+#define GLRTX_HALF_8 4
+#define GLRTX_STEPS_PER_TRIP_HALF_X(n) GLRTX_STEPS_PER_TRIP_HALF_(n)
+#define GLRTX_STEPS_PER_TRIP_HALF GLRTX_STEPS_PER_TRIP_HALF_X(GLRTX_STEPS_PER_TRIP)
 #define GLRTX_STR_(x) #x
 #define GLRTX_STR(x) GLRTX_STR_(x)
 #define GLRTX_ASM_SET_VBASE ".set GLRTX_VB, " GLRTX_STR(GLRTX_ASM_VBASE) "\n\t"
-// Both forms of the node fetch are compiled (pt_render_wgwf<*, false, PAIR>); the host picks one per scene (glrtx.hip: launch_wgwf, GLRTX_PAIR_FETCH=0/1 overrides).
+// Both forms of the node fetch are compiled, and a third that alternates them step by step (pt_render_wgwf<*, false, FETCH>); the host picks one per scene
+// (glrtx.hip: launch_wgwf; GLRTX_PAIR_FETCH=0/1/2 overrides).
 #if GLRTX_ASM_VBASE == 96
 #define GLRTX_ASM_VCLOBBERS "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117"
 #define GLRTX_ASM_VCLOBBERS_PAIR GLRTX_ASM_VCLOBBERS, "v118", "v119"

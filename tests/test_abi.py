@@ -65,7 +65,7 @@ def test_code_object_invariants():
     import sys
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_report.py"), "--check"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    for inst in ("false, false, false", "false, false, true", "false, true, false"):
+    for inst in ("false, false, 0", "false, false, 1", "false, false, 2", "false, true, 0"):
         rows = [ln.replace(f"glrtx::pt_render_wgwf<{inst}>", "K").split() for ln in r.stdout.splitlines() if ln.startswith(f"glrtx::pt_render_wgwf<{inst}>")]
         assert rows, r.stdout
         vgpr, agpr, sgpr, vspill, sspill, scratch = (int(v) for v in rows[0][1:7])

@@ -54,8 +54,8 @@ def test_bench_prints_one_contract_json_line():
         # ... the pipe's share follows from the instruction mix: node fetches (4 per wave-step) at their pattern's cost, the streams at the floor
         assert 0.5 < vm["node_fetch_share_of_insts"] < 0.95 and 16.0 < vm["clk_per_inst_of_the_mix"] < 37.5
         # ... and the derived occupancy agrees with the hardware's own busy counter of the profiled dispatches (headline, one record per lane: 0.76-0.86 on
-        # every box so far) -- the band is what a run may drift from its committed profile, not a free parameter
-        assert 0.6 < vm["frac"] < 0.95, vm
+        # every box so far; the alternating fetch of the default build: ~0.7) -- the band is what a run may drift from its committed profile, not a free parameter
+        assert 0.55 < vm["frac"] < 0.95, vm
         if vm["ta_busy_counter"] is not None:
             assert abs(vm["frac"] - vm["ta_busy_counter"]) < 0.12, vm
         lo, hi = rv["simd_issue_busy_estimate"]

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 from fuzz_scenes import CASES, case_scene_and_params, fuzz_scene as _scene
 
 
-@pytest.mark.parametrize("pair_fetch", ["0", "1"], ids=["lane-fetch", "pair-fetch"])  # both forms of the wavefront kernel's node fetch (GLRTX_PAIR_FETCH)
+@pytest.mark.parametrize("pair_fetch", ["0", "1", "2"], ids=["lane-fetch", "pair-fetch", "alternating-fetch"])  # every form of the wavefront kernel's node fetch (GLRTX_PAIR_FETCH)
 @pytest.mark.parametrize("case", CASES, ids=[f"seed{c[0]}" for c in CASES])
 def test_fuzz_scene_matches_oracle(gpu_device, monkeypatch, case, pair_fetch):
     from oracle import pt_oracle
@@ -55,7 +55,7 @@ def test_fuzz_random_parameters(gpu_device, monkeypatch, seed):
     """Parameters drawn from the seed: triangle count, tree builder, image size, depth, samples, lens, flags -- and the form of the node fetch."""
     from oracle import pt_oracle
     rng = np.random.default_rng(seed)
-    monkeypatch.setenv("GLRTX_PAIR_FETCH", "01"[seed & 1])
+    monkeypatch.setenv("GLRTX_PAIR_FETCH", "012"[seed % 3])
     flags = {k: bool(rng.integers(0, 4) == 0) for k in ("duplicates", "degenerate", "axis_aligned")}
     n_tri = int(rng.integers(1, 400))
     bvh = ("sah", "lbvh", "chain")[int(rng.integers(0, 3))] if n_tri < 120 else ("sah", "lbvh")[int(rng.integers(0, 2))]

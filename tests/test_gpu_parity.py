@@ -16,9 +16,10 @@ TOL = 1e-4  # north_star: "pixels within 1e-4 of the GL reference"
 # The render kernels exist in two compilations: with ray counting (what the ray-count assertions need) and without (what bench.py
 # TIMES: pt_render_wgwf<false, *>, its own register allocation around the hand-written inline asm).  The image tests run on both.
 BOTH_INSTANTIATIONS = pytest.mark.parametrize("count_rays", [True, False], ids=["counting", "timed"])
-# ... and, since round 4, with two forms of the traversal step's node fetch: one record per lane, and pair-cooperative (the two lanes of a pair fetch one
-# lane's record between them and exchange the pieces; the host picks it for large trees).  GLRTX_PAIR_FETCH forces either; the image tests run on both.
-BOTH_NODE_FETCHES = pytest.mark.parametrize("pair_fetch", ["0", "1"], ids=["lane-fetch", "pair-fetch"])
+# ... and, since round 4, with three forms of the traversal step's node fetch: one record per lane, pair-cooperative (the two lanes of a pair fetch one
+# lane's record between them and exchange the pieces; the host picks it for large trees), and the two in alternate steps (small trees).  GLRTX_PAIR_FETCH
+# forces one; the image tests run on all three.
+BOTH_NODE_FETCHES = pytest.mark.parametrize("pair_fetch", ["0", "1", "2"], ids=["lane-fetch", "pair-fetch", "alternating-fetch"])
 
 
 def gpu_render(d, scene, params, frames=None, count_rays=True):
@@ -64,7 +65,7 @@ def test_hip_bit_exact_vs_oracle(gpu_device, monkeypatch, cfg, kw):
     scene, params = scenes.CONFIGS[cfg](**kw)
     ref, ref_rays = pt_oracle.render(scene, params)
     fetches = set()
-    for pair_fetch in ("0", "1", None):  # both forms of the node fetch forced, then the host's own choice
+    for pair_fetch in ("0", "1", "2", None):  # every form of the node fetch forced, then the host's own choice
         if pair_fetch is None:
             monkeypatch.delenv("GLRTX_PAIR_FETCH")
         else:
@@ -77,11 +78,11 @@ def test_hip_bit_exact_vs_oracle(gpu_device, monkeypatch, cfg, kw):
         assert st.rays == 0
         assert_bit_equal(acc, ref, f"{cfg} {kw}, kernel without ray counting, pair_fetch={pair_fetch}")
     if "chain" not in str(scene.get("bvh_kind", "")):
-        assert fetches == {0, 1}, "both forms of the node fetch ran"
+        assert fetches == {0, 1, 2}, "every form of the node fetch ran"
     if cfg == "c5":
         assert st.node_fetch_last == 1, "100 k triangles: the host picks the pair-cooperative fetch by itself"
     if cfg == "headline":
-        assert st.node_fetch_last == 0
+        assert st.node_fetch_last == 2, "10 k triangles: the two forms in alternate steps"
 
 
 def test_dof_and_seed_sweep_vs_oracle(gpu_device):
