@@ -104,6 +104,7 @@ if main:
     if ts.exists():
         t = json.loads(ts.read_text())
         shutil.copy(ts, dst / f"{tag}_travstats.json") if ts.parent != dst else None
+    if ts.exists() and t.get("wave_iters", 0) > 0:  # (the list scan of a vine tree has no stepping block: no node fetches)
         summ["wave_steps_per_frame"] = t["wave_iters"] / t["frames"]
         summ["node_fetch_insts_per_frame"] = 4.0 * t["wave_iters"] / t["frames"]
         summ["lanes_per_wave_step"] = t["lane_iters"] / t["wave_iters"]
