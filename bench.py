@@ -532,6 +532,10 @@ def main(argv=None):
                     "node_fetch_share_of_insts": round(share, 4), "clk_per_inst_of_the_mix": round(clk_mix, 2),
                     "clk_per_inst": {"node fetch": clk_node, "streams": VMEM_CLK_STREAM},
                     "ta_busy_counter": None if prof.get("ta_busy_frac") is None else round(prof["ta_busy_frac"], 4),
+                    # the same ratio for the PROFILED dispatches (their own duration): what ta_busy_counter is to be compared with -- `frac` moves with this run's
+                    # launch shape (a launch of few frames carries more of the launch's fixed cost per frame)
+                    "frac_of_profiled_dispatches": None if not prof.get("kernel_ms_per_frame_profiled") else
+                        round(prof["vmem_insts_per_frame"] / (prof["kernel_ms_per_frame_profiled"] * 1e-3) / 1e9 / vmem_peak, 4),
                     "vmem_insts_per_launch": int(mi), "source": prof["file"],
                     "note": "SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR per frame (committed --pmc pass) / kernel time of this run, against what a CU's vector-memory pipe takes for "
                             "this mix: node fetches (4 per wave-step, tools/gpu_travstats.py) at the span-measured cost of their access pattern, everything else at the pipe's "

@@ -53,11 +53,12 @@ def test_bench_prints_one_contract_json_line():
         assert abs(vm["peak"] - 256 * vm["clock_ghz"] / vm["clk_per_inst_of_the_mix"]) < 0.05 * vm["peak"]
         # ... the pipe's share follows from the instruction mix: node fetches (4 per wave-step) at their pattern's cost, the streams at the floor
         assert 0.5 < vm["node_fetch_share_of_insts"] < 0.95 and 16.0 < vm["clk_per_inst_of_the_mix"] < 37.5
-        # ... and the derived occupancy agrees with the hardware's own busy counter of the profiled dispatches (headline, one record per lane: 0.76-0.86 on
-        # every box so far; the alternating fetch of the default build: ~0.7) -- the band is what a run may drift from its committed profile, not a free parameter
-        assert 0.55 < vm["frac"] < 0.95, vm
-        if vm["ta_busy_counter"] is not None:
-            assert abs(vm["frac"] - vm["ta_busy_counter"]) < 0.12, vm
+        # ... and the derived occupancy agrees with the hardware's own busy counter of the profiled dispatches (headline: 0.71-0.83 against 0.74-0.81 so far).
+        # `frac` itself is this run's: launches of three frames, as here, carry more of a launch's fixed cost per frame than the profiled launches of 16
+        assert 0.3 < vm["frac"] < 0.95, vm
+        if vm["ta_busy_counter"] is not None and vm["frac_of_profiled_dispatches"] is not None:
+            assert abs(vm["frac_of_profiled_dispatches"] - vm["ta_busy_counter"]) < 0.1, vm
+            assert vm["frac"] < vm["frac_of_profiled_dispatches"] * 1.15, vm
         lo, hi = rv["simd_issue_busy_estimate"]
         assert 0.4 < lo <= hi < 1.0 and 0.3 < rv["wave_cycles_waiting_frac"] < 0.7
     aux = out["roofline_aux"]

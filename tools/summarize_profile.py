@@ -93,6 +93,8 @@ if main:
     if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
         # cycles the 256 CUs' address / L1 front ends had work, over the kernel's cycles: reads 0.965-0.98 on the saturated micro-benchmark (profiles/r04_ta_counters.json)
         summ["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / 256.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
+    if "grbm_pass_duration_ms" in m:
+        summ["kernel_ms_per_frame_profiled"] = m["grbm_pass_duration_ms"] / FRAMES  # duration of the dispatches the clock and the TA counter were read from
     if "clock_ghz" in m:
         summ["clock_ghz"] = m["clock_ghz"]
         summ["clock_note"] = ("GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same dispatch (rocprofv3 --pmc GRBM_GUI_ACTIVE pass, median over its launches): the clock the "
