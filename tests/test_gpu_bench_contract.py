@@ -72,3 +72,20 @@ def test_bench_prints_one_contract_json_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] == "port" and cb["unit"] == "Mrays/s" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_check_what_the_collective_delivered():
+    """`bench.py --gpus 2` with both ranks on this one GPU (gloo carries the gather: RCCL needs distinct devices): the real renderer through the C ABI, two
+    row-stripe partitions, the weak and the strong region, and the untimed self-check of both gather paths against a one-rank render on rank 0's GPU --
+    the part of the N > 1 control flow that needs a device (partition switch, accumulator re-binding) and that the CPU rehearsal cannot reach."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--device-map", "0,0", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+                        "--steps-per-launch", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and cfg["frames_per_step"] == 2 and out["value"] > 0
+    assert cfg["gather_check"] == "bit-identical", cfg["gather_check"]
+    assert cfg["strong"]["gather_check"] == "bit-identical" and cfg["strong"]["frames"] == 6
+    assert "bit-identical" in cfg["timed_kernel_image_check"]
