@@ -94,7 +94,7 @@ int main(int argc, char **argv) {
     if (argc > 3 && !only_records) sscanf(argv[3], "%d:%d:%d", &f_width, &f_mask, &f_lines);
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
-    const int n_cu = prop.multiProcessorCount, blocks = n_cu * 4, rounds = 512;
+    const int n_cu = prop.multiProcessorCount, blocks = n_cu * (getenv("TA_WGS_PER_CU") ? atoi(getenv("TA_WGS_PER_CU")) : 4), rounds = getenv("TA_ROUNDS") ? atoi(getenv("TA_ROUNDS")) : 512;
     char *table; float *out; unsigned long long *cyc, *rt, *where;
     CK(hipMalloc(&table, 64 * 8192 + 4096)); CK(hipMemset(table, 0, 64 * 8192 + 4096));
     CK(hipMalloc(&out, (size_t)blocks * 256 * 4)); CK(hipMalloc(&cyc, (size_t)blocks * 4 * 8)); CK(hipMalloc(&rt, (size_t)blocks * 4 * 8)); CK(hipMalloc(&where, (size_t)blocks * 4 * 4 * 8));
@@ -138,8 +138,9 @@ int main(int argc, char **argv) {
                 for (size_t i = 0; i < h.size(); i++) mhz[i] = hr[i] ? (double)h[i] / (double)hr[i] * 100.0 : 0.0;
                 std::sort(mhz.begin(), mhz.end());
                 const double clock_mhz = mhz[mhz.size() / 2];
-                const double inst_per_cu = 16.0 * rounds * 16;  // wave-instructions issued by one CU's 16 waves
-                const double cpi = clk / (rounds * 16.0) / 16.0, gps = inst_per_cu * n_cu / (ms * 1e-3) * 1e-9;
+                const double waves_per_cu = 4.0 * blocks / n_cu;  // 16 with the default 4 workgroups per CU (TA_WGS_PER_CU)
+                const double inst_per_cu = waves_per_cu * rounds * 16;  // wave-instructions issued by one CU's waves
+                const double cpi = clk / (rounds * 16.0) / waves_per_cu, gps = inst_per_cu * n_cu / (ms * 1e-3) * 1e-9;
                 printf("dwordx%d  %-24s %2d line(s): %6.2f clk per wave-instruction per CU, in-kernel clock %6.0f MHz, %7.1f G wave-inst/s chip-wide at that clock (%.3f ms x %d launches)\n",
                        width, mk.name, lines, cpi, clock_mhz, gps, ms, n);
                 fflush(stdout);
@@ -161,6 +162,16 @@ int main(int argc, char **argv) {
                 for (int v : per_cu) if (v) { used++; mx = std::max(mx, v); mn = std::min(mn, v); }
                 const double span_clk = (double)(hi - lo) * clock_mhz / 100.0;
                 const double cpi_span = span_clk / ((double)blocks * 4 * rounds * 16 / std::max(used, 1));
+                if (f_width) {  // one case selected: when the waves of the launch started and how long their loops ran (deciles over the 4096 waves, us)
+                    std::vector<double> st(blocks * 4), du(blocks * 4);
+                    for (int i = 0; i < blocks * 4; i++) { st[i] = (double)(w[4 * i] - lo) * 1e-2; du[i] = (double)(w[4 * i + 1] - w[4 * i]) * 1e-2; }
+                    std::sort(st.begin(), st.end()); std::sort(du.begin(), du.end());
+                    printf("    wave start after the first wave's, us (deciles):");
+                    for (int d = 0; d <= 10; d++) printf(" %.0f", st[std::min<size_t>(st.size() - 1, d * st.size() / 10)]);
+                    printf("\n    wave loop duration, us (deciles):              ");
+                    for (int d = 0; d <= 10; d++) printf(" %.0f", du[std::min<size_t>(du.size() - 1, d * du.size() / 10)]);
+                    printf("\n");
+                }
                 printf("    span: %d waves on %d CUs (%d..%d per CU), kernel span %.3f ms, a wave's loop %.1f %% of it => %6.2f clk per wave-instruction per CU from the span = %.1f G/s at %.0f MHz\n",
                        blocks * 4, used, mn, mx, (double)(hi - lo) * 1e-5, 100.0 * loop_sum / (blocks * 4) / (double)(hi - lo), cpi_span, n_cu * clock_mhz * 1e-3 / cpi_span, clock_mhz);
                 if (js) fprintf(js, "{\"width_dwords\": %d, \"lanes\": \"%s\", \"active_lanes\": %d, \"distinct_lines\": %d, \"clk_per_wave_inst_per_cu\": %.3f, \"clock_mhz_in_kernel\": %.1f, "
