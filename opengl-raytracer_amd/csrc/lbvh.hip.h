@@ -292,19 +292,23 @@ constexpr int kRebuildSahLevels = 20;  // as in host/bvh.cpp: deeper segments ar
 // The rebuild forms unions of many boxes in an order of its own (scans across lanes; the CPU statement: sequential sweeps).  min and
 // max give the same result in any order once no operand is a negative zero, so the leaf boxes are read as x + 0.0f (-0 -> +0,
 // everything else unchanged) and the unions use the plain instructions.
-// Leaves below every internal node, capped at kRebuildLeaves + 1: one thread per node, a depth-first walk that stops at the cap.
-__global__ __launch_bounds__(256) void k_subtree_count(int n, const float *nodes, int *count) {
+// Leaves below every internal node, capped at kRebuildLeaves + 1: one thread per node, a depth-first walk that stops at the cap.  The walk keeps no stack (round 4; a
+// per-thread int[64] lived in scratch memory): it finds its way by the parent links -- from above to the left child, back from the left child to the right one, back
+// from the right child up -- so the kernel needs no private memory, and no depth limit either (the CPU statement, host/bvh.cpp: rebuild_subtrees, counts exactly as well).
+__global__ __launch_bounds__(256) void k_subtree_count(int n, const float *nodes, const int *parent, int *count) {
     const int i = (int)(blockIdx.x * 256u + threadIdx.x);
     if (i >= n - 1) return;
-    int stack[64];
-    int sp = 0, cnt = 0;
-    stack[sp++] = i;
-    while (sp > 0 && cnt <= kRebuildLeaves) {
-        const int v = stack[--sp];
-        if (v >= n - 1) { cnt++; continue; }
-        if (sp + 2 > 64) { cnt = kRebuildLeaves + 1; break; }  // deeper than any tree the traversal accepts
-        stack[sp++] = (int)nodes[9 * (size_t)v + 6];
-        stack[sp++] = (int)nodes[9 * (size_t)v + 7];
+    int v = i, prev = -1, cnt = 0;  // prev: the node the walk came from (-1: from above)
+    for (;;) {
+        if (v >= n - 1) {  // a leaf
+            if (++cnt > kRebuildLeaves) break;
+            prev = v; v = parent[v];
+            continue;
+        }
+        const int l = (int)nodes[9 * (size_t)v + 6], r = (int)nodes[9 * (size_t)v + 7];
+        if (prev == l) { prev = v; v = r; }
+        else if (prev == r) { if (v == i) break; prev = v; v = parent[v]; }
+        else { prev = v; v = l; }
     }
     count[i] = cnt < kRebuildLeaves + 1 ? cnt : kRebuildLeaves + 1;
 }
@@ -549,7 +553,7 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
         int *count = (int *)arrived;  // the rotation levels are no longer needed
         int *roots = (int *)keys0, *n_roots = (int *)(bounds + 194);  // the unsorted keys are no longer needed
         LBVH_TRY(hipMemsetAsync(n_roots, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(k_subtree_count, grid, block, 0, stream, (int)n, d_nodes, count);
+        hipLaunchKernelGGL(k_subtree_count, grid, block, 0, stream, (int)n, d_nodes, parent, count);
         hipLaunchKernelGGL(k_subtree_roots, grid, block, 0, stream, (int)n, parent, count, roots, n_roots);
         hipLaunchKernelGGL(k_rebuild_subtrees, dim3(std::min<unsigned>(n - 1, 8192u)), dim3(64), 0, stream, (int)n, d_nodes, parent, roots, n_roots);
         LBVH_TRY(hipMemsetAsync(max_depth, 0, sizeof(int), stream));
