@@ -129,7 +129,7 @@ static_assert(GLRTX_STEPS_PER_TRIP % 2 == 0, "the alternating form of the node f
     "s_or_b64 %[tmp], %[tmp], %[pop]\n\t" \
     "s_or_b64 %[pop], %[tmp], %[act]\n\t"   /* (%[pop] holds the pair mask until the fork arm assigns it) */ \
     "s_mov_b64 exec, %[pop]\n\t" \
-    "v_cndmask_b32_e64 v[GLRTX_VB+4], 0, %[cur], %[act]\n\t"   /* a partner that is not running fetches record 0 for itself (its cur is REF_FIN: not an address) */ \
+    "v_cndmask_b32_e64 v[GLRTX_VB+4], -1, %[cur], %[act]\n\t"   /* a partner that is not running fetches record -1 for itself -- the never-hit record, present in every scene (a tree of one leaf has no fork 0) -- its cur is REF_FIN: not an address */ \
     "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t"   /* lanes at a triangle (only ever used under %[act]) */ \
     "s_nop 0\n\t"   /* (a DPP source written by the vector ALU needs two wait states) */ \
     "v_mov_b32_dpp v[GLRTX_VB+15], v[GLRTX_VB+4] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"   /* the even lane's ref in both lanes of the pair */ \
