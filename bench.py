@@ -180,6 +180,23 @@ class GpuRenderer:
         else:
             self.dev.render_frames(self.params, [seed_of(f0 + i) for i in range(n)])
 
+    def prepare_frames(self, f0, n, seed_of):
+        """Everything the host can do for a launch ahead of time -- the params struct, the seed array -- so that issuing it is one C call.  (A device that has been
+        idle runs the next launch slower: +2 % after 1 ms, +5 % after 3 ms, +9 % after 10 ms, profiles/r04_ab_launch_warmth.txt; the timed region starts behind a
+        barrier, so what the host does between the barrier and the launch is idle time of the device.)"""
+        from glrt_amd import device
+        if n == 1:
+            return (1, device.make_params(dict(self.params, seed=seed_of(f0))), None)
+        sd = np.ascontiguousarray(np.asarray([seed_of(f0 + i) for i in range(n)], np.float32).reshape(-1, 2))
+        return (n, device.make_params(dict(self.params, seed=(0.0, 0.0))), sd)
+
+    def render_prepared(self, prep):
+        n, p, sd = prep
+        if n == 1:
+            self.dev.render(p)
+        else:
+            self.dev.render_frames(p, sd)
+
     def device_sync(self):
         self.torch.cuda.synchronize()
 
@@ -307,16 +324,32 @@ def main(argv=None):
 
     S = max(1, args.steps_per_launch)
 
-    def run(s0, n_steps, per_launch=None, gather=True):
+    def prepare(s0, n_steps, per_launch=None):
+        """The launches of steps [s0, s0 + n_steps), with everything the host can do ahead of time done (renderers without prepare_frames: the plain plan)."""
+        plan = launch_plan(n_steps, per_launch or S)
+        if not hasattr(R, "prepare_frames"):
+            return [(a, k, None) for a, k in plan]
+        return [(a, k, R.prepare_frames((s0 + a) * world, k * world, seed)) for a, k in plan]
+
+    def run(s0, n_steps, per_launch=None, gather=True, prepared=None):
         """Steps [s0, s0 + n_steps) = frames [s0*N, (s0+n_steps)*N), in balanced launches; returns the gathered image (rank 0) or None."""
         img = None
-        plan = launch_plan(n_steps, per_launch or S)
-        for i, (a, k) in enumerate(plan):
-            R.render_frames((s0 + a) * world, k * world, seed)
+        plan = prepared if prepared is not None else [(a, k, None) for a, k in launch_plan(n_steps, per_launch or S)]
+        for i, (a, k, prep) in enumerate(plan):
+            if prep is not None:
+                R.render_prepared(prep)
+            else:
+                R.render_frames((s0 + a) * world, k * world, seed)
             last = i + 1 == len(plan)
             if gatherer is not None and gather and not args.no_gather and (last or (args.gather_every > 0 and (i + 1) % args.gather_every == 0)):
                 img = gatherer.gather_to_root(R.accum)
         return img
+
+    def clear_accum():
+        """Zero the resident accumulator, ordered on the render stream, without making the host wait (a renderer that keeps a copy elsewhere clears that too)."""
+        R.accum.zero_()
+        if hasattr(R, "cleared"):
+            R.cleared()
 
     def barrier():
         R.device_sync()
@@ -324,43 +357,63 @@ def main(argv=None):
             td.barrier()
         R.device_sync()
 
-    # ---- exact ray count for the timed steps (untimed, counting kernel variant)
+    # ---- untimed preamble, enqueued WITHOUT a host wait from its first launch to the barrier in front of the timed region:
+    #   (1) the timed steps by the counting kernel variant: the exact ray count;
+    #   (2) the same steps by the kernel that is timed (compiled without ray counting): its accumulator must equal (1)'s bit for bit -- compared on the device, the
+    #       verdict read after the timed region (a mismatch aborts the run before anything is printed);
+    #   (3) the W warm-up steps.
+    # Why without a wait: a launch issued on a device that has been idle runs longer, and the effect outlasts the idle time by tens of milliseconds -- 20 frames take
+    # 20.2-20.7 ms back to back, +2 % behind a pause of 1 ms, +5 % behind 3 ms, +9 % behind 10 ms, +12 % from cold (tools/gpu_launch_warmth.py,
+    # profiles/r04_ab_launch_warmth.txt).  With a host round trip between (1) and (2), as in rounds 1-3, the driver's cadence (K = 20, W = 5) timed its one launch
+    # 5-6 % above the steady state of the same launch; with W = 20 it did not.  All launches are prepared beforehand so that issuing one is a single C call.
+    # torch's own kernels used below (copy, compare, reduce, fill) are launched once HERE, on the idle device: the first launch of a kernel loads its code object, and
+    # such a load stalls the device for milliseconds in the middle of whatever is enqueued (profiles/r04_ab_pipeline_robustness.txt) -- inside the preamble that is an
+    # idle gap in front of the timed region (measured: the timed launch of 20 frames 21.4 ms the first time the process runs these ops, 20.6 ms the second time)
+    _w = R.accum.clone()
+    _ = (R.accum.view(torch.int32) == _w.view(torch.int32)).all().to(torch.int32).reshape(1)
+    R.accum.zero_()
+    del _w, _
+    R.device_sync()
+    count_launches = prepare(args.warmup, args.steps)
+    replay_launches = prepare(args.warmup, args.steps)
+    warm_launches = prepare(0, args.warmup)
+    timed_launches = prepare(args.warmup, args.steps)
+    R.reset_stats()
+    clear_accum()
     R.count_rays(True)
-    R.reset_stats()
-    run(args.warmup, args.steps, gather=False)
-    R.sync()
-    rays_local = int(R.stats().rays)
-    untraced_local = int(R.stats().rays_untraced)
+    run(args.warmup, args.steps, gather=False, prepared=count_launches)
     R.count_rays(False)
-    # ---- the kernel that is timed (compiled without ray counting) must produce the image the counting kernel produced: untimed replay
     counted_img = R.accum.clone()
-    R.accum.zero_()
-    R.reset_stats()
-    run(args.warmup, args.steps, gather=False)
-    R.sync()
-    same = torch.tensor([1 if torch.equal(R.accum.view(torch.int32), counted_img.view(torch.int32)) else 0], dtype=torch.int32, device=R.accum.device)
-    if world > 1:
-        td.all_reduce(same, op=td.ReduceOp.MIN)
-    if int(same.item()) != 1:
-        raise SystemExit("bench.py: the timed kernel's image differs from the counting kernel's image for the same steps: refusing to time it")
+    clear_accum()
+    run(args.warmup, args.steps, gather=False, prepared=replay_launches)
+    same = (R.accum.view(torch.int32) == counted_img.view(torch.int32)).all().to(torch.int32).reshape(1)
     del counted_img
-    R.accum.zero_()
-    R.reset_stats()
-
-    # ---- warm-up, then K timed steps
-    run(0, args.warmup)
-    R.sync()
-    R.reset_stats()
+    clear_accum()
+    run(0, args.warmup, prepared=warm_launches)
+    R.sync()  # the first host wait since the preamble began; it is part of the barrier that opens the timed region
+    st0 = R.stats()
+    rays_local = int(st0.rays)
+    untraced_local = int(st0.rays_untraced)
     barrier()
     t0 = time.perf_counter()
     R.timer_begin()
-    img = run(args.warmup, args.steps)
+    img = run(args.warmup, args.steps, prepared=timed_launches)
+    t_issued = time.perf_counter()
     ev_ms = R.timer_end()
     barrier()
     t1 = time.perf_counter()
     R.sync()
-    st = R.stats()
+    st1 = R.stats()
+    # what the timed region added to the context's running totals
+    import types
+    st = types.SimpleNamespace(kernel_ms_total=st1.kernel_ms_total - st0.kernel_ms_total, kernel_launches=st1.kernel_launches - st0.kernel_launches,
+                               launches=st1.launches - st0.launches, accumulate_ms_total=getattr(st1, "accumulate_ms_total", 0.0) - getattr(st0, "accumulate_ms_total", 0.0),
+                               node_fetch_last=getattr(st1, "node_fetch_last", 0))
     del img
+    if world > 1:
+        td.all_reduce(same, op=td.ReduceOp.MIN)
+    if int(same.item()) != 1:
+        raise SystemExit("bench.py: the timed kernel's image differs from the counting kernel's image for the same steps: refusing to report a time for it")
 
     # ---- the same steps once more, one frame per launch (reported next to the headline figure; N = 1 only)
     single = None
@@ -622,6 +675,7 @@ def main(argv=None):
                        "mrays_per_s_reference_equivalent": round(ref_rays / elapsed_s / 1e6, 3),
                        "mpaths_per_s": round(W * H * params["n_samples"] * n_frames / elapsed_s / 1e6, 3),
                        "event_ms_per_step": round(ev_ms / args.steps, 4),
+                       "host_ms_to_issue_timed_launches": round((t_issued - t0) * 1e3, 3),
                        # N > 1: the image RCCL gathered for min(K, 4) of the timed steps against the same frames rendered by rank 0's GPU alone
                        "gather_check": gather_check if world > 1 else None,
                        "gather_check_what": None if world == 1 else f"frames [{args.warmup * world}, {(args.warmup + min(args.steps, 4)) * world}) re-rendered untimed by all ranks, gathered to "

@@ -63,6 +63,9 @@ class OracleRenderer:
             self.o.render(self.scene, dict(self.params, seed=seed_of(f)), accum=full, threads=1)
         return torch.from_numpy(full)
 
+    def cleared(self):
+        self.full[:] = 0.0  # bench.py zeroed `accum` without a reset_stats behind it
+
     def device_sync(self):
         pass
 
@@ -73,7 +76,7 @@ class OracleRenderer:
         pass
 
     def stats(self):
-        return self.st
+        return types.SimpleNamespace(**vars(self.st))  # a snapshot: bench.py takes differences
 
     def reset_stats(self):
         self.full[:] = 0.0 if not self.accum.any() else self.full  # bench zeroes accum right before: keep both in step
