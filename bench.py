@@ -373,7 +373,9 @@ def main(argv=None):
     _ = (R.accum.view(torch.int32) == _w.view(torch.int32)).all().to(torch.int32).reshape(1)
     R.accum.zero_()
     del _w, _
-    R.device_sync()
+    if gatherer is not None and not args.no_gather:
+        gatherer.gather_to_root(R.accum)  # the collective's and the de-interleave's kernels as well (N > 1), and the communicator is set up
+    barrier()
     count_launches = prepare(args.warmup, args.steps)
     replay_launches = prepare(args.warmup, args.steps)
     warm_launches = prepare(0, args.warmup)
