@@ -119,6 +119,36 @@ def test_bench_gather_check_reports_a_corrupted_gather(tmp_path):
     assert out["config"]["strong"]["gather_check"] == "bit-identical"
 
 
+def test_bench_single_rank_flow_rehearsed_on_cpu():
+    """The N = 1 control flow of bench.py -- prepared launches, the untimed preamble enqueued without a host wait (counting pass, replay by the timed kernel, image check read
+    after the timed region, warm-up), stats taken as differences around the timed region -- with the oracle-backed renderer: one JSON line, exact frame order, ray count of the
+    timed steps only."""
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out_dir = pathlib.Path(os.environ.get("PYTEST_TMP", "/tmp")) / f"glrt_rehearsal_n1_{os.getpid()}"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    env.update(OMP_NUM_THREADS="1", GLRT_REHEARSAL_OUT=str(out_dir))
+    steps, warm = 3, 1
+    r = subprocess.run([sys.executable, str(root / "tests" / "bench_rehearsal.py"), "--gpus", "1", "--steps", str(steps), "--warmup", str(warm),
+                        "--steps-per-launch", "2", "--config", "rehearsal", "--backend", "gloo", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == steps and out["config"]["launches"] == [2, 1]
+    assert out["config"]["strong"] is None and out["config"]["gather_check"] is None and "bit-identical" in out["config"]["timed_kernel_image_check"]
+    timed = list(range(warm, warm + steps))
+    frames = np.load(out_dir / "frames_rank0.npy").tolist()
+    assert frames[:3 * steps + warm] == timed + timed + list(range(warm)) + timed, frames   # counting pass, replay, warm-up, timed region
+    # `value` counts the rays of the timed steps (counted by the first pass over them)
+    from glrt_amd import host
+    from tests.bench_rehearsal import small_config
+    sc, pr = small_config()
+    rays = sum(pt_oracle.render(sc, dict(pr, seed=host.frame_seed(f)), threads=2)[1] for f in timed)
+    assert abs(out["config"]["rays_reference_equivalent_per_frame"] * steps - rays) < 0.5
+
+
 def test_launch_plan_is_balanced():
     import bench
     assert bench.launch_plan(20, 16) == [(0, 10), (10, 10)]
