@@ -1,6 +1,6 @@
 """A/B timing of several builds of libglrtx.so (and/or environment settings) on the headline workload.
 
-    python tools/gpu_abx.py [--config headline] [--frames 16] [--rounds 6] [--repeat 1] NAME=path/to/lib.so[,ENV=VAL...] ...
+    python tools/gpu_abx.py [--config headline|c2..c5|rand:N] [--frames 16] [--rounds 6] [--repeat 1] NAME=path/to/lib.so[,ENV=VAL...] ...
 
 Each variant runs in its own child process (one libglrtx per process), sequentially: an untimed counting launch
 (ray count + image checksum), then `rounds` timed launches of `frames` frames in flight.  Prints ms/frame (median,
@@ -21,7 +21,11 @@ def child(lib, config, frames, rounds):
     import numpy as np
     from glrt_amd import device, host, scenes
     device.lib_path = lambda: pathlib.Path(lib)
-    sc, pr = scenes.CONFIGS[config]()
+    if config.startswith("rand:"):  # rand:N -- N random triangles at config 5's density and camera distance (tree-size sweeps)
+        n = int(config[5:]); ext = 10.0 * (n / 100_000.0) ** (1.0 / 3.0)
+        sc, pr = scenes._random_tri_scene(n, 20260102, ext, 3.4 * ext, 1920, 1080, 4, 1, "sah")
+    else:
+        sc, pr = scenes.CONFIGS[config]()
     d = device.Device(); d.upload_scene(sc); d.resize(pr["width"], pr["height"])
     seeds = lambda f0: [host.frame_seed(f0 + i) for i in range(frames)]
     d.count_rays(True); d.reset_stats()
