@@ -204,6 +204,7 @@ int pfail(glrtx_ctx *c, std::string *err_out, int code, const char *fmt, ...) {
 struct Packed {
     std::vector<float4> forks, tris, nrms, mats, lights, vine;
     int vine_uniform = 0;
+    int n_vine = 0, vine_main = 0;  // records of the list (= triangles), index of the last one (the list is padded: see pack_scene)
     float4 root_lo = make_float4(0.f, 0.f, 0.f, 0.f), root_hi = make_float4(0.f, 0.f, 0.f, 0.f);
     int root_ref = REF_ABSENT;
     int root_boxed = 0;   // the wire root is a fork: its own box (root_lo / root_hi) is tested before anything else
@@ -428,7 +429,22 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
                 if (!is_fork(l)) { rec(all_lo, all_hi, ~ref_of[l]); break; }
                 n = l;
             }
-            if (is_vine && v.size() == 4 * leaf_tri.size()) { P.vine.swap(v); P.vine_uniform = uniform ? 1 : 0; }
+            if (is_vine && v.size() == 4 * leaf_tri.size()) {
+                // Device layout (trav_scan): the n - 1 fork records in groups of four -- the last group filled up with never-hit records (an infinite box, an
+                // all-zero triangle: det = 0) --, then the last leaf's record at index vine_main = roundup4(n - 1), then three more never-hit records: the scan
+                // works through whole groups while the next ones are being fetched and reads up to three records past the one it needs.
+                const size_t n = leaf_tri.size(), n_main = (n - 1 + 3) / 4 * 4;
+                std::vector<float4> d(4 * (n_main + 4));
+                const float4 pad[4] = {make_float4(-inf, -inf, -inf, 0.f), make_float4(inf, inf, inf, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, as_float(0))};
+                for (size_t i = 0; i < n_main + 4; i++) {
+                    const float4 *src = i < n - 1 ? &v[4 * i] : (i == n_main ? &v[4 * (n - 1)] : pad);
+                    for (int j = 0; j < 4; j++) d[4 * i + j] = src[j];
+                }
+                P.vine.swap(d);
+                P.n_vine = (int)n;
+                P.vine_main = (int)n_main;
+                P.vine_uniform = uniform ? 1 : 0;
+            }
         }
     }
     // Renumbering: the forks of the tree's top levels (breadth-first from the root, kTopForks of them) take the first indices, the
@@ -841,7 +857,8 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     sc.stack_entries = stack_need;
     sc.mats_in_lds = (n_mat > 0 && n_mat <= (size_t)kMaxLdsMaterials) ? 1 : 0;
     sc.vine = P.vine.empty() ? nullptr : (const float4 *)c->vine.p;
-    sc.n_vine = (int)(P.vine.size() / 4);
+    sc.n_vine = P.n_vine;
+    sc.vine_main = P.vine_main;
     sc.vine_uniform = P.vine_uniform;
     if (std::getenv("GLRTX_NO_VINE_SCAN")) sc.n_vine = 0;  // A/B: force the generic tree traversal
     c->n_tri = (int)n_tri; c->n_fork = (int)(forks.size() / 4); c->n_mat = (int)n_mat; c->n_light = (int)n_light;

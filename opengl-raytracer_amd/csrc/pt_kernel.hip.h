@@ -36,6 +36,7 @@
 #include <stdint.h>
 
 #include "trav_asm.hip.h"
+#include "scan_asm.hip.h"
 
 namespace glrtx {
 
@@ -72,9 +73,11 @@ struct DevScene {
     int mats_in_lds;    // 1: materials staged into LDS at kernel start
     // "Vine" trees -- every fork has a leaf as children.y: the brute-force scan of BASELINE config 3 expressed in the
     // node format (glrt_bvh_build_chain) -- are also stored as a list in visiting order and scanned, see trav_scan().
-    const float4 *vine;  // n_vine x 4 float4: {fork box min, v0.x} {fork box max, v0.y} {v0.z, v1-v0} {v2-v0, triangle}
-    int n_vine;          // 0: not a vine
+    const float4 *vine;  // records of 4 float4: {fork box min, v0.x} {fork box max, v0.y} {v0.z, v1-v0} {v2-v0, triangle}: the n_vine - 1 fork records, never-hit
+                         // records up to index vine_main (a multiple of 4), the last leaf's record there, three never-hit records behind it (glrtx.hip: pack_scene)
+    int n_vine;          // triangles in the list; 0: not a vine
     int vine_uniform;    // 1: all fork boxes are the same box (vine[0]'s)
+    int vine_main;       // index of the last record
 };
 
 struct KernelArgs {
@@ -199,17 +202,34 @@ DEV float pt_rand(Rng &s) {
 
 // ------------------------------------------------------------------------------------------ helpers
 DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (az * bz + ay * by) + ax * bx; }
-DEV float rsq(float x) { return 1.0f / __builtin_sqrtf(x); }  // IEEE sqrt then IEEE divide
-// The correctly rounded 1.0f / x in three instructions where that is provably the same value: v_rcp_f32 and ONE Newton step with
-// fused multiply-adds equal the IEEE quotient for EVERY float with FLT_MIN <= |x| <= 2^126 (tools/ubench/rcp_exact.hip runs all 2^32
-// bit patterns on the device: 0 mismatches there, and a NaN stays a NaN); beyond 2^126 (a denormal quotient) and for infinities the
-// compiler's ten-instruction expansion runs.  For the caller's purposes |x| below FLT_MIN need not be exact: the triangle test
-// rejects |det| < EPS whatever the reciprocal is.
-DEV float rcp_exact(float x) {
-    if (__builtin_fabsf(x) > 0x1p126f) return 1.0f / x;
+// Quotients.  The kernels run with fp32 denormals flushed on input and output (-fgpu-flush-denormals-to-zero): that is the reference's arithmetic -- llvmpipe's
+// rasteriser threads set MXCSR FTZ | DAZ, and so does the oracle (pt_oracle.c: pt_render_rows).  In that mode the compiler's correctly rounded a / b switches
+// the denormal mode on and off around its core (two s_setreg per quotient), and three short forms are PROVABLY the same value -- tools/ubench/rcp_exact.hip runs
+// every one of the 2^32 float bit patterns through each of them on the device against the compiler's quotient (tests/test_gpu_parity.py runs it): 0 mismatches.
+//   rcp_newton(x): v_rcp_f32 and ONE Newton step with fused multiply-adds = 1.0f / x for every normal finite x (beyond 2^126 both give the flushed zero of x's
+//                  sign).  Zeros, denormals and infinities come out as NaN instead of inf / 0: the triangle tests, its only users, reject |det| < EPS before
+//                  anything reads the quotient, and an infinite det changes nothing either way (t comes out as 0 or NaN: never a hit that is closer).
+//   frcp(x):       the same, with the raw v_rcp_f32 result where x is a zero, a denormal or an infinity: = 1.0f / x for EVERY bit pattern (a NaN stays a NaN).
+//   div_pi(x):     x * RN(1 / PI) corrected by one residual step = x / PI for every x that is 0 or has 2^-100 <= |x| <= 2^120; a wave that holds any other
+//                  value takes the full division (a branch, not a select between both).
+DEV float rcp_newton(float x) {
     const float r = __builtin_amdgcn_rcpf(x);
     return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
+DEV float frcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float n = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    return __builtin_amdgcn_class(x, 0x2F4) ? r : n;  // -inf, -denormal, -0, +0, +denormal, +inf
+}
+constexpr float PT_INV_PI = 0.318309873342514038f;  // RN(1 / PT_PI)
+DEV float div_pi(float x) {
+    const unsigned a = __float_as_uint(x) & 0x7FFFFFFFu;
+    if (__any(a != 0u && (a - 0x0D800000u) > (0x7B800000u - 0x0D800000u))) return x / PT_PI;  // 0 < |x| < 2^-100, |x| > 2^120, inf, NaN
+    const float q = x * PT_INV_PI;
+    return __builtin_fmaf(__builtin_fmaf(-PT_PI, q, x), PT_INV_PI, q);
+}
+DEV float fdiv(float a, float b) { return a / b; }
+DEV float rsq(float x) { return frcp(__builtin_sqrtf(x)); }  // IEEE sqrt then IEEE reciprocal
 // GLSL min/max as the reference's GL implementation lowers them (other operand on NaN):
 DEV float fmin_g(float a, float b) { return (b != b) ? a : (a < b ? a : b); }
 DEV float fmax_g(float a, float b) { return (b != b) ? a : (a > b ? a : b); }
@@ -324,7 +344,7 @@ struct Trav {
 DEV bool trav_init(const DevScene &sc, const float4 *root, Trav &T, float ox, float oy, float oz, float dx, float dy, float dz,
                    float limit = PT_INFTY, float stop_d = -__builtin_inff()) {
     T.ox = ox; T.oy = oy; T.oz = oz; T.dx = dx; T.dy = dy; T.dz = dz;
-    T.ix = 1.0f / dx; T.iy = 1.0f / dy; T.iz = 1.0f / dz;  // :260 (loop-invariant there)
+    T.ix = frcp(dx); T.iy = frcp(dy); T.iz = frcp(dz);  // :260 (loop-invariant there)
     T.h.t = limit; T.h.tri = -1; T.h.u = 0.f; T.h.v = 0.f;
     T.stop_d = stop_d;
     T.sp = 0;
@@ -428,7 +448,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
         const float pz = T.dx * C.y - T.dy * C.x;
         const float det = dot3(B.x, B.y, B.z, px, py, pz);
         const float U = dot3(tx, ty, tz, px, py, pz);
-        const float inv = rcp_exact(det);
+        const float inv = rcp_newton(det);
         const float u = U * inv;
         const float qx = ty * B.z - tz * B.y;
         const float qy = tz * B.x - tx * B.z;
@@ -528,7 +548,7 @@ DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) 
             : [th] "+&v"(T.h.t), [tri] "+&v"(T.h.tri), [hu] "+&v"(T.h.u), [hv] "+&v"(T.h.v), [cur] "+&v"(T.cur), [sp] "+&v"(T.sp),
               [entry] "=&s"(s_entry), [act] "=&s"(s_act), [leaf] "=&s"(s_leaf), [bl] "=&s"(s_bl), [br] "=&s"(s_br), [pop] "=&s"(s_pop), [tmp] "=&s"(s_tmp) GLRTX_TS_OPERANDS
             : [ox] "v"(T.ox), [oy] "v"(T.oy), [oz] "v"(T.oz), [dx] "v"(T.dx), [dy] "v"(T.dy), [dz] "v"(T.dz), [ix] "v"(T.ix), [iy] "v"(T.iy), [iz] "v"(T.iz),
-              [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [bias] "s"(sc.node_bias), [eps] "s"(PT_EPS), [big] "s"(0x1p126f),
+              [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [bias] "s"(sc.node_bias), [eps] "s"(PT_EPS),
               [odd] "s"(0xAAAAAAAAAAAAAAAAull), [biase] "v"(bias_e), [biaso] "v"(bias_o)
             : "vcc", "scc", "memory", GLRTX_ASM_VCLOBBERS_PAIR GLRTX_TS_CLOBBERS);
         return;
@@ -545,7 +565,7 @@ DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) 
             : [th] "+&v"(T.h.t), [tri] "+&v"(T.h.tri), [hu] "+&v"(T.h.u), [hv] "+&v"(T.h.v), [cur] "+&v"(T.cur), [sp] "+&v"(T.sp),
               [entry] "=&s"(s_entry), [act] "=&s"(s_act), [leaf] "=&s"(s_leaf), [bl] "=&s"(s_bl), [br] "=&s"(s_br), [pop] "=&s"(s_pop), [tmp] "=&s"(s_tmp) GLRTX_TS_OPERANDS
             : [ox] "v"(T.ox), [oy] "v"(T.oy), [oz] "v"(T.oz), [dx] "v"(T.dx), [dy] "v"(T.dy), [dz] "v"(T.dz), [ix] "v"(T.ix), [iy] "v"(T.iy), [iz] "v"(T.iz),
-              [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [eps] "s"(PT_EPS), [big] "s"(0x1p126f),
+              [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [eps] "s"(PT_EPS),
               [odd] "s"(0xAAAAAAAAAAAAAAAAull), [biase] "v"(bias_e), [biaso] "v"(bias_o)
             : "vcc", "scc", "memory", GLRTX_ASM_VCLOBBERS_PAIR GLRTX_TS_CLOBBERS);
         return;
@@ -561,11 +581,14 @@ DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) 
         : [th] "+&v"(T.h.t), [tri] "+&v"(T.h.tri), [hu] "+&v"(T.h.u), [hv] "+&v"(T.h.v), [cur] "+&v"(T.cur), [sp] "+&v"(T.sp),
           [entry] "=&s"(s_entry), [act] "=&s"(s_act), [leaf] "=&s"(s_leaf), [bl] "=&s"(s_bl), [br] "=&s"(s_br), [pop] "=&s"(s_pop), [tmp] "=&s"(s_tmp) GLRTX_TS_OPERANDS
         : [ox] "v"(T.ox), [oy] "v"(T.oy), [oz] "v"(T.oz), [dx] "v"(T.dx), [dy] "v"(T.dy), [dz] "v"(T.dz), [ix] "v"(T.ix), [iy] "v"(T.iy), [iz] "v"(T.iz),
-          [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [bias] "s"(sc.node_bias), [eps] "s"(PT_EPS), [big] "s"(0x1p126f)
+          [sd] "v"(T.stop_d), [stk] "v"(stk), [base] "s"(sc.nodes0), [bias] "s"(sc.node_bias), [eps] "s"(PT_EPS)
         : "vcc", "scc", "memory", GLRTX_ASM_VCLOBBERS GLRTX_TS_CLOBBERS);
 }
 
-// intersect(Ray, Triangle) :226-257 against the running closest hit; v0 / e1 = v1-v0 / e2 = v2-v0
+// intersect(Ray, Triangle) :226-257 against the running closest hit; v0 / e1 = v1-v0 / e2 = v2-v0.  Used by the list scan only (the tree
+// kernels carry the test in their step).  All lanes of a wave test the SAME triangle here, and most triangles are missed by all of
+// them: the test leaves as soon as no lane of the wave can still hit -- after u (22 of the ~60 vector instructions), after v -- which
+// skips operations whose results nothing would have read; the ones that are executed are the same, in the same order.
 template <bool CLOSEST>
 DEV void tri_test(Hit &h, int t, float ox, float oy, float oz, float dx, float dy, float dz, float v0x, float v0y, float v0z, float e1x,
                   float e1y, float e1z, float e2x, float e2y, float e2z) {
@@ -575,15 +598,19 @@ DEV void tri_test(Hit &h, int t, float ox, float oy, float oz, float dx, float d
     const float pz = dx * e2y - dy * e2x;
     const float det = dot3(e1x, e1y, e1z, px, py, pz);
     const float U = dot3(tx, ty, tz, px, py, pz);
-    const float inv = 1.0f / det;
+    const float inv = rcp_newton(det);  // (|det| < EPS is rejected below whatever its reciprocal is)
     const float u = U * inv;
+    const bool ok_u = !(-PT_EPS < det && det < PT_EPS) && !(u < 0.0f || 1.0f < u);
+    if (!__any(ok_u)) return;
     const float qx = ty * e1z - tz * e1y;
     const float qy = tz * e1x - tx * e1z;
     const float qz = tx * e1y - ty * e1x;
     const float V = dot3(dx, dy, dz, qx, qy, qz);
     const float v = V * inv;
+    const bool ok_v = ok_u && !(v < 0.0f || 1.0f < inv * (U + V));
+    if (!__any(ok_v)) return;
     const float tt = dot3(e2x, e2y, e2z, qx, qy, qz) * inv;
-    const bool hit = !(-PT_EPS < det && det < PT_EPS) && !(u < 0.0f || 1.0f < u) && !(v < 0.0f || 1.0f < inv * (U + V)) && !(PT_EPS >= tt);
+    const bool hit = ok_v && !(PT_EPS >= tt);
     const bool closer = hit && tt < h.t;
     h.tri = closer ? t : h.tri;
     if (CLOSEST) { h.u = closer ? u : h.u; h.v = closer ? v : h.v; }
@@ -593,14 +620,17 @@ DEV void tri_test(Hit &h, int t, float ox, float oy, float oz, float dx, float d
 // Traversal of a vine = a scan of its list in the order the reference's DFS meets the nodes: fork i (its own box is
 // tested against the current tHit, :296-298; a failed test pushes nothing, which ends the traversal), then the
 // triangle hanging off it; the last record is the final fork's other leaf, reached without a test (infinite box).
-// All lanes of a wave walk the same list position: the record address is wave-uniform, so the compiler fetches it
-// with scalar loads and broadcasts it -- no vector-memory traffic, no stack.
+// All lanes of a wave walk the same list position: the record address is wave-uniform, so records come in through the scalar
+// cache and are broadcast -- no vector-memory traffic, no stack.  List layout: DevScene::vine.
+// A list whose forks all have the same box (what glrt_bvh_build_chain emits: BASELINE config 3) is scanned by the hand-written
+// loop of scan_asm.hip.h; this C++ statement serves every other vine, and as the form the assembly is checked against (-DGLRTX_SCAN_CXX).
+// Precondition: stop_d - limit < EPS (see scan_asm.hip.h).
 template <bool CLOSEST>
 DEV Hit trav_scan(const DevScene &sc, float ox, float oy, float oz, float dx, float dy, float dz, bool valid,
               float limit = PT_INFTY, float stop_d = -__builtin_inff()) {
     Hit h;
     h.t = limit; h.tri = -1; h.u = 0.f; h.v = 0.f;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float ix = frcp(dx), iy = frcp(dy), iz = frcp(dz);
     bool alive = valid;
     float t0u = 0.f, t1u = 0.f;
     if (sc.vine_uniform) {  // one box for every fork: its slab interval is a per-ray constant
@@ -609,14 +639,28 @@ DEV Hit trav_scan(const DevScene &sc, float ox, float oy, float oz, float dx, fl
         const float nx = (lo.x - ox) * ix, ny = (lo.y - oy) * iy, nz = (lo.z - oz) * iz;
         t1u = __builtin_fminf(__builtin_fmaxf(fx, nx), __builtin_fminf(__builtin_fmaxf(fy, ny), __builtin_fmaxf(fz, nz)));
         t0u = __builtin_fmaxf(__builtin_fminf(fx, nx), __builtin_fmaxf(__builtin_fminf(fy, ny), __builtin_fminf(fz, nz)));
+#ifndef GLRTX_SCAN_CXX
+        if (valid) {
+            unsigned groups = (unsigned)sc.vine_main >> 2;
+            unsigned long long s_entry, s_alive, s_tmp;
+            asm volatile(GLRTX_SCAN_UNIFORM_ASM
+                         : [th] "+&v"(h.t), [tri] "+&v"(h.tri), [hu] "+&v"(h.u), [hv] "+&v"(h.v), [grp] "+&s"(groups), [entry] "=&s"(s_entry), [alive] "=&s"(s_alive),
+                           [tmp] "=&s"(s_tmp)
+                         : [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [sd] "v"(stop_d),
+                           [t0u] "v"(t0u), [t1u] "v"(t1u), [ptr] "s"(sc.vine), [eps] "s"(PT_EPS)
+                         : "vcc", "scc", "memory", GLRTX_ASM_VCLOBBERS, GLRTX_SCAN_SCLOBBERS);
+        }
+        return h;
+#endif
     }
-    const int n = sc.n_vine;
-    // Records come in through the scalar cache (the list position is wave-uniform), one record ahead of the arithmetic:
-    // 16 SGPRs per record, two sets used alternately.  (As plain loads the compiler issues them on the vector-memory
-    // path, per lane.)  The waits are explicit because the compiler does not count loads issued from inline asm.
+    const int n = sc.n_vine, last_at = sc.vine_main;
+    // Two records in flight while two are worked on (four sets of 16 SGPRs; as plain loads the compiler would fetch the records on the vector-memory path, per
+    // lane).  The waits are explicit because the compiler does not count loads issued from inline asm; scalar loads return out of order, so the only wait there
+    // is is lgkmcnt(0), and a load is covered by the work issued between it and that wait.  i: position in the visiting order; the last leaf's record lies at
+    // index vine_main, never-hit records around it (positions past the end read those; they are not stepped).
     typedef float rec_t __attribute__((ext_vector_type(16)));
-    auto issue = [&](rec_t &r, int i) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(sc.vine + 4 * (size_t)i) : "memory"); };
-    auto arrive = [&](rec_t &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r) : : "memory"); };  // readers of r are ordered behind the wait
+    auto issue = [&](rec_t &r, int i) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(sc.vine + 4 * (size_t)(i < n - 1 ? i : last_at + (i - (n - 1)))) : "memory"); };
+    auto pair_arrive = [&](rec_t &a, rec_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) : : "memory"); };
     auto step = [&](const rec_t &r, int i) {
         if (alive) {
             bool pass;
@@ -632,18 +676,23 @@ DEV Hit trav_scan(const DevScene &sc, float ox, float oy, float oz, float dx, fl
             }
         }
     };
-    rec_t r0, r1;
-    issue(r0, 0);
-    arrive(r0);
-    for (int i = 0; i < n; i += 2) {
+    rec_t a0, a1, b0, b1;
+    issue(a0, 0);
+    issue(a1, 1);
+    pair_arrive(a0, a1);
+    for (int i = 0; i < n; i += 4) {
         if (!__any(alive)) break;
-        if (i + 1 < n) issue(r1, i + 1);
-        step(r0, i);
-        if (i + 1 >= n) break;
-        arrive(r1);
-        if (i + 2 < n) issue(r0, i + 2);
-        step(r1, i + 1);
-        if (i + 2 < n) arrive(r0);
+        issue(b0, i + 2);
+        issue(b1, i + 3);
+        step(a0, i);
+        if (i + 1 < n) step(a1, i + 1);
+        pair_arrive(b0, b1);
+        if (i + 2 >= n) break;
+        issue(a0, i + 4);
+        issue(a1, i + 5);
+        step(b0, i + 2);
+        if (i + 3 < n) step(b1, i + 3);
+        pair_arrive(a0, a1);
     }
     return h;
 }
@@ -665,17 +714,17 @@ DEV float fresnel1(float c2, float s2, float cosI, float eta, float k) {
     const float temp1 = a2pb2 + c2;
     const float a = __builtin_sqrtf(fmax_c((a2pb2 + temp0) * 0.5f, 0.0f));
     const float temp2 = (2.0f * a) * cosI;
-    const float Rs2 = (temp1 - temp2) / (temp1 + temp2);
+    const float Rs2 = fdiv(temp1 - temp2, temp1 + temp2);
     const float temp3 = a2pb2 * c2 + s2 * s2;
     const float temp4 = temp2 * s2;
-    const float Rp2 = (Rs2 * (temp3 - temp4)) / (temp3 + temp4);
+    const float Rp2 = fdiv(Rs2 * (temp3 - temp4), temp3 + temp4);
     return 0.5f * (Rp2 + Rs2);
 }
 // GGX :180-184, denominator associated as (PI*ax) * ((ay*l2)*l2)
 DEV float ggx(float hx, float hy, float hz, float ax, float ay) {
-    const float sx = hx / ax, sy = hy / ay;
+    const float sx = fdiv(hx, ax), sy = fdiv(hy, ay);
     const float l2 = (hz * hz + sy * sy) + sx * sx;
-    return 1.0f / ((PT_PI * ax) * ((ay * l2) * l2));
+    return frcp((PT_PI * ax) * ((ay * l2) * l2));
 }
 
 struct Mat {
@@ -801,7 +850,7 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
             const float fnx = entering ? nx : -nx, fny = entering ? ny : -ny, fnz = entering ? nz : -nz;
             const float ci = __builtin_fabsf(ci0);
             const float ior = M.m2.x;
-            const float eta = entering ? 1.0f / ior : ior;
+            const float eta = entering ? frcp(ior) : ior;
             const float k = 1.0f - (eta * eta) * (1.0f - ci * ci);
             float F = 1.0f;  // total internal reflection
             float ct = 0.0f;
@@ -850,8 +899,9 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
                 wlx = pt_cos(r1) * r2s;
                 wly = pt_sin(r1) * r2s;
                 wlz = __builtin_sqrtf(1.0f - rb);
-                fx = M.m1.x / PT_PI; fy = M.m1.y / PT_PI; fz = M.m1.z / PT_PI;
-                pdf = wlz / PT_PI;
+                if (sc.mats_in_lds) { fx = M.m2.x; fy = M.m2.y; fz = M.m2.z; }  // albedo / PI, formed when the materials were staged (stage_mats)
+                else { fx = div_pi(M.m1.x); fy = div_pi(M.m1.y); fz = div_pi(M.m1.z); }
+                pdf = div_pi(wlz);
             } else if (type == 3) {
                 // conductor :520-532; param0 = kappa, param1 = eta
                 const float ax = M.m1.w, ay = M.m2.w;
@@ -900,14 +950,14 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
                 const float len_wi = __builtin_sqrtf((c2 + wisy * wisy) + wisx * wisx);
                 const float len_wo = __builtin_sqrtf(lw);
                 const float den = 2.0f * (__builtin_fabsf(woz) * len_wi + __builtin_fabsf(wlz) * len_wo);
-                const float brdf = D / den;
+                const float brdf = fdiv(D, den);
                 fx = Fx * brdf; fy = Fy * brdf; fz = Fz * brdf;
                 // weightedGGXPDF :216-219
                 const float D2 = ggx(whx, why, whz, ax, ay);
-                const float g1 = 0.5f / (len_wo + woz);
+                const float g1 = fdiv(0.5f, len_wo + woz);
                 const float pn = (g1 * D2) * fmax_c(dwh, 0.0f);
                 const float dwi = (wlz * whz + wly * why) + wlx * whx;
-                pdf = pn / fmax_c(dwi, PT_EPS);
+                pdf = fdiv(pn, fmax_c(dwi, PT_EPS));
             }
 
             // isBlack(f) || pdf == 0 :534, evaluated as min(|f|, |pdf|) == 0
@@ -971,7 +1021,7 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
                         const float wosx = wox * ax, wosy = woy * ay;
                         const float len_wo = __builtin_sqrtf((woz * woz + wosy * wosy) + wosx * wosx);
                         const float den = 2.0f * (__builtin_fabsf(woz) * len_wi + __builtin_fabsf(ilz) * len_wo);
-                        const float brdf = D / den;
+                        const float brdf = fdiv(D, den);
                         gx = Fx * brdf; gy = Fy * brdf; gz = Fz * brdf;
                     }
                     const Mat LM = load_mat(sc, lds_mats, __float_as_int(V0.w));
@@ -983,12 +1033,12 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
                         const float kx = e1y * e2z - e1z * e2y;
                         const float ky = e1z * e2x - e1x * e2z;
                         const float kz = e1x * e2y - e1y * e2x;
-                        const float G = (dot0 * dot1) / dd;  // dist*dist is folded to dd
+                        const float G = fdiv(dot0 * dot1, dd);  // dist*dist is folded to dd
                         const float area = 0.5f * __builtin_sqrtf((kz * kz + ky * ky) + kx * kx);
-                        const float lpdf = 1.0f / (area * nLf);
-                        cx = ((LM.m0.x * gx) * G) / lpdf;
-                        cy = ((LM.m0.y * gy) * G) / lpdf;
-                        cz = ((LM.m0.z * gz) * G) / lpdf;
+                        const float lpdf = frcp(area * nLf);
+                        cx = fdiv((LM.m0.x * gx) * G, lpdf);
+                        cy = fdiv((LM.m0.y * gy) * G, lpdf);
+                        cz = fdiv((LM.m0.z * gz) * G, lpdf);
                     }
                 }
             }
@@ -1002,9 +1052,9 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
             ox = sox; oy = soy; oz = soz;
             dx = wix; dy = wiy; dz = wiz;
             const float cw = fmax_c((nz * wiz + ny * wiy) + nx * wix, 0.0f);
-            bx = bx * ((fx * cw) / pdf);
-            by = by * ((fy * cw) / pdf);
-            bz = bz * ((fz * cw) / pdf);
+            bx = bx * fdiv(fx * cw, pdf);
+            by = by * fdiv(fy * cw, pdf);
+            bz = bz * fdiv(fz * cw, pdf);
             if (EXT && (ext_flags & EXT_WHITTED) && type == 2) stop_after = true;  // Whitted: direct light only at a diffuse surface
         }
         if (EXT && stop_after) break;
@@ -1016,7 +1066,7 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
             const float pq = fmin_c(pm, 0.95f);
             const float rr = pt_rand(rng);
             if (pq < rr) break;
-            bx = bx / pq; by = by / pq; bz = bz / pq;
+            bx = fdiv(bx, pq); by = fdiv(by, pq); bz = fdiv(bz, pq);
         }
         done = false;
     } while (false);
@@ -1202,12 +1252,23 @@ DEV int local_row_to_y(const KernelArgs &a, int lrow) {  // owned stripe s holds
     return ((lrow / a.stripe) * a.world + a.rank) * a.stripe + lrow % a.stripe;
 }
 
+// Materials into LDS (at most kMaxLdsMaterials).  A diffuse material's BSDF value -- albedo / PI (:514), the same three quotients at every diffuse hit -- is
+// formed here, once per workgroup, in the slot a diffuse material leaves unused (param1); shade_core reads it instead of dividing.
+DEV void stage_mats(const KernelArgs &a, float4 *lds_mats) {
+    for (int m = threadIdx.x; m < a.sc.n_mat; m += kBlockThreads) {
+        const float4 m0 = a.sc.mats[3 * m], m1 = a.sc.mats[3 * m + 1];
+        float4 m2 = a.sc.mats[3 * m + 2];
+        if (__float_as_int(m0.w) == 2) { m2.x = m1.x / PT_PI; m2.y = m1.y / PT_PI; m2.z = m1.z / PT_PI; }
+        lds_mats[3 * m] = m0; lds_mats[3 * m + 1] = m1; lds_mats[3 * m + 2] = m2;
+    }
+}
+
 DEV void lds_setup(const KernelArgs &a, unsigned char *lds_raw, float4 *&lds_mats, int *&stack) {
     lds_mats = reinterpret_cast<float4 *>(lds_raw);
     const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
     stack = reinterpret_cast<int *>(lds_raw + (size_t)mat_f4 * sizeof(float4)) + 2 * threadIdx.x;  // 8-byte entries
     if (a.sc.mats_in_lds) {
-        for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
+        stage_mats(a, lds_mats);
         __syncthreads();
     }
 }
@@ -1720,7 +1781,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         if (lane < cnt) {
             o = ld_stream(&rq[2 * (size_t)(base + lane)]);
             d = ld_stream(&rq[2 * (size_t)(base + lane) + 1]);
-            cur_ix = 1.0f / d.x; cur_iy = 1.0f / d.y; cur_iz = 1.0f / d.z;
+            cur_ix = frcp(d.x); cur_iy = frcp(d.y); cur_iz = frcp(d.z);
             const bool shadow = (__float_as_uint(o.w) & 1u) != 0u;
             float t0;
             if (a.sc.root_boxed && !box_pass(root[0], root[1], o.x, o.y, o.z, cur_ix, cur_iy, cur_iz, shadow ? shadow_limit(d.w) : PT_INFTY, t0))
@@ -1754,7 +1815,7 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
             susp[3] = make_float4(0.f, 0.f, 0.f, 0.f);
             T.ox = s0.x; T.oy = s0.y; T.oz = s0.z; rid = __float_as_uint(s0.w);
             T.dx = s1.x; T.dy = s1.y; T.dz = s1.z; T.stop_d = s1.w;
-            T.ix = 1.0f / T.dx; T.iy = 1.0f / T.dy; T.iz = 1.0f / T.dz;  // :260, as at chunk time
+            T.ix = frcp(T.dx); T.iy = frcp(T.dy); T.iz = frcp(T.dz);  // :260, as at chunk time
             T.h.t = s2.x; T.h.tri = __float_as_int(s2.y); T.h.u = s2.z; T.h.v = s2.w;
             T.cur = __float_as_int(s3.x); T.sp = __float_as_int(s3.y);
 #ifdef GLRTX_TRAV_STATS
@@ -1976,8 +2037,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     // per-workgroup slice of the queue buffer: ray records float4[2][2 * block_paths][2], then path ids unsigned[2][block_paths]
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
     unsigned *pathQ = reinterpret_cast<unsigned *>(rayQ + 8 * (size_t)w.block_paths);
-    if (a.sc.mats_in_lds)
-        for (int i = threadIdx.x; i < mat_f4; i += kBlockThreads) lds_mats[i] = a.sc.mats[i];
+    if (a.sc.mats_in_lds) stage_mats(a, lds_mats);
 
     const int kWgPaths = w.block_paths;
     unsigned long long rays = 0;  // low half: reference rays, high half: those resolved without a traversal

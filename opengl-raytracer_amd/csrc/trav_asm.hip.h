@@ -32,8 +32,7 @@
 // address), 22 without.  Of those: 22 scratch registers v[GLRTX_VB .. GLRTX_VB+21] (GLRTX_ASM_VBASE, default 96; clobbered), written below relative to the
 // assembler symbol GLRTX_VB; in the default build they are v96-v117: v96-v99 A, v100-v103 B, v104-v106 C, v108-v110 D (the 56-byte record; the arms
 // compute in place in it), v107 = REF_FIN, v111 an address / u, v112-v117 temporaries.  gfx950 hazards handled by hand (the assembler does not insert wait
-// states into inline asm): one independent instruction between v_rcp_f32 and the first use of its result (trans forwarding);
-// >= 4 instructions between v_div_scale (vcc) and v_div_fmas.
+// states into inline asm): one independent instruction between v_rcp_f32 and the first use of its result (trans forwarding).
 #pragma once
 
 #ifndef GLRTX_STEPS_PER_TRIP
@@ -301,24 +300,8 @@ static_assert(GLRTX_STEPS_PER_TRIP % 2 == 0, "the alternating form of the node f
     "v_sub_f32 v[GLRTX_VB+0], %[ox], v[GLRTX_VB+0]\n\t"                                     /* t = o - v0, in place */                                                     \
     "v_sub_f32 v[GLRTX_VB+1], %[oy], v[GLRTX_VB+1]\n\t"                                                                                                                    \
     "v_sub_f32 v[GLRTX_VB+2], %[oz], v[GLRTX_VB+2]\n\t"                                                                                                                    \
-    "v_fma_f32 v[GLRTX_VB+19], -v[GLRTX_VB+20], v[GLRTX_VB+21], 1.0\n\t"                              /* 1 / det: v_rcp + one Newton step (rcp_exact) */                             \
+    "v_fma_f32 v[GLRTX_VB+19], -v[GLRTX_VB+20], v[GLRTX_VB+21], 1.0\n\t"                              /* 1 / det: v_rcp + one Newton step (rcp_newton: the IEEE quotient of every normal det, denormals being flushed) */                             \
     "v_fma_f32 v[GLRTX_VB+21], v[GLRTX_VB+19], v[GLRTX_VB+21], v[GLRTX_VB+21]\n\t"                                                                                                             \
-    "v_cmp_lt_f32_e64 vcc, %[big], |v[GLRTX_VB+20]|\n\t"                          /* |det| > 2^126: the full IEEE quotient */                                    \
-    "s_cbranch_vccz 12f\n\t"                                                                                                                           \
-    "v_div_scale_f32 v[GLRTX_VB+19], %[tmp], v[GLRTX_VB+20], v[GLRTX_VB+20], 1.0\n\t"                                                                                                \
-    "v_rcp_f32 v[GLRTX_VB+12], v[GLRTX_VB+19]\n\t"                                                                                                                         \
-    "v_div_scale_f32 v[GLRTX_VB+13], vcc, 1.0, v[GLRTX_VB+20], 1.0\n\t"                                                                                                    \
-    "v_fma_f32 v[GLRTX_VB+14], -v[GLRTX_VB+19], v[GLRTX_VB+12], 1.0\n\t"                                                                                                             \
-    "v_fma_f32 v[GLRTX_VB+12], v[GLRTX_VB+14], v[GLRTX_VB+12], v[GLRTX_VB+12]\n\t"                                                                                                             \
-    "v_mul_f32 v[GLRTX_VB+14], v[GLRTX_VB+13], v[GLRTX_VB+12]\n\t"                                                                                                                   \
-    "v_fma_f32 v[GLRTX_VB+7], -v[GLRTX_VB+19], v[GLRTX_VB+14], v[GLRTX_VB+13]\n\t"                                                                                                            \
-    "v_fma_f32 v[GLRTX_VB+14], v[GLRTX_VB+7], v[GLRTX_VB+12], v[GLRTX_VB+14]\n\t"                                                                                                             \
-    "v_fma_f32 v[GLRTX_VB+19], -v[GLRTX_VB+19], v[GLRTX_VB+14], v[GLRTX_VB+13]\n\t"                                                                                                            \
-    "v_div_fmas_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+12], v[GLRTX_VB+14]\n\t"                                                                                                        \
-    "v_div_fixup_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+20], 1.0\n\t"                                                                                                        \
-    "v_cmp_lt_f32_e64 vcc, %[big], |v[GLRTX_VB+20]|\n\t"                                                                                                         \
-    "v_cndmask_b32 v[GLRTX_VB+21], v[GLRTX_VB+21], v[GLRTX_VB+19], vcc\n\t"                                                                                                          \
-    "12:\n\t"                                                                                                                                          \
     "v_mul_f32 v[GLRTX_VB+18], v[GLRTX_VB+2], v[GLRTX_VB+18]\n\t"                                     /* U = (tz pz + ty py) + tx px */                                              \
     "v_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+1], v[GLRTX_VB+17]\n\t"                                                                                                                    \
     "v_add_f32 v[GLRTX_VB+18], v[GLRTX_VB+18], v[GLRTX_VB+19]\n\t"                                                                                                                   \

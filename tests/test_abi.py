@@ -59,8 +59,9 @@ def test_code_object_invariants():
     destination of trav_scan's s_load_dwordx16 between the load and its s_waitcnt (the load and the wait are separate asm statements),
     the hand-written pop loop of trav_step keeps its sentinel and the ref it overwrites in different registers, and behind every node fetch of
     the hand-written step the waits come in stages (one record per lane: vmcnt(3) .. vmcnt(0); pair-cooperative fetch: vmcnt(2), vmcnt(0)) with no other
-    vector-memory instruction in between, and the DPP moves of the pair exchange keep their manual hazards.  The timed instantiations -- both forms of the
-    node fetch and the list scan -- spill nothing."""
+    vector-memory instruction in between, and the DPP moves of the pair exchange keep their manual hazards.  The timed instantiations of the tree kernels
+    spill nothing; the list scan keeps four record sets in 64 fixed SGPRs (csrc/scan_asm.hip.h), so the compiler parks the kernel's own scalar values in
+    VGPR lanes around the scan -- once per 64 rays and 10,000 records: no vector spills, no scratch memory."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_report.py"), "--check"], capture_output=True, text=True, timeout=300)
@@ -69,4 +70,4 @@ def test_code_object_invariants():
         rows = [ln.replace(f"glrtx::pt_render_wgwf<{inst}>", "K").split() for ln in r.stdout.splitlines() if ln.startswith(f"glrtx::pt_render_wgwf<{inst}>")]
         assert rows, r.stdout
         vgpr, agpr, sgpr, vspill, sspill, scratch = (int(v) for v in rows[0][1:7])
-        assert vspill == 0 and scratch == 0 and sspill == 0 and vgpr <= 128, (inst, rows[0])
+        assert vspill == 0 and scratch == 0 and sspill <= (40 if inst == "false, true, 0" else 0) and vgpr <= 128, (inst, rows[0])

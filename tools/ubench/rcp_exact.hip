@@ -1,41 +1,57 @@
-// Exhaustive check: for which float32 x does a short reciprocal sequence (v_rcp_f32 + Newton steps with FMA) give exactly the
-// correctly rounded 1.0f / x that the compiler's IEEE division expansion gives?  All 2^32 bit patterns.
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -o rcp_exact rcp_exact.hip && ./rcp_exact
+// Exhaustive checks behind the short quotients of pt_kernel.hip.h, trav_asm.hip.h and scan_asm.hip.h: every float32 bit pattern, on the device, against the
+// compiler's correctly rounded IEEE division -- in the float mode the kernels run in: fp32 denormals flushed on input and output (-fgpu-flush-denormals-to-zero,
+// what the reference's GL implementation does: llvmpipe's rasteriser threads set MXCSR FTZ | DAZ).
+//   newton(x)  = v_rcp_f32 + one Newton step with fused multiply-adds                     -- 1 / det in the triangle tests (no guard around it)
+//   frcp(x)    = newton(x), but the raw v_rcp_f32 result where x is a zero, a denormal or an infinity   -- 1 / x everywhere else (rsq, 1 / d, ...)
+//   div_pi(x)  = x * RN(1 / PI) corrected by one residual step; full division for the waves that hold a tiny or huge x       -- x / PI
+// Built like the kernels:  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
-__device__ __forceinline__ float rcp_hw(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float seq1(float x) { float r = rcp_hw(x); float e = __builtin_fmaf(-x, r, 1.0f); return __builtin_fmaf(e, r, r); }
-__device__ __forceinline__ float seq2(float x) { float r = seq1(x); float e = __builtin_fmaf(-x, r, 1.0f); return __builtin_fmaf(e, r, r); }
-// out[0..1]: mismatches of seq1 / seq2 inside [lo, hi]; out[2..5]: smallest / largest |x| bit pattern with a seq2 mismatch; out[6]: values in range
-__global__ void k(unsigned lo_bits, unsigned hi_bits, unsigned long long *out) {
+#define DEV __device__ __forceinline__
+constexpr float PT_PI = 3.14159274101257324f;
+constexpr float PT_INV_PI = 0.318309873342514038f;  // RN(1 / PT_PI)
+DEV float newton(float x) { const float r = __builtin_amdgcn_rcpf(x); return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r); }
+DEV float frcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float n = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    return __builtin_amdgcn_class(x, 0x2F4) ? r : n;  // -inf, -denormal, -0, +0, +denormal, +inf
+}
+DEV float div_pi(float x) {
+    const unsigned a = __float_as_uint(x) & 0x7FFFFFFFu;
+    const bool plain = a != 0u && (a - 0x0D800000u) > (0x7B800000u - 0x0D800000u);  // 0 < |x| < 2^-100, |x| > 2^120, inf, NaN
+    if (__any(plain)) return x / PT_PI;
+    const float q = x * PT_INV_PI;
+    return __builtin_fmaf(__builtin_fmaf(-PT_PI, q, x), PT_INV_PI, q);
+}
+DEV bool same(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+// out[0]: newton mismatches with |x| >= FLT_MIN and finite; [1]: newton mismatches among zeros / denormals / infinities / NaNs; [2]: frcp mismatches (all);
+// [3]: div_pi mismatches (all); [4]: patterns visited; [5]: newton mismatches with |x| > 2^126 (the quotient is flushed: both must give a zero of det's sign)
+__global__ void k(unsigned long long *out) {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    unsigned long long m1 = 0, m2 = 0, n = 0;
-    unsigned lo_bad = 0xFFFFFFFFu, hi_bad = 0u;
+    unsigned long long m[6] = {0, 0, 0, 0, 0, 0};
     for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < (1ull << 32); u += stride) {
-        const unsigned a = (unsigned)u & 0x7FFFFFFFu;
-        if (a < lo_bits || a > hi_bits) continue;
         const float x = __uint_as_float((unsigned)u);
+        const unsigned a = (unsigned)u & 0x7FFFFFFFu;
         const float ref = 1.0f / x;
-        n++;
-        if (__float_as_uint(seq1(x)) != __float_as_uint(ref)) m1++;
-        if (__float_as_uint(seq2(x)) != __float_as_uint(ref)) { m2++; lo_bad = a < lo_bad ? a : lo_bad; hi_bad = a > hi_bad ? a : hi_bad; }
+        const bool ordinary = a >= 0x00800000u && a < 0x7F800000u;
+        if (!same(newton(x), ref)) { m[ordinary ? 0 : 1]++; if (ordinary && a > 0x7E800000u) m[5]++; }
+        if (!same(frcp(x), ref)) m[2]++;
+        if (!same(div_pi(x), x / PT_PI)) m[3]++;
+        m[4]++;
     }
-    atomicAdd(&out[0], m1); atomicAdd(&out[1], m2); atomicAdd(&out[6], n);
-    atomicMin((unsigned *)&out[2], lo_bad); atomicMax((unsigned *)&out[3], hi_bad);
+    for (int i = 0; i < 6; i++) atomicAdd(&out[i], m[i]);
 }
 int main() {
-    unsigned long long *d, h[8];
-    hipMalloc(&d, sizeof h);
-    const float ranges[][2] = {{1e-4f, 1e30f}, {1.1754944e-38f, 1.7014118e38f}, {1e-30f, 1e30f}};
-    for (auto &r : ranges) {
-        unsigned lo, hi; memcpy(&lo, &r[0], 4); memcpy(&hi, &r[1], 4);
-        unsigned long long init[8] = {0, 0, 0xFFFFFFFFull, 0, 0, 0, 0, 0};
-        hipMemcpy(d, init, sizeof init, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(k, dim3(4096), dim3(256), 0, 0, lo, hi, d);
-        hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
-        printf("|x| in [%g, %g]: %llu values; rcp + 1 Newton step: %llu mismatches; rcp + 2 steps: %llu mismatches (|x| bits %08x .. %08x)\n", r[0], r[1], h[6], h[0], h[1], (unsigned)h[2], (unsigned)h[3]);
-    }
+    unsigned long long *d, h[6] = {0, 0, 0, 0, 0, 0};
+    if (hipMalloc(&d, sizeof h) != hipSuccess) return 2;
+    hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3(4096), dim3(256), 0, 0, d);
+    if (hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    printf("patterns %llu\n", h[4]);
+    printf("newton: %llu mismatches among normal finite x (%llu of them above 2^126), %llu among zeros, denormals, infinities and NaNs\n", h[0], h[5], h[1]);
+    printf("frcp: %llu mismatches\n", h[2]);
+    printf("div_pi: %llu mismatches\n", h[3]);
     return 0;
 }
