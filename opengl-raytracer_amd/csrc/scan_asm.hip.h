@@ -5,11 +5,16 @@
 // (reference: intersect(Ray, Triangle) raytrace.frag:226-257, intersectBBox :259-274, the cull of :298), the same IEEE operations in the same order; the
 // C++ statement stays in trav_scan() for lists whose forks have boxes of their own, and tests/test_gpu_parity.py compares both with the oracle.
 //
-// Why by hand (profiles/r04_c3_*): as compiled, a record cost a SIMD ~57 vector + ~20 scalar instructions + ~7 branches -- the scan sat at the SIMDs'
-// issue limit with more than a third of it spent on exec-mask bookkeeping, and computed the whole triangle test for every record although all 64 lanes miss
-// most triangles after the first barycentric.  Here the common case -- no lane of the wave passes the u test -- is 30 vector instructions, one scalar one
-// and one branch that is not taken; everything behind the u test and the shadow rays' early stop (needed only after a hit) sit out of line.  Four sets of 16 SGPRs: two records are worked on while the next two are in flight (a scalar load that misses the scalar
-// cache takes ~600 clk, scalar loads return out of order, so the only wait is lgkmcnt(0): a load is covered by what is issued between it and that wait).
+// Why by hand (profiles/r04_c3_*, r04_ab_list_scan.txt): as compiled, a record cost a SIMD ~57 vector + ~20 scalar instructions + ~7 branches -- the scan sat at
+// the SIMDs' issue limit with more than a third of it spent on exec-mask bookkeeping, and computed the whole triangle test for every record although all 64
+// lanes miss most triangles after the first barycentric.  Here the common case -- no lane of the wave passes the u test -- is 30 vector instructions, one scalar
+// one and one branch that is not taken; everything behind the u test, the commit of a closer hit, the shadow rays' early stop and the next fork's box test (all
+// needed only after a hit) sit out of line.  The box test of a list with ONE common fork box -- min(t1u, tHit) >= t0u, a per-ray constant interval -- changes
+// its verdict only when tHit does: it is evaluated in front of the loop and behind hits, not per record.  Four sets of 16 SGPRs: two records are worked on
+// while the next two are in flight (scalar loads return out of order, so the only wait is lgkmcnt(0): a load is covered by what is issued between it and that
+// wait).  Measured and not kept: six sets of ten dwords, three records ahead (the same time: the scan is not waiting for its records, it issues vector
+// instructions); the products and differences as v_pk_mul_f32 / v_pk_add_f32 on register pairs, 23 instructions instead of 30 (exact, and 4 % slower: a packed
+// instruction takes the SIMD as long as its two results would).
 //
 // List layout (glrtx.hip: pack_scene): the n - 1 fork records, never-hit records up to a multiple of four (vine_main), the last leaf's record there (its
 // box is infinite: tested with the general box test, as the reference reaches that leaf without a test), three never-hit records behind it.
@@ -87,13 +92,13 @@
     "v_cmpx_nlt_f32_e64 %[tmp], |v[GLRTX_VB+4]|, %[eps]\n\t"          /* !(-EPS < det && det < EPS) */ \
     "v_cmpx_ngt_f32 vcc, 0, v[GLRTX_VB+10]\n\t"                       /* !(u < 0) */ \
     "v_cmpx_nlt_f32 vcc, 1.0, v[GLRTX_VB+10]\n\t"                     /* !(1 < u) */ \
-    "s_cbranch_execnz Lscan_rest" #ID "_%=\n\t"                       /* some lane may still hit: the rest of the test, out of line */ \
-    "Lscan_back" #ID "_%=:\n\t" \
+    "s_cbranch_execnz .Lscan_rest" #ID "_%=\n\t"                       /* some lane may still hit: the rest of the test, out of line */ \
+    ".Lscan_back" #ID "_%=:\n\t" \
     "s_mov_b64 exec, %[alive]\n\t"
 
 // Out of line, per record set: the rest of the triangle test with the commit of a closer hit and the shadow rays' early stop.
 #define GLRTX_SCAN_TRI_REST(S, ID) \
-    "Lscan_rest" #ID "_%=:\n\t" \
+    ".Lscan_rest" #ID "_%=:\n\t" \
     "v_mul_f32 v[GLRTX_VB+12], s[" S "+11], v[GLRTX_VB+7]\n\t"        /* q = t x e1 */ \
     "v_mul_f32 v[GLRTX_VB+11], s[" S "+10], v[GLRTX_VB+8]\n\t" \
     "v_sub_f32 v[GLRTX_VB+12], v[GLRTX_VB+12], v[GLRTX_VB+11]\n\t" \
@@ -113,7 +118,7 @@
     "v_mul_f32 v[GLRTX_VB+11], v[GLRTX_VB+5], v[GLRTX_VB+11]\n\t"     /* inv (U + V): u + v > 1 is tested on it */ \
     "v_cmpx_ngt_f32 vcc, 0, v[GLRTX_VB+16]\n\t"                       /* !(v < 0) */ \
     "v_cmpx_nlt_f32 vcc, 1.0, v[GLRTX_VB+11]\n\t"                     /* !(1 < inv (U + V)) */ \
-    "s_cbranch_execz Lscan_back" #ID "_%=\n\t"                        /* nothing was hit: tHit stands, and so does every lane's early-stop verdict */ \
+    "s_cbranch_execz .Lscan_back" #ID "_%=\n\t"                        /* nothing was hit: tHit stands, and so does every lane's early-stop verdict */ \
     "v_mul_f32 v[GLRTX_VB+18], s[" S "+14], v[GLRTX_VB+14]\n\t"       /* t = ((e2.z qz + e2.y qy) + e2.x qx) inv */ \
     "v_mul_f32 v[GLRTX_VB+11], s[" S "+13], v[GLRTX_VB+13]\n\t" \
     "v_add_f32 v[GLRTX_VB+18], v[GLRTX_VB+18], v[GLRTX_VB+11]\n\t" \
@@ -131,7 +136,7 @@
     "v_cmpx_nle_f32 vcc, %[eps], v[GLRTX_VB+11]\n\t"                  /* !(stop_d - tHit >= EPS): the ray goes on */ \
     GLRTX_SCAN_BOX_UNIFORM                                             /* ... if the next fork's box is still within reach (tHit has changed) */ \
     "s_mov_b64 %[alive], exec\n\t" \
-    "s_branch Lscan_back" #ID "_%=\n\t"
+    "s_branch .Lscan_back" #ID "_%=\n\t"
 
 // A fork of the common box: its test -- min(t1u, tHit) >= t0u -- changes its verdict only when tHit changes, so it is evaluated once in front of the loop and
 // behind every hit (GLRTX_SCAN_TRI_REST), not per record; exec = %[alive] = the lanes still scanning on entry and on exit.
@@ -148,7 +153,7 @@
     GLRTX_SCAN_BOX_UNIFORM \
     "s_mov_b64 %[alive], exec\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t" \
-    "Lscan_loop_%=:\n\t" \
+    ".Lscan_loop_%=:\n\t" \
     "s_load_dwordx16 s[GLRTX_SB0:GLRTX_SB0+15], s[34:35], 0x80\n\t" \
     "s_load_dwordx16 s[GLRTX_SB1:GLRTX_SB1+15], s[34:35], 0xc0\n\t" \
     GLRTX_SCAN_STEP_UNIFORM("GLRTX_SA0", 1) \
@@ -162,15 +167,15 @@
     "s_addc_u32 s35, s35, 0\n\t" \
     "s_sub_u32 %[grp], %[grp], 1\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t" \
-    "s_cbranch_execz Lscan_end_%=\n\t"                                /* no lane is still scanning */ \
+    "s_cbranch_execz .Lscan_end_%=\n\t"                                /* no lane is still scanning */ \
     "s_cmp_lg_u32 %[grp], 0\n\t" \
-    "s_cbranch_scc1 Lscan_loop_%=\n\t" \
+    "s_cbranch_scc1 .Lscan_loop_%=\n\t" \
     GLRTX_SCAN_STEP_RECORD("GLRTX_SA0", 5)                            /* the last leaf (index vine_main: fetched by the last pass of the loop) */ \
-    "s_branch Lscan_end_%=\n\t" \
+    "s_branch .Lscan_end_%=\n\t" \
     GLRTX_SCAN_TRI_REST("GLRTX_SA0", 1) \
     GLRTX_SCAN_TRI_REST("GLRTX_SA1", 2) \
     GLRTX_SCAN_TRI_REST("GLRTX_SB0", 3) \
     GLRTX_SCAN_TRI_REST("GLRTX_SB1", 4) \
     GLRTX_SCAN_TRI_REST("GLRTX_SA0", 5) \
-    "Lscan_end_%=:\n\t" \
+    ".Lscan_end_%=:\n\t" \
     "s_mov_b64 exec, %[entry]"

@@ -347,7 +347,7 @@ def _scan_case(d, sc, params, what, ref=None, ref_rays=None):
         assert_bit_equal(acc, ref, f"{what}, counting {count}")
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 64, 65, 130])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 19, 64, 65, 130])
 def test_list_scan_of_any_length(gpu_device, n):
     """The hand-written scan works through the list in groups of four records with the last leaf's record behind them (never-hit records fill the last
     group): every remainder of (n - 1) mod 4, the shortest list there is, and lists of about one and two wave's worth of records."""

@@ -24,12 +24,20 @@ src = root / "gpurun_out" / f"prof_{tag}"
 dst = root / "profiles"
 dst.mkdir(exist_ok=True)
 
-for f in glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")):
+def newest(pattern):
+    """Per pass directory the files of the NEWEST run only: gpurun merges a call's output into the local gpurun_out/, where an earlier call's files remain."""
+    by_dir = collections.defaultdict(list)
+    for f in glob.glob(pattern):
+        by_dir[pathlib.Path(f).parent].append(f)
+    return [max(fs, key=lambda f: pathlib.Path(f).stat().st_mtime) for fs in by_dir.values()]
+
+
+for f in newest(str(src / "kt" / "*" / "*_kernel_stats.csv")):
     shutil.copy(f, dst / f"{tag}_kernel_stats.csv")
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
-for f in glob.glob(str(src / "pmc_*" / "*" / "*_counter_collection.csv")):
+for f in newest(str(src / "pmc_*" / "*" / "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if kernel_substr in k and "resolve" not in k:

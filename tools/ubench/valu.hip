@@ -92,6 +92,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define I_PKADD(n) "v_pk_add_f32 %" #n ", %20, %" #n "\n\t"
 #define D_PKADD(n) "v_pk_add_f32 %8, %20, %8\n\t"
 #define I_PKMUL_OPSEL(n) "v_pk_mul_f32 %" #n ", %20, %" #n " op_sel_hi:[0,1]\n\t"  // both results take the LOW half of source 0 (the broadcast a slab test would use)
+#define I_PKMUL_S(n) "v_pk_mul_f32 %" #n ", %16, %" #n "\n\t"  // one SGPR-pair source (what a list scan would use: the record is in SGPRs)
+#define I_PKADD_S(n) "v_pk_add_f32 %" #n ", %" #n ", %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"  // x - (SGPR pair)
+#define I_SUB_S(n) "v_subrev_f32 %" #n ", %23, %" #n "\n\t"  // one SGPR source
+#define I_FMA_S(n) "v_fma_f32 %" #n ", %23, %19, %" #n "\n\t"  // one SGPR source
 #define I_PKMOV(n) "v_pk_mov_b32 %" #n ", %20, %21\n\t"
 #define I_MOV(n) "v_mov_b32 %" #n ", %18\n\t"
 #define I_MOV_DPP(n) "v_mov_b32_dpp %" #n ", %18 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -155,6 +159,10 @@ KERNEL(k_med3, false, R64(I_MED3))
 KERNEL(k_pkfma, false, R64P(I_PKFMA))
 KERNEL(k_pkfma_dep, false, R64P(D_PKFMA))
 KERNEL(k_pkmul, false, R64P(I_PKMUL))
+KERNEL(k_pkmul_s, false, R64P(I_PKMUL_S))
+KERNEL(k_pkadd_s, false, R64P(I_PKADD_S))
+KERNEL(k_sub_s, false, R64(I_SUB_S))
+KERNEL(k_fma_s, false, R64(I_FMA_S))
 KERNEL(k_pkmul_dep, false, R64P(D_PKMUL))
 KERNEL(k_pkadd, false, R64P(I_PKADD))
 KERNEL(k_pkadd_dep, false, R64P(D_PKADD))
@@ -207,7 +215,8 @@ static const Entry kTable[] = {
     {"max", "v_max_f32", k_max, 64}, {"max_dep", "v_max_f32, dependent chain", k_max_dep, 64}, {"min", "v_min_f32", k_min, 64}, {"min3", "v_min3_f32", k_min3, 64},
     {"max3", "v_max3_f32", k_max3, 64}, {"med3", "v_med3_f32", k_med3, 64},
     {"pk_fma", "v_pk_fma_f32", k_pkfma, 64}, {"pk_fma_dep", "v_pk_fma_f32, dependent chain", k_pkfma_dep, 64}, {"pk_mul", "v_pk_mul_f32", k_pkmul, 64},
-    {"pk_mul_dep", "v_pk_mul_f32, dependent chain", k_pkmul_dep, 64}, {"pk_add", "v_pk_add_f32", k_pkadd, 64}, {"pk_add_dep", "v_pk_add_f32, dependent chain", k_pkadd_dep, 64},
+    {"pk_mul_dep", "v_pk_mul_f32, dependent chain", k_pkmul_dep, 64}, {"pk_mul_sgpr", "v_pk_mul_f32, one SGPR-pair source", k_pkmul_s, 64},
+    {"pk_add_sgpr", "v_pk_add_f32, minus an SGPR pair", k_pkadd_s, 64}, {"sub_sgpr", "v_subrev_f32, one SGPR source", k_sub_s, 64}, {"fma_sgpr", "v_fma_f32, one SGPR source", k_fma_s, 64}, {"pk_add", "v_pk_add_f32", k_pkadd, 64}, {"pk_add_dep", "v_pk_add_f32, dependent chain", k_pkadd_dep, 64},
     {"pk_mul_opsel", "v_pk_mul_f32 op_sel_hi:[0,1] (broadcast of one half)", k_pkmul_opsel, 64}, {"pk_mov", "v_pk_mov_b32", k_pkmov, 64},
     {"mov", "v_mov_b32", k_mov, 64}, {"mov_dpp", "v_mov_b32_dpp quad_perm", k_mov_dpp, 64},
     {"cndmask_vcc", "v_cndmask_b32 (vcc, not written in the loop)", k_cnd_vcc, 64}, {"cndmask_sgpr", "v_cndmask_b32_e64 (mask in an SGPR pair)", k_cnd_sgpr, 64},
