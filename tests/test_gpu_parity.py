@@ -355,26 +355,26 @@ def test_list_scan_of_any_length(gpu_device, n):
     _scan_case(gpu_device, scene, params, f"chain of {n}")
 
 
-def test_list_scan_with_a_box_per_fork(gpu_device):
+@pytest.mark.parametrize("n", [3, 4, 5, 6, 7, 9, 200])
+def test_list_scan_with_a_box_per_fork(gpu_device, n):
     """A vine whose forks carry boxes of their own (each the bounds of the triangles still to come) takes the C++ statement of the scan, every
     fork's box tested against the running tHit; the chain builder's vine -- one box for all -- takes the hand-written one.  Same image: the boxes only cull."""
     from oracle import pt_oracle
-    scene, params = scenes.config_c3(96, 64, max_depth=3, n=200, bvh="chain")
+    w, h = (96, 64) if n > 50 else (48, 32)
+    scene, params = scenes.config_c3(w, h, max_depth=3, n=n, bvh="chain")
     ref, ref_rays = pt_oracle.render(scene, params)
     nodes = scene["bvh"].reshape(-1, 9).copy()
-    n = 200
-    lo, hi = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
     leaf_of = lambda i: 2 * i + 1 if i < n - 1 else 2 * n - 2
-    lo = np.minimum(lo, nodes[leaf_of(n - 1), 0:3]); hi = np.maximum(hi, nodes[leaf_of(n - 1), 3:6])
+    lo, hi = nodes[leaf_of(n - 1), 0:3].copy(), nodes[leaf_of(n - 1), 3:6].copy()
     for i in range(n - 2, -1, -1):  # fork i = node 2 i: bounds of leaves i .. n - 1
         lo = np.minimum(lo, nodes[leaf_of(i), 0:3]); hi = np.maximum(hi, nodes[leaf_of(i), 3:6])
         nodes[2 * i, 0:3], nodes[2 * i, 3:6] = lo, hi
-    assert not np.array_equal(nodes[0, 0:6], nodes[2 * (n - 2), 0:6])
+    assert not np.array_equal(nodes[0, 0:6], nodes[2 * (n - 2), 0:6]), "the forks' boxes differ: not the one-box list"
     sc = dict(scene, bvh=nodes.reshape(-1, 3))
     ref2, rays2 = pt_oracle.render(sc, params)
     assert_bit_equal(ref2, ref, "oracle: tighter fork boxes do not change the image")
-    _scan_case(gpu_device, sc, params, "vine with a box per fork", ref2, rays2)
-    _scan_case(gpu_device, scene, params, "vine with one box", ref, ref_rays)
+    _scan_case(gpu_device, sc, params, f"vine of {n} with a box per fork", ref2, rays2)
+    _scan_case(gpu_device, scene, params, f"vine of {n} with one box", ref, ref_rays)
 
 
 def test_list_scan_takes_the_ieee_quotient_for_huge_determinants(gpu_device):
