@@ -377,8 +377,10 @@ def test_list_scan_with_a_box_per_fork(gpu_device, n):
     _scan_case(gpu_device, scene, params, f"vine of {n} with one box", ref, ref_rays)
 
 
-def test_list_scan_takes_the_ieee_quotient_for_huge_determinants(gpu_device):
-    """1 / det is v_rcp_f32 + one Newton step where that is the IEEE quotient bit for bit (|det| <= 2^126) and the full division beyond.  Triangles
+def test_huge_determinants_flush_like_the_reference(gpu_device):
+    """Beyond |det| = 2^126 the reciprocal is a denormal: the reference's GL implementation flushes it to zero (no hit), and so must the device -- the
+    scene that showed, in round 4, that the kernels had kept denormals since round 1 (684 of 1536 pixels differed).  1 / det is v_rcp_f32 + one Newton
+    step, which in that float mode is the IEEE quotient of every normal det (test_short_quotients_equal_the_ieee_quotient_on_every_float).  Triangles
     with edges of ~1e19 and one corner in front of the camera have determinants of 4e37 .. 1.7e38 -- on both sides of 2^126 = 8.5e37, below FLT_MAX --
     and are hit next to that corner at t ~ 2 (u, v ~ 1e-19): the image is finite and lit, and it is the oracle's."""
     from oracle import pt_oracle
@@ -393,12 +395,13 @@ def test_list_scan_takes_the_ieee_quotient_for_huge_determinants(gpu_device):
     b.add_mesh(np.array(pos), np.array([[[0, 0, 1]] * 3] * 9), grey)
     b.add_mesh(np.array([[[-1.5, 1.0, -1.0], [-1.0, 1.0, -1.0], [-1.5, 1.0, -1.6]], [[-1.0, 1.0, -1.0], [-1.0, 1.0, -1.6], [-1.5, 1.0, -1.6]]]),
                np.array([[[0, -1, 0]] * 3] * 2), lamp)
-    sc = b.build("chain")
     c2w, s2c = scenes.camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0, 48, 32, 0.1, 100.0)
     params = scenes.make_params(c2w, s2c, 48, 32, 3, 2)
-    ref, ref_rays = pt_oracle.render(sc, params)
-    assert np.isfinite(ref).all() and (ref[..., :3].sum(-1) > 0).mean() > 0.1, "the giant triangles are seen and lit"
-    _scan_case(gpu_device, sc, params, "huge determinants", ref, ref_rays)
+    for kind in ("chain", "sah"):  # the list scan and the tree traversal
+        sc = b.build(kind)
+        ref, ref_rays = pt_oracle.render(sc, params)
+        assert np.isfinite(ref).all() and (ref[..., :3].sum(-1) > 0).mean() > 0.1, "the giant triangles are seen and lit"
+        _scan_case(gpu_device, sc, params, f"huge determinants, {kind} tree", ref, ref_rays)
 
 
 @pytest.mark.parametrize("n", [12, 40, 63])
