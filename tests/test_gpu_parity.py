@@ -97,6 +97,22 @@ def test_dof_and_seed_sweep_vs_oracle(gpu_device):
         assert_bit_equal(acc, ref, f"seed {p['seed']} aperture {p['aperture']}")
 
 
+def test_seeds_far_outside_the_unit_interval(gpu_device):
+    """u_seed is a pair of rand() values in [0, 1) in the reference (window.cpp:226-229), but the uniform takes any float: the hash's sin() then sees arguments
+    up to 1e22 -- beyond the float -> int conversion's range, where the reference's GL implementation returns INT_MIN --, infinities and NaNs."""
+    from oracle import pt_oracle
+    scene, params = scenes.config_c1(64, 48, max_depth=4, n_samples=2)
+    inf, nan = float("inf"), float("nan")
+    for seed in [(-0.5, 1.5), (1234.5, -77.25), (1.0e6, -3.0e5), (2.0e7, 0.5), (3.0e9, 0.5), (1.0e20, -1.0e20), (inf, 0.5), (nan, 0.5)]:
+        p = dict(params, seed=seed)
+        ref, ref_rays = pt_oracle.render(scene, p)
+        for count in (True, False):
+            acc, st = gpu_render(gpu_device, scene, p, count_rays=count)
+            if count:
+                assert st.rays == ref_rays
+            assert_bit_equal(acc, ref, f"seed {seed}, counting {count}")
+
+
 # ---------------------------------------------------------------- full-size properties (no oracle at 1080p/4K)
 def test_full_size_determinism_and_partition_invariance(gpu_device):
     """1920x1080, 8 bounces (the headline config): two runs agree bitwise, and stitching the row-stripe
