@@ -316,16 +316,31 @@ DEV void trav_stats_iter(int cur, const void *rec, bool path_ray, int sp) {
 // (run it to completion) and the wavefront traversal kernel (one step per loop trip, lanes refilled
 // with fresh rays as they finish) execute literally the same code.
 // Shadow rays (sampleDirect, :337-403) are closest-hit queries in the reference, but their result is used for one thing
-// only: "hit && |dist - tHit| < EPS" (:367).  That outcome is settled early in two ways, both exact:
-//  * no hit at or beyond `limit` = max(dist + 2 EPS, the float after dist) can be accepted (dist - t <= -EPS for all of
-//    them, also after rounding), and if the closest hit lies out there the test fails whatever it is -- so the search starts
-//    with tHit = limit instead of INFTY and reports a miss in that case (same outcome: rejected);
+// only: "hit && |dist - tHit| < EPS" (:367).  That outcome is settled early in two ways:
 //  * once any hit with dist - t >= EPS is known the test has failed: the final tHit can only be smaller, and rounding is
-//    monotonic -- so the traversal stops there.
+//    monotonic -- so the traversal stops there (exact);
+//  * no hit at or beyond dist + EPS can be accepted, and if the closest hit lies out there the test fails whatever it is -- so the
+//    search starts with tHit = `limit` instead of INFTY and reports a miss in that case (same outcome: rejected).  The limit also
+//    culls BOXES, and a fork box's computed entry distance can lie a few ulps beyond the computed t of a triangle inside it (two
+//    different roundings of nearly the same number): the limit therefore keeps a margin -- 2 EPS (rounds 1-3), and since round 4
+//    also 2^-13 of dist, ~1000 ulps: with the absolute margin alone a scene a thousand units across, where an ulp of dist exceeds
+//    EPS, lost light samples whose light lies flush in its ancestors' boxes (profiles/r04_ab_shadow_limit.txt; tests:
+//    test_scaled_scenes_match_the_oracle).  What remains outside is a triangle test so ill-conditioned that its t is off by more
+//    than a thousand ulps AND lands within EPS of dist; -DGLRTX_NO_SHADOW_LIMIT (lib/libglrtx_nolimit.so, `make diag`) drops the limit
+//    altogether -- the reference's own search, +3.6 % per frame; a margin of 2^-9 already costs 2.3 %, 2^-13 nothing.
 // A path's own rays use limit = INFTY and stop_d = -inf, which switches both off.
+#ifndef GLRTX_SHADOW_REL
+#define GLRTX_SHADOW_REL 0x1p-13f
+#endif
 DEV float shadow_limit(float dist) {
-    const float m = __builtin_fmaxf(dist + 2.0f * PT_EPS, __uint_as_float(__float_as_uint(dist) + 1u));
+#ifdef GLRTX_NO_SHADOW_LIMIT
+    (void)dist;
+    return PT_INFTY;
+#else
+    float m = __builtin_fmaxf(dist + 2.0f * PT_EPS, __uint_as_float(__float_as_uint(dist) + 1u));
+    m = __builtin_fmaxf(m, __builtin_fmaf(dist, GLRTX_SHADOW_REL, dist));
     return fmin_c(m, PT_INFTY);  // NaN distance: INFTY, i.e. the unrestricted search
+#endif
 }
 
 struct Trav {

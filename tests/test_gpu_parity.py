@@ -97,6 +97,31 @@ def test_dof_and_seed_sweep_vs_oracle(gpu_device):
         assert_bit_equal(acc, ref, f"seed {p['seed']} aperture {p['aperture']}")
 
 
+@pytest.mark.parametrize("kind", ["sah", "chain"])
+def test_scaled_scenes_match_the_oracle(gpu_device, kind):
+    """BASELINE config 1's scene scaled by powers of ten -- geometry, BVH boxes and camera alike.  Small scales drive products into the denormal range (flushed on
+    both sides), large ones make an ulp of a distance exceed EPS: at 1000x the shadow rays' range limit, whose margin was the absolute 2 EPS until round 4, culled
+    the boxes of lights lying flush in them (a box's computed entry distance a few ulps beyond the light's computed t) and one pixel of this image went dark."""
+    from oracle import pt_oracle
+    scene0, params0 = scenes.config_c1(48, 32, max_depth=4, n_samples=1, bvh=kind, subdiv=1)
+    for k in (1e-12, 1e-6, 1e-3, 1e2, 1e3, 1e4, 1e6, 1e12):
+        kf = np.float32(k)
+        vert = scene0["vert"].reshape(-1, 5, 3).copy()
+        vert[:, 0] *= kf
+        nodes = scene0["bvh"].reshape(-1, 9).copy()
+        nodes[:, 0:6] *= kf
+        sc = dict(scene0, vert=vert.reshape(-1, 3), bvh=nodes.reshape(-1, 3))
+        c2w = np.array(params0["c2w"], np.float32).reshape(4, 4).copy()
+        c2w[3, :3] *= kf
+        p = dict(params0, c2w=c2w.reshape(-1))
+        ref, ref_rays = pt_oracle.render(sc, p)
+        for count in (True, False):
+            acc, st = gpu_render(gpu_device, sc, p, count_rays=count)
+            if count:
+                assert st.rays == ref_rays
+            assert_bit_equal(acc, ref, f"{kind} tree, scale {k:g}, counting {count}")
+
+
 def test_seeds_far_outside_the_unit_interval(gpu_device):
     """u_seed is a pair of rand() values in [0, 1) in the reference (window.cpp:226-229), but the uniform takes any float: the hash's sin() then sees arguments
     up to 1e22 -- beyond the float -> int conversion's range, where the reference's GL implementation returns INT_MIN --, infinities and NaNs."""
