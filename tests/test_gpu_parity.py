@@ -122,6 +122,58 @@ def test_scaled_scenes_match_the_oracle(gpu_device, kind):
             assert_bit_equal(acc, ref, f"{kind} tree, scale {k:g}, counting {count}")
 
 
+@pytest.mark.parametrize("kind", ["sah", "chain"])
+def test_scenes_far_from_the_origin_match_the_oracle(gpu_device, kind):
+    """Config 2's scene (Cornell-style box, icospheres, ceiling emitter) moved 1e5 .. 3e6 units away from the origin, camera and all, the tree rebuilt around the
+    rounded vertices: coordinates of which an ulp is 0.008 .. 0.25 with distances of ~10."""
+    from oracle import pt_oracle
+    scene0, params0 = scenes.config_c2(48, 32, 4, 1, kind, 1)
+    for off in ((1e5, 1e5, -1e5), (3e6, 0.0, 1e6)):
+        o = np.asarray(off, np.float32)
+        vert = scene0["vert"].reshape(-1, 5, 3).copy()
+        vert[:, 0] += o
+        sc = scenes.rebuild_bvh(dict(scene0, vert=vert.reshape(-1, 3)), kind)
+        c2w = np.array(params0["c2w"], np.float32).reshape(4, 4).copy()
+        c2w[3, :3] += o
+        p = dict(params0, c2w=c2w.reshape(-1))
+        ref, ref_rays = pt_oracle.render(sc, p)
+        acc, st = gpu_render(gpu_device, sc, p)
+        assert st.rays == ref_rays
+        assert_bit_equal(acc, ref, f"{kind} tree, offset {off}")
+
+
+def test_extreme_material_parameters(gpu_device):
+    """Conductors of roughness 1e-8 .. 1e4 and eta / kappa of 0 .. 1e19, albedos of 0, 10, -1, 1e30 / 1e-40, inf and NaN, emitters of 1e30, 1e-40, negative,
+    inf and NaN: whatever the reference's arithmetic makes of them (the radiance clamp swallows the non-finite values), bit for bit."""
+    from oracle import pt_oracle
+    from glrt_amd.scenes import SceneBuilder, quad, conductor, diffuse, emitter, camera, make_params
+    W, H = 64, 48
+    inf, nan = float("inf"), float("nan")
+    grey = diffuse((0.7, 0.7, 0.7))
+    cases = [(f"conductor alpha {a:g}", [grey, grey, conductor((0.2, 0.9, 1.1), (3.9, 2.4, 2.2), a), conductor((1.5,) * 3, (0.0,) * 3, a)], (10.0,) * 3) for a in (1e-8, 1e-2, 1e4)]
+    cases += [(f"conductor eta {e:g} kappa {k:g}", [grey, conductor((e,) * 3, (k,) * 3, 0.1), conductor((e,) * 3, (k,) * 3, 0.5), grey], (10.0,) * 3)
+              for e, k in ((0.0, 0.0), (1e3, 1e-3), (1e19, 1e19), (-1.0, 2.0))]
+    cases += [(f"albedo {alb}", [diffuse(alb), grey, diffuse(alb), grey], (10.0,) * 3) for alb in ((0.0,) * 3, (10.0, 5.0, 1.0), (-1.0, 0.5, 2.0), (1e30, 1e-30, 1e-40), (inf, 0.5, 0.5), (nan, 0.5, 0.5))]
+    cases += [(f"emitter {e}", [grey] * 4, e) for e in ((1e30,) * 3, (1e-30, 1e-40, 0.0), (-5.0, 1.0, 1.0), (inf, 1.0, 1.0), (nan, 1.0, 1.0))]
+    for tag, mats, lamp_e in cases:
+        b = SceneBuilder()
+        ids = [b.add_material(m) for m in mats]
+        lamp = b.add_material(emitter(lamp_e))
+        b.add_mesh(*quad((-4, 0, 4), (8, 0, 0), (0, 0, -8)), ids[0])
+        b.add_mesh(*quad((-4, 0, -4), (8, 0, 0), (0, 6, 0)), ids[1])
+        b.add_mesh(*quad((-2.5, 0.01, 1.0), (2, 0, 0), (0, 2, -1)), ids[2])
+        b.add_mesh(*quad((0.5, 0.01, 1.0), (2, 0, 0), (0, 2, -1)), ids[3])
+        b.add_mesh(*quad((-1.5, 5.5, -1.5), (3, 0, 0), (0, 0, 3)), lamp)
+        sc = b.build("sah")
+        c2w, s2c = camera((0, 2.5, 8), (0, 1.0, 0), (0, 1, 0), 45.0, W, H)
+        p = make_params(c2w, s2c, W, H, 6, 2, seed=(0.31, 0.62))
+        ref, ref_rays = pt_oracle.render(sc, p)
+        assert np.isfinite(ref).all(), f"{tag}: the reference's clamp keeps the accumulator finite"
+        acc, st = gpu_render(gpu_device, sc, p)
+        assert st.rays == ref_rays, tag
+        assert_bit_equal(acc, ref, tag)
+
+
 def test_seeds_far_outside_the_unit_interval(gpu_device):
     """u_seed is a pair of rand() values in [0, 1) in the reference (window.cpp:226-229), but the uniform takes any float: the hash's sin() then sees arguments
     up to 1e22 -- beyond the float -> int conversion's range, where the reference's GL implementation returns INT_MIN --, infinities and NaNs."""
