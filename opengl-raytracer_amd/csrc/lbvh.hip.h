@@ -32,10 +32,13 @@ __device__ __forceinline__ unsigned expand10(unsigned v) {  // 10 bits -> every 
 __device__ __forceinline__ unsigned quantize(float c, float lo, float ext) {
     if (!(ext > 0.0f)) return 0u;
     const float q = (c - lo) / ext * 1024.0f;
-    int i = (int)q;
-    if (i < 0) i = 0;
-    if (i > 1023) i = 1023;
-    return (unsigned)i;
+    if (!(q >= 0.0f)) return 0u;  // (also a NaN: an extent that overflowed)
+    return q >= 1024.0f ? 1023u : (unsigned)(int)q;
+}
+// A box's centre as the build orders by it: 0 where it is not finite (host/bvh.cpp: centre)
+__device__ __forceinline__ float centre(float lo, float hi) {
+    const float c = 0.5f * (lo + hi);
+    return (c - c == 0.0f) ? c : 0.0f;
 }
 
 // float <-> unsigned with the same ordering, for atomicMin/atomicMax
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void k_centre_bounds(const float *vert, unsign
         Box3 b;
         if (!tri_box(vert, n_vert, tri, t, b)) *err = 1;
         else
-            for (int a = 0; a < 3; a++) lo[a] = hi[a] = f2ord(0.5f * (b.lo[a] + b.hi[a]));
+            for (int a = 0; a < 3; a++) lo[a] = hi[a] = f2ord(centre(b.lo[a], b.hi[a]));
     }
     // one atomic per workgroup and component, each component on its own 128-byte line (atomics on one line serialise
     // at ~90 per microsecond)
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void k_keys(const float *vert, unsigned n_vert
     unsigned m = 0;
     for (int a = 0; a < 3; a++) {
         const float lo = ord2f(bounds[32 * a]), hi = ord2f(bounds[32 * (3 + a)]);
-        const float c = 0.5f * (b.lo[a] + b.hi[a]);
+        const float c = centre(b.lo[a], b.hi[a]);
         m |= expand10(quantize(c, lo, hi - lo)) << (2 - a);
     }
     keys[t] = ((unsigned long long)m << 32) | t;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, in
     if (lane < m) {
         const float *L = nodes + 9 * (size_t)leaves[lane];
         for (int k = 0; k < 6; k++) box[lane][k] = L[k] + 0.0f;
-        for (int k = 0; k < 3; k++) cen[lane][k] = 0.5f * (L[k] + L[3 + k]);
+        for (int k = 0; k < 3; k++) cen[lane][k] = centre(L[k], L[3 + k]);
         ord[lane] = lane;
     }
     __syncthreads();

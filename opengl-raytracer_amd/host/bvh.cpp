@@ -19,6 +19,9 @@
 #include <cstring>
 #include <limits>
 #include <vector>
+#if defined(__SSE__)
+#include <xmmintrin.h>
+#endif
 
 #include "glrt_host.h"
 
@@ -56,6 +59,19 @@ struct Prim {
     float c[3];
     int tri;
 };
+
+// A box's centre as the builders order and bin by it: 0 where it is not finite (a vertex at infinity, or at +inf and -inf at once: NaN), so that every
+// comparison below is a total order and every float -> int conversion is in range.  The boxes themselves keep their values.  (csrc/lbvh.hip.h: the same.)
+inline float centre(float lo, float hi) {
+    const float c = 0.5f * (lo + hi);
+    return (c - c == 0.0f) ? c : 0.0f;
+}
+// Bin of a centre on an axis of the centroid box; anything that is not a number in range (an extent that overflowed: scale = 0, inf * 0) goes to bin 0.
+inline int bin_of(float c, float lo, float scale, int bins) {
+    const float f = (c - lo) * scale;
+    if (!(f >= 0.0f)) return 0;
+    return f >= (float)bins ? bins - 1 : (int)f;
+}
 
 constexpr int kBins = 16;
 // Past this depth the builder switches to median splits, which bounds the total
@@ -102,7 +118,7 @@ struct Builder {
                 for (auto &b : bb) b.reset();
                 const float scale = (float)kBins / ext;
                 for (int i = l; i < r; i++) {
-                    int k = std::min(kBins - 1, (int)((prims[i].c[a] - cb.lo[a]) * scale));
+                    const int k = bin_of(prims[i].c[a], cb.lo[a], scale, kBins);
                     cnt[k]++;
                     bb[k].grow(prims[i].box);
                 }
@@ -136,7 +152,7 @@ struct Builder {
                 const float scale = (float)kBins / (cb.hi[a] - cb.lo[a]);
                 const float lo = cb.lo[a];
                 auto it = std::partition(prims.begin() + l, prims.begin() + r, [&](const Prim &p) {
-                    return std::min(kBins - 1, (int)((p.c[a] - lo) * scale)) <= best_bin;
+                    return bin_of(p.c[a], lo, scale, kBins) <= best_bin;
                 });
                 mid = (int)(it - prims.begin());
                 if (mid == l || mid == r) mid = -1;
@@ -168,7 +184,7 @@ bool load_prims(const float *vert, size_t n_vert, const float *tri, size_t n_tri
             if (!(fi >= 0.f) || (size_t)fi >= n_vert) return false;
             p.box.grow(vert + GLRT_VERTEX_FLOATS * (size_t)fi);
         }
-        for (int a = 0; a < 3; a++) p.c[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
+        for (int a = 0; a < 3; a++) p.c[a] = centre(p.box.lo[a], p.box.hi[a]);
     }
     return true;
 }
@@ -212,10 +228,8 @@ inline uint32_t expand10(uint32_t v) {  // 10 bits -> every third bit
 inline uint32_t quantize(float c, float lo, float ext) {
     if (!(ext > 0.0f)) return 0u;
     const float q = (c - lo) / ext * 1024.0f;
-    int i = (int)q;
-    if (i < 0) i = 0;
-    if (i > 1023) i = 1023;
-    return (uint32_t)i;
+    if (!(q >= 0.0f)) return 0u;  // (also a NaN: an extent that overflowed)
+    return q >= 1024.0f ? 1023u : (uint32_t)(int)q;
 }
 
 inline int delta(const std::vector<uint64_t> &k, int n, int i, int j) {
@@ -392,7 +406,7 @@ inline void rebuild_subtrees(float *nodes, int n, int max_leaves) {
         cen.resize(3 * (size_t)m);
         for (int k = 0; k < m; k++) {
             const float *L = nodes + 9 * (size_t)leaves[(size_t)k];
-            for (int a = 0; a < 3; a++) cen[3 * (size_t)k + a] = 0.5f * (L[a] + L[3 + a]);
+            for (int a = 0; a < 3; a++) cen[3 * (size_t)k + a] = centre(L[a], L[3 + a]);
         }
         ord.resize((size_t)m);
         for (int k = 0; k < m; k++) ord[(size_t)k] = k;
@@ -476,6 +490,16 @@ int glrt_bvh_build_lbvh(const float *vert, size_t n_vert, const float *tri, size
                         int *max_depth_out) {
     if (!vert || !tri || !nodes_out || n_tri == 0) return GLRT_HOST_EINVAL;
     if (2 * n_tri - 1 > ((size_t)1 << 24)) return GLRT_HOST_EINVAL;  // node indices travel as floats
+    // This function is the CPU statement of the device build (csrc/lbvh.hip.h), which runs with fp32 denormals flushed like the rest of the device code:
+    // the same mode here, for the duration of the call.
+    struct FlushDenormals {
+#if defined(__SSE__)
+        unsigned csr = _mm_getcsr();
+        FlushDenormals() { _mm_setcsr(csr | 0x8040u); }
+        ~FlushDenormals() { _mm_setcsr(csr); }
+#endif
+    } flush_denormals;
+    (void)flush_denormals;
     std::vector<Prim> prims;
     if (!load_prims(vert, n_vert, tri, n_tri, prims)) return GLRT_HOST_EINDEX;
     const int n = (int)n_tri;

@@ -641,6 +641,36 @@ def test_gpu_lbvh_many_equal_centres_and_bad_index(gpu_device):
     assert e.value.code == device.GLRTX_ESCENE
 
 
+def _non_finite_variants(scene):
+    """The scene with a few vertex coordinates replaced: NaN, +inf, -inf, 3e38, and a mix (a triangle reaching from -inf to +inf has a NaN centre)."""
+    for tag, val in (("nan", np.nan), ("+inf", np.inf), ("-inf", -np.inf), ("3e38", 3e38), ("mixed", None)):
+        vert = scene["vert"].reshape(-1, 5, 3).copy()
+        if val is None:
+            vert[7, 0, 1], vert[8, 0, 1], vert[100, 0, 0], vert[101, 0, 0], vert[333, 0, 2] = np.inf, -np.inf, 3e38, -3e38, np.nan
+        else:
+            vert[7, 0, 1] = vert[100, 0, 0] = vert[333, 0, 2] = val
+        yield tag, dict(scene, vert=vert.reshape(-1, 3))
+
+
+def test_non_finite_vertices(gpu_device):
+    """Vertices at infinity, at 3e38, NaN: the host builders take them (a box's centre that is not finite is ordered and binned as 0; until round 4 the SAH
+    builder indexed its bins with (int)NaN and crashed), the device builds the same linear BVH as the CPU statement bit for bit, and the image is the oracle's
+    under every tree."""
+    from oracle import pt_oracle
+    scene0, params = scenes.config_c1(64, 48, max_depth=4, n_samples=1, bvh="sah", subdiv=1)
+    for tag, sc0 in _non_finite_variants(scene0):
+        nodes, depth, _ = gpu_device.build_lbvh(sc0["vert"], sc0["tri"])
+        want, want_depth = host.build_bvh(sc0["vert"], sc0["tri"], "lbvh")
+        assert depth == want_depth
+        assert_bit_equal(nodes.view(np.uint32), np.asarray(want, np.float32).reshape(-1, 3).view(np.uint32), f"{tag}: LBVH nodes, device against CPU statement")
+        for kind in ("sah", "chain", "lbvh"):
+            sc = scenes.rebuild_bvh(sc0, kind)
+            ref, ref_rays = pt_oracle.render(sc, params)
+            acc, st = gpu_render(gpu_device, sc, params)
+            assert st.rays == ref_rays, (tag, kind)
+            assert_bit_equal(acc, ref, f"{tag} vertices, {kind} tree")
+
+
 def test_render_with_gpu_built_lbvh_matches_oracle(gpu_device):
     """BASELINE config 5 (100k triangles, linear BVH) at reduced resolution: tree from the GPU builder, image vs the oracle
     with the same tree -- and vs the oracle with the SAH tree (random triangles: no exact ties)."""

@@ -379,3 +379,24 @@ def test_row_partition_is_a_bijection(world, stripe, height):
         ys = dist.owned_rows(r, world, stripe, height)
         for i, y in enumerate(ys):  # same formula as the kernel / glrtx_local_row_to_y
             assert y == ((i // stripe) * world + r) * stripe + i % stripe
+
+
+@pytest.mark.parametrize("kind", ["sah", "chain", "lbvh"])
+def test_builders_take_non_finite_vertices(kind):
+    """Vertices at +-inf, at 3e38 (extents that overflow) and NaN: every builder returns a tree over all triangles that the device layer accepts.  A box's
+    centre that is not finite is ordered and binned as 0 (host/bvh.cpp: centre, bin_of); until round 4 the SAH builder indexed its bins with (int)NaN."""
+    sc0, _ = scenes.config_c1(16, 16, bvh="sah", subdiv=1)
+    for val in (np.nan, np.inf, -np.inf, 3e38, None):
+        vert = sc0["vert"].reshape(-1, 5, 3).copy()
+        if val is None:
+            vert[7, 0, 1], vert[8, 0, 1], vert[100, 0, 0], vert[101, 0, 0], vert[333, 0, 2] = np.inf, -np.inf, 3e38, -3e38, np.nan
+        else:
+            vert[7, 0, 1] = vert[100, 0, 0] = vert[333, 0, 2] = val
+        sc = scenes.rebuild_bvh(dict(sc0, vert=vert.reshape(-1, 3)), kind)
+        nodes = _nodes(sc)
+        n_tri = sc["tri"].shape[0]
+        assert nodes.shape[0] == 2 * n_tri - 1
+        leaves = nodes[nodes[:, 8] >= 0]
+        assert sorted(leaves[:, 8].astype(int).tolist()) == list(range(n_tri)), "every triangle once"
+        rc, _, _, msg = _check(sc)
+        assert rc == device.GLRTX_OK, msg
