@@ -129,3 +129,37 @@ def test_mutated_wire_scenes(gpu_device):
         assert same.all(), f"mutation {it} of {key}: {int((~same).any(-1).sum())} pixels differ"
         assert d.stats().rays == ref_rays, f"mutation {it} of {key}"
     assert accepted > 50 and refused > 20, (accepted, refused)
+
+
+def test_hostile_render_parameters(gpu_device):
+    """Camera matrices with NaN / inf / zero / random entries, aperture and focal length NaN, inf, negative, zero, denormal, zero samples, zero depth, seeds at
+    infinity: whatever the reference's arithmetic makes of them, bit for bit (NaNs as NaNs).  (tools/gpu_param_fuzz.py: 1500 sets in round 4, 0 mismatches.)"""
+    from oracle import pt_oracle
+    rng = np.random.default_rng(5)
+    specials = [np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-30, 1e30, -1.0, 1e-45, 3e38]
+    sc, pr0 = scenes.config_c1(40, 28, max_depth=3, n_samples=2, subdiv=1)
+    d = gpu_device
+    d.upload_scene(sc); d.set_partition(0, 1, 16); d.resize(40, 28)
+    for it in range(100):
+        p = dict(pr0)
+        c2w, s2c = np.array(p["c2w"], np.float32).copy(), np.array(p["s2c"], np.float32).copy()
+        for _ in range(int(rng.integers(0, 3))):
+            m = c2w if rng.integers(0, 2) else s2c
+            m[int(rng.integers(0, 16))] = specials[int(rng.integers(0, len(specials)))] if rng.integers(0, 2) else float(rng.normal()) * 10
+        p["c2w"], p["s2c"] = c2w, s2c
+        if rng.integers(0, 3) == 0:
+            p["aperture"] = float(specials[int(rng.integers(0, len(specials)))])
+        if rng.integers(0, 3) == 0:
+            p["focal"] = float(specials[int(rng.integers(0, len(specials)))])
+        if rng.integers(0, 5) == 0:
+            p["n_samples"] = int(rng.integers(0, 4))
+        if rng.integers(0, 5) == 0:
+            p["max_depth"] = int(rng.integers(0, 4))
+        if rng.integers(0, 4) == 0:
+            p["seed"] = (float(specials[int(rng.integers(0, len(specials)))]), float(rng.uniform()))
+        d.clear(); d.count_rays(True); d.reset_stats(); d.render(p); d.sync()
+        ref, ref_rays = pt_oracle.render(sc, p)
+        acc = d.read_accum()
+        same = (acc.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(acc) & np.isnan(ref))
+        assert same.all(), f"parameter set {it}: {int((~same).any(-1).sum())} pixels differ ({p})"
+        assert d.stats().rays == ref_rays, f"parameter set {it}"
