@@ -890,7 +890,10 @@ void pt_oracle_sincos(const float *x, int n, float *s, float *c) {
  *   - float -> unorm8: min(v, 1) * 255, cvtps2dq (round to nearest even), saturating packs; alpha = 255.
  * The reference samples the accumulators through GL_LINEAR samplers at gl_FragCoord / u_windowSize: exactly the texel at
  * power-of-two sizes; at other sizes a neighbour leaks in at the 1e-7 level, which this restatement and
- * the device kernel do not reproduce (fixture screen_npot_* records how many bytes that moves). */
+ * the device kernel do not reproduce (fixture screen_npot_* records how many bytes that moves).  The filter also adds the
+ * neighbours with weight 0: a NaN or infinite texel poisons the pixels around it (0 * inf), and a count of -0 comes out as +0
+ * (v / +0 = +inf where the exact read gives -inf): non-finite texels and negative-zero counts are outside this restatement's
+ * domain -- the renderer produces neither (radiance is clamped to 100, counts count up from +0). */
 INL float rs_log2(float x) {
     uint32_t i; memcpy(&i, &x, 4);
     const float ef = (float)((int)((i & 0x7f800000u) >> 23) - 127);
@@ -935,6 +938,10 @@ INL unsigned char rs_channel(float v, float count, float inv_gamma) {
 __attribute__((target_clones("default", "fma")))
 void pt_oracle_resolve(const float *accum, size_t pitch_bytes, int width, int height, float gamma, int flip_y, unsigned char *out,
                        size_t out_pitch_bytes) {
+    /* llvmpipe runs this pass, like every fragment shader, with denormals flushed (MXCSR FTZ | DAZ): a quotient v / count or an exponent 1 / u_gamma below
+     * FLT_MIN is 0 there (found in round 4 with counts of 3e38 and gammas of 3e38: pow(x, 0) = 1 against a denormal power; no committed fixture is affected) */
+    const unsigned csr = _mm_getcsr();
+    _mm_setcsr(csr | 0x8040u);
     const float inv_gamma = 1.0f / gamma;
     for (int y = 0; y < height; y++) {
         const float *row = (const float *)((const char *)accum + (size_t)y * pitch_bytes);
@@ -946,6 +953,7 @@ void pt_oracle_resolve(const float *accum, size_t pitch_bytes, int width, int he
             o[4 * x + 3] = 255;
         }
     }
+    _mm_setcsr(csr);
 }
 
 #ifdef PT_ORDERED_EXPERIMENT

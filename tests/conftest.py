@@ -46,6 +46,10 @@ def screen_cases():
         acc = np.concatenate([z["rgb"], z["count"][..., None]], -1).astype(np.float32)
         for gm, o in zip(z["gammas"], z["out"]):
             out.append((f"{name[7:]}_gamma{float(gm):.1f}", acc, float(gm), o))
+    z = np.load(GOLDEN / "screen_extreme.npz")  # round 4 (make_golden_screen_r04.py): finite but hostile texels, gammas 2.2 .. 1e-45 / 3e38: denormals are flushed
+    acc = np.concatenate([z["rgb"], z["count"][..., None]], -1).astype(np.float32)
+    for i, (gm, o) in enumerate(zip(z["gammas"], z["out"])):
+        out.append((f"extreme_{i}_gamma{float(gm):g}", acc, float(gm), o))
     return out
 
 

@@ -163,3 +163,37 @@ def test_hostile_render_parameters(gpu_device):
         same = (acc.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(acc) & np.isnan(ref))
         assert same.all(), f"parameter set {it}: {int((~same).any(-1).sum())} pixels differ ({p})"
         assert d.stats().rays == ref_rays, f"parameter set {it}"
+
+
+def test_resolve_on_hostile_accumulators(gpu_device):
+    """The resolve kernel against the oracle's restatement of screen.frag on finite but hostile accumulators (denormals, negatives, 1e-30 .. 3e38, counts of 0, 3e38
+    and fractions) with gammas from 1e-45 to 3e38 and inf: both flush denormals, as llvmpipe does (pinned by tests/golden/screen_extreme.npz).  NaN / infinite
+    texels and negative zeros are outside the pass's domain (tools/gpu_resolve_fuzz.py: 600 buffers in round 4, 0 mismatches)."""
+    import torch
+    from oracle import pt_oracle
+    rng = np.random.default_rng(21)
+    specials = np.array([0.0, 1e-45, 1e-40, 1.1754944e-38, 1e-30, 1e-6, 0.5, 1.0, 1.0000001, 2.0, 100.0, 1e30, 3e38, -1.0, -1e-30], np.float32)
+    d = gpu_device
+    W = H = 64
+    d.resize(W, H)
+    try:
+        for it in range(80):
+            acc = rng.uniform(0, 4, (H, W, 4)).astype(np.float32)
+            acc[..., 3] = rng.integers(0, 5, (H, W)).astype(np.float32)
+            m = rng.uniform(0, 1, acc.shape) < 0.15
+            acc[m] = specials[rng.integers(0, specials.size, int(m.sum()))]
+            e = rng.uniform(0, 1, acc.shape) < 0.2
+            with np.errstate(all="ignore"):
+                acc[e] = (acc[e] * np.float32(2.0) ** rng.integers(-140, 120, int(e.sum())).astype(np.float32)).astype(np.float32)
+            acc[~np.isfinite(acc)] = 1.0
+            acc[(acc == 0) & np.signbit(acc)] = 0.0
+            acc[(np.abs(acc) < 1.1754944e-38) & (acc < 0)] = 0.0
+            gamma = float(rng.choice([2.2, 1.0, 0.45, 1e-20, 1e20, np.inf, 3.0, 1e-45, 3e38, float(rng.uniform(0.1, 5))]))
+            t = torch.from_numpy(np.ascontiguousarray(acc)).cuda()
+            d.bind_accum(t.data_ptr(), W * 16, H)
+            got = d.resolve_rgba8(gamma=gamma, flip_y=False)
+            with np.errstate(all="ignore"):
+                want = pt_oracle.resolve(acc, gamma, flip_y=False)
+            assert np.array_equal(got, want), f"buffer {it}, gamma {gamma}: {int((got != want).sum())} bytes differ"
+    finally:
+        d.bind_accum(0, 0, 0)
