@@ -92,3 +92,19 @@ def test_resolve_restatement_vs_live_screen_shader_on_hostile_accumulators(gl):
         ref = gl.render_screen(a[..., :3].copy(), a[..., 3].copy(), gamma)
         got = pt_oracle.resolve(a, gamma)
         assert np.array_equal(got, ref), f"arrangement {it}, gamma {gamma}: {int((got != ref).sum())} bytes differ"
+
+
+def test_oracle_bit_exact_vs_live_reference_on_hostile_inputs(gl):
+    """The inputs that round 4's device fuzzes throw at the kernels -- determinants beyond 2^126 (the reciprocal is a denormal: llvmpipe flushes it, no hit), scenes
+    scaled by 1e-12 .. 1e12, seeds up to 1e20 / inf / NaN, conductors and albedos and emitters of 0 .. 1e30 / inf / NaN, vertices at infinity and NaN -- through the
+    LIVE reference: the oracle is the reference there too, so the device-against-oracle tests of the same inputs (tests/test_gpu_parity.py) mean what they say."""
+    from hostile_cases import cases
+    n = 0
+    for tag, sc, p in cases():
+        rgb, cnt = gl.render_reference(sc, p)
+        acc, _ = pt_oracle.render(sc, p)
+        a = np.concatenate([rgb, cnt[..., None]], -1)
+        same = (a.view(np.uint32) == acc.view(np.uint32)) | (np.isnan(a) & np.isnan(acc))
+        assert same.all(), f"{tag}: {int((~same).any(-1).sum())} pixels differ"
+        n += 1
+    assert n >= 50
