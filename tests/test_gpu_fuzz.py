@@ -197,3 +197,48 @@ def test_resolve_on_hostile_accumulators(gpu_device):
             assert np.array_equal(got, want), f"buffer {it}, gamma {gamma}: {int((got != want).sum())} bytes differ"
     finally:
         d.bind_accum(0, 0, 0)
+
+
+def test_odd_image_sizes_and_partitions(gpu_device):
+    """Images from 1 x 1 to 4097 x 2 (and transposes): one launch per frame, frames in flight, and row-stripe partitions of 2 .. 5 ranks with stripes of 8 .. 40
+    rows, stitched -- three accumulated frames against the oracle, ray counts included."""
+    from glrt_amd import dist
+    from oracle import pt_oracle
+    d = gpu_device
+    sc, _ = scenes.config_c1(8, 8, max_depth=3, n_samples=1, subdiv=1)
+    d.upload_scene(sc)
+    rng = np.random.default_rng(3)
+    try:
+        for (w, h) in [(1, 1), (1, 2), (2, 1), (3, 3), (7, 5), (9, 9), (63, 1), (65, 3), (127, 17), (1, 129), (1000, 3), (3, 1000), (4097, 2), (2, 4097), (257, 255)]:
+            c2w, s2c = scenes.camera((0, 5, 16), (0, 2.0, 0), (0, 1, 0), 40.0, w, h)
+            p = scenes.make_params(c2w, s2c, w, h, 3, 1, seed=(0.2, 0.7))
+            seeds = [host.frame_seed(f) for f in range(3)]
+            ref, rays = None, 0
+            for sd in seeds:
+                ref, n = pt_oracle.render(sc, dict(p, seed=sd), accum=ref)
+                rays += n
+            for mode in ("one launch per frame", "frames in flight"):
+                d.set_partition(0, 1, 16); d.resize(w, h); d.clear(); d.count_rays(True); d.reset_stats()
+                if mode == "frames in flight":
+                    d.render_frames(p, seeds)
+                else:
+                    for sd in seeds:
+                        d.render(dict(p, seed=sd))
+                d.sync()
+                assert_bit_equal(d.read_accum(), ref, f"{w}x{h}, {mode}")
+                assert d.stats().rays == rays, f"{w}x{h}, {mode}"
+            world, stripe = int(rng.integers(2, 6)), int(rng.choice([8, 16, 24, 40]))
+            stitched, total = np.zeros_like(ref), 0
+            for rank in range(world):
+                d.set_partition(rank, world, stripe); d.resize(w, h); d.clear(); d.count_rays(True); d.reset_stats()
+                d.render_frames(p, seeds); d.sync()
+                ys = dist.owned_rows(rank, world, stripe, h)
+                a = d.read_accum()
+                assert a.shape[0] == len(ys)
+                if len(ys):
+                    stitched[ys] = a
+                total += d.stats().rays
+            assert_bit_equal(stitched, ref, f"{w}x{h}, {world} ranks, {stripe}-row stripes")
+            assert total == rays
+    finally:
+        d.set_partition(0, 1, 16)
