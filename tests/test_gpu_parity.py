@@ -1025,3 +1025,59 @@ def test_short_quotients_equal_the_ieee_quotient_on_every_float():
     assert int(m.group(3)) == (1 << 24) + 2, "... and of nothing else but NaNs: 2^24 zeros and denormals, two infinities (its callers reject |det| < EPS first)"
     assert re.search(r"^frcp: 0 mismatches$", r.stdout, re.M), r.stdout
     assert re.search(r"^div_pi: 0 mismatches$", r.stdout, re.M), r.stdout
+
+
+def test_contexts_driven_from_concurrent_host_threads(gpu_device):
+    """include/glrtx.h: one host thread drives a context -- and several contexts, each with its thread, share the device: three threads upload different scenes
+    (tree, list scan, extension spheres) into contexts of their own and render frames at the same time; every image is the oracle's."""
+    import threading
+    from oracle import pt_oracle
+    jobs = [("c1", scenes.config_c1(96, 64, max_depth=4, n_samples=1, subdiv=1), None),
+            ("c3 chain", scenes.config_c3(64, 48, max_depth=2, n=300, bvh="chain"), None),
+            ("spheres", scenes.config_spheres(64, 48, max_depth=4, n_samples=1)[:2], scenes.config_spheres(64, 48, max_depth=4, n_samples=1)[2])]
+    seeds = [host.frame_seed(f) for f in range(6)]
+    refs = []
+    for name, (sc, pr), sph in jobs:
+        ref = None
+        for sd in seeds:
+            ref, _ = pt_oracle.render(sc, dict(pr, seed=sd), accum=ref, spheres=sph)
+        refs.append(ref)
+    results, errors = [None] * len(jobs), []
+    start = threading.Barrier(len(jobs))
+
+    def work(i):
+        try:
+            name, (sc, pr), sph = jobs[i]
+            d = device.Device()
+            try:
+                d.upload_scene(sc)
+                if sph is not None:
+                    d.upload_spheres(sph)
+                d.resize(pr["width"], pr["height"])
+                start.wait(timeout=60)
+                for rep in range(3):  # the same six frames three times over: launches of the three contexts interleave on the device
+                    d.clear()
+                    for k, sd in enumerate(seeds):
+                        if k % 2:
+                            d.render(dict(pr, seed=sd))
+                        else:
+                            d.render_frames(pr, [sd])
+                    d.sync()
+                    acc = d.read_accum()
+                    if results[i] is None:
+                        results[i] = acc
+                    elif not np.array_equal(results[i].view(np.uint32), acc.view(np.uint32)):
+                        errors.append(f"{name}: repetition {rep} differs from the first")
+            finally:
+                d.close() if hasattr(d, "close") else None
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"{jobs[i][0]}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for (name, _, _), got, ref in zip(jobs, results, refs):
+        assert_bit_equal(got, ref, f"{name}, rendered next to two other contexts")
