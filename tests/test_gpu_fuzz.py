@@ -50,7 +50,7 @@ def test_fuzz_scene_matches_oracle(gpu_device, monkeypatch, case, pair_fetch):
 import os
 
 
-@pytest.mark.parametrize("seed", range(1000, 1000 + int(os.environ.get("GLRT_FUZZ_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GLRT_FUZZ_FIRST", "1000")), int(os.environ.get("GLRT_FUZZ_FIRST", "1000")) + int(os.environ.get("GLRT_FUZZ_SEEDS", "24"))))
 def test_fuzz_random_parameters(gpu_device, monkeypatch, seed):
     """Parameters drawn from the seed: triangle count, tree builder, image size, depth, samples, lens, flags -- and the form of the node fetch."""
     from oracle import pt_oracle
