@@ -683,6 +683,7 @@ def main(argv=None):
                        "gather_check_what": None if world == 1 else f"frames [{args.warmup * world}, {(args.warmup + min(args.steps, 4)) * world}) re-rendered untimed by all ranks, gathered to "
                                                                       "rank 0 over the timed region's collective path, compared bit for bit with a one-rank render of the same frames on rank 0's GPU",
                        "timed_kernel_image_check": f"bit-identical to the counting kernel's accumulator over the {args.steps} timed steps (untimed replay)",
+                       "run_to_run": "one context = one draw: contexts of one binary differ by up to 3 % with where the 4 GB path-state buffer lands physically (profiles/r04_context_regimes.txt)",
                        # strong scaling: the same K frames whatever N is, S frames in flight IN TOTAL per launch, framebuffer gathered after every launch
                        "strong": ({"error": strong_err} if strong_err else None) if strong_s is None else
                            {"frames": args.steps, "frames_in_flight_total": S, "gather": "none" if args.no_gather else "to rank 0 after every launch, overlapped with the next launch",
