@@ -104,6 +104,35 @@ def test_bench_self_spawns_its_ranks_and_gathers_to_root(tmp_path):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_bench_at_eight_ranks_under_gloo(tmp_path):
+    """The driver's largest run shape -- `bench.py --gpus 8` -- rehearsed on CPU: eight ranks under gloo with the oracle-backed renderer, 72 rows in 8-row stripes
+    (rank 0 owns two stripes, the others one: ragged blocks, padded for the collective).  The line must carry both self-checks of the collective as bit-identical,
+    and the image gathered to rank 0 must equal a single-process render of the frames behind the last clear."""
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GLRT_REHEARSAL_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+    steps, warm, spl, world = 3, 1, 2, 8
+    r = subprocess.run([sys.executable, str(root / "tests" / "bench_rehearsal.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", str(warm),
+                        "--steps-per-launch", str(spl), "--config", "rehearsal", "--backend", "gloo", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["steps"] == steps and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["frames_per_step"] == world and out["config"]["launches"] == [2, 1]
+    assert out["config"]["gather_check"] == "bit-identical", out["config"]["gather_check"]
+    assert out["config"]["strong"]["gather_check"] == "bit-identical" and out["config"]["strong"]["frames"] == steps
+    from glrt_amd import host
+    from tests.bench_rehearsal import small_config
+    sc, pr = small_config()
+    ref = np.zeros((pr["height"], pr["width"], 4), np.float32)
+    for f in range(warm * world, (warm + min(steps, 4)) * world):  # the self-check's frames through the strong region's gather, accumulated from zero
+        pt_oracle.render(sc, dict(pr, seed=host.frame_seed(f)), accum=ref, threads=2)
+    got = np.load(tmp_path / "gathered.npy")
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def test_bench_gather_check_reports_a_corrupted_gather(tmp_path):
     """The same rehearsal with a gather that delivers one wrong value on the weak region's path: the contract line is still printed and
     config.gather_check names the damage; the strong region's (asynchronous) path is untouched and stays bit-identical."""
