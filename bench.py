@@ -234,6 +234,51 @@ class GpuRenderer:
             self.dev.set_partition(0, 1, STRIPE)
         return sorted(ms[1:])[len(ms[1:]) // 2]
 
+    def predict_strong(self, world, frames_in_flight, seed_of, launches=3):
+        """ms per FRAME of rank 0's share of a `world`-rank strong-scaling launch, on this one GPU (no gather): stripes s % world == 0 of `frames_in_flight`
+        frames per launch -- 1 / world of the paths a one-GPU launch holds.  Leaves the partition as it was."""
+        ms = []
+        try:
+            self.dev.set_partition(0, world, STRIPE)
+            for it in range(launches):
+                self.dev.reset_stats()
+                self.dev.render_frames(self.params, [seed_of(it * frames_in_flight + f) for f in range(frames_in_flight)])
+                self.dev.sync()
+                st = self.dev.stats()
+                ms.append((st.kernel_ms_total + st.accumulate_ms_total) / frames_in_flight)
+        finally:
+            self.dev.set_partition(0, 1, STRIPE)
+        return sorted(ms[1:])[len(ms[1:]) // 2]
+
+    def time_one_rank(self, f0, n, seed_of, per_launch):
+        """Seconds this GPU ALONE takes for frames [f0, f0 + n) as a one-rank partition, `per_launch` frames in flight -- the N = 1 run of the strong-scaling
+        workload, measured inside an N-rank run (the other ranks wait) so that the line carries its own denominator.  HIP events on the render stream around the
+        launches, behind an untimed launch of the same shape (buffers sized, device warm).  Leaves partition and accumulator binding as they were."""
+        torch = self.torch
+        W, H = self.params["width"], self.params["height"]
+        rank, world = self._part
+        full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        self.dev.sync()
+        self.dev.bind_accum(0, 0, 0)
+        try:
+            self.dev.set_partition(0, 1, STRIPE)
+            self.dev.bind_accum(full.data_ptr(), W * 16, H)
+            plan = [self.prepare_frames(f0 + a, k, seed_of) for a, k in launch_plan(n, per_launch)]
+            warm = self.prepare_frames(f0, min(n, per_launch), seed_of)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.render_prepared(warm)
+            e0.record(self.stream)
+            for prep in plan:
+                self.render_prepared(prep)
+            e1.record(self.stream)
+            self.dev.sync()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3
+        finally:
+            self.dev.bind_accum(0, 0, 0)
+            self.dev.set_partition(rank, world, STRIPE)
+            self.dev.bind_accum(self.accum.data_ptr(), W * 16, self.accum.shape[0])
+
     def render_full_reference(self, f0, n, seed_of, per_launch=16):
         """Frames [f0, f0 + n) rendered by THIS GPU alone as a one-rank partition into a fresh full-size accumulator (untimed; what the gathered image of
         an N-rank run of the same frames must equal bit for bit).  Leaves partition and accumulator binding as they were."""
@@ -276,6 +321,8 @@ def main(argv=None):
     ap.add_argument("--bvh", default="default", help="default (the config's CPU SAH tree) | lbvh (linear BVH built on the GPU, glrtx_build_lbvh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline sample")
+    ap.add_argument("--no-llvmpipe", action="store_true", help="skip the llvmpipe leg of cpu_baseline (the repository's own GLSL port through oracle/glref)")
+    ap.add_argument("--llvmpipe-frames", type=int, default=3, help="timed llvmpipe frames (a 1080p headline frame takes seconds there)")
     ap.add_argument("--no-gather", action="store_true", help="skip the framebuffer gather (N > 1)")
     ap.add_argument("--gather-every", type=int, default=0, help="gather the framebuffer to rank 0 after every L-th launch (0: once, at the end of the timed region)")
     ap.add_argument("--no-single", action="store_true", help="skip the extra one-launch-per-frame measurement (profiling runs)")
@@ -316,6 +363,8 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": R.device} if args.backend == "nccl" else {}
         td.init_process_group(args.backend, rank=rank, world_size=world, **kw)
+    ranks_seen = td.get_world_size() if world > 1 else 1       # what the process group itself reports after init ("nccl" IS RCCL on ROCm)
+    backend_seen = td.get_backend() if world > 1 else None
     ys = dist.owned_rows(rank, world, STRIPE, H)
     gatherer = dist.RowGather(world, STRIPE, H, R.accum) if world > 1 else None  # index tensors built once, here
 
@@ -331,6 +380,25 @@ def main(argv=None):
             return [(a, k, None) for a, k in plan]
         return [(a, k, R.prepare_frames((s0 + a) * world, k * world, seed)) for a, k in plan]
 
+    gather_sink = None  # a list while the timed region runs: (event, event) or seconds per collective of THIS rank
+
+    def gather_now(local):
+        """The framebuffer gather, timed when the timed region asks for it: HIP events on the render stream around the collective and its de-interleave (what
+        lies between them is the collective alone: the first event fires when the render work in front of it has finished)."""
+        if gather_sink is None:
+            return gatherer.gather_to_root(local)
+        if local.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            img = gatherer.gather_to_root(local)
+            e1.record()
+            gather_sink.append((e0, e1))
+        else:
+            t = time.perf_counter()
+            img = gatherer.gather_to_root(local)
+            gather_sink.append(time.perf_counter() - t)
+        return img
+
     def run(s0, n_steps, per_launch=None, gather=True, prepared=None):
         """Steps [s0, s0 + n_steps) = frames [s0*N, (s0+n_steps)*N), in balanced launches; returns the gathered image (rank 0) or None."""
         img = None
@@ -342,7 +410,7 @@ def main(argv=None):
                 R.render_frames((s0 + a) * world, k * world, seed)
             last = i + 1 == len(plan)
             if gatherer is not None and gather and not args.no_gather and (last or (args.gather_every > 0 and (i + 1) % args.gather_every == 0)):
-                img = gatherer.gather_to_root(R.accum)
+                img = gather_now(R.accum)
         return img
 
     def clear_accum():
@@ -397,6 +465,7 @@ def main(argv=None):
     rays_local = int(st0.rays)
     untraced_local = int(st0.rays_untraced)
     barrier()
+    gather_sink = []
     t0 = time.perf_counter()
     R.timer_begin()
     img = run(args.warmup, args.steps, prepared=timed_launches)
@@ -404,6 +473,9 @@ def main(argv=None):
     ev_ms = R.timer_end()
     barrier()
     t1 = time.perf_counter()
+    gather_ms_local = sum((g[0].elapsed_time(g[1]) if isinstance(g, tuple) else g * 1e3) for g in gather_sink)
+    n_gathers = len(gather_sink)
+    gather_sink = None
     R.sync()
     st1 = R.stats()
     # what the timed region added to the context's running totals
@@ -462,6 +534,17 @@ def main(argv=None):
             strong_err = f"{type(e).__name__}: {e}"
             strong_s = None
 
+    # ---- the strong-scaling DENOMINATOR, measured in this same run (N > 1): rank 0's GPU alone renders the same K frames as a one-rank partition with S frames in
+    # flight per launch -- exactly what `bench.py --gpus 1 --steps K` times -- while the other ranks wait at the barrier behind it.
+    n1_s, n1_err = None, None
+    if world > 1 and hasattr(R, "time_one_rank"):
+        try:
+            if rank == 0:
+                n1_s = R.time_one_rank(args.warmup * world, args.steps, seed, S)
+            barrier()
+        except Exception as e:
+            n1_err = f"{type(e).__name__}: {e}"
+
     # ---- self-check of what the collective delivered (N > 1, untimed): min(K, 4) of the timed steps are rendered again by all ranks into cleared
     # accumulators and gathered over the same collective path -- once as the weak region issues them, once as the strong region does -- and rank 0
     # compares each gathered image, bit for bit, with the same frames rendered by its own GPU alone as a one-rank partition.  (The timed regions drop
@@ -503,6 +586,8 @@ def main(argv=None):
             for w in (2, 4, 8):
                 ms = R.predict_weak(w, S, seed)
                 predicted[str(w)] = {"ms_per_step": round(ms, 4)}
+                if hasattr(R, "predict_strong"):
+                    predicted[str(w)]["strong_ms_per_frame"] = round(R.predict_strong(w, S, seed), 4)
         resolve_ms = R.resolve_ms() if (world == 1 and hasattr(R, "resolve_ms")) else None
     except Exception as e:  # extras only
         predicted = {"error": f"{type(e).__name__}: {e}"}
@@ -511,10 +596,19 @@ def main(argv=None):
     elapsed = torch.tensor([t1 - t0, strong_s if strong_s is not None else -1.0], dtype=torch.float64, device=dev0)
     rays = torch.tensor([rays_local, untraced_local], dtype=torch.int64, device=dev0)
     kern_ms = torch.tensor([st.kernel_ms_total / max(st.kernel_launches, 1)], dtype=torch.float64, device=dev0)
+    # per rank: [render-kernel ms summed over the timed launches, event-timed ms of its collectives in the timed region]
+    per_rank = torch.zeros((world, 2), dtype=torch.float64, device=dev0)
+    per_rank[rank, 0] = st.kernel_ms_total
+    per_rank[rank, 1] = gather_ms_local
+    n1 = torch.tensor([n1_s if n1_s is not None else -1.0], dtype=torch.float64, device=dev0)
     if world > 1:
         td.all_reduce(elapsed, op=td.ReduceOp.MAX)
         td.all_reduce(rays, op=td.ReduceOp.SUM)
         td.all_reduce(kern_ms, op=td.ReduceOp.MAX)
+        td.all_reduce(per_rank, op=td.ReduceOp.SUM)
+        td.all_reduce(n1, op=td.ReduceOp.MAX)
+    per_rank = per_rank.cpu().tolist()
+    n1_s = float(n1.item()) if float(n1.item()) > 0 else None
     elapsed_s, ref_rays, total_untraced, kernel_ms = float(elapsed[0].item()), int(rays[0].item()), int(rays[1].item()), float(kern_ms.item())
     strong_s = float(elapsed[1].item()) if float(elapsed[1].item()) > 0 and strong_err is None else None  # (MAX over ranks: -1 everywhere = not measured)
     traced_rays = ref_rays - total_untraced
@@ -625,15 +719,17 @@ def main(argv=None):
                                      "what": f"{W}x{len(ys)}: rgb / count, clamp, pow(1 / 2.2), RGBA8; at this size the launch itself (~10 us) is a third of the time "
                                              "-- profiles/r03_aux_kernels.json has 4K"}
 
-    cpu_baseline = None
+    cpu_baseline, oracle_check = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and RENDERER_FACTORY is None:
         from oracle import pt_oracle
         cores = effective_cpus(pt_oracle.max_threads())
-        acc = np.zeros((H, W, 4), np.float32)
+        scratch = np.zeros((H, W, 4), np.float32)
         t = time.perf_counter()
-        _, r = pt_oracle.render(scene, dict(params, seed=seed(args.warmup)), accum=acc, threads=cores)
+        pt_oracle.render(scene, dict(params, seed=seed(args.warmup)), accum=scratch, threads=cores)  # sizes the sample (and warms the cores); its image is not kept
         one = time.perf_counter() - t
+        del scratch
         n = int(min(max(args.cpu_seconds / max(one, 1e-3), 1), 64))
+        acc = np.zeros((H, W, 4), np.float32)  # the accumulation loop over the FIRST n TIMED frames, from cleared accumulators
         cpu_rays, t = 0, time.perf_counter()
         for i in range(n):
             _, r = pt_oracle.render(scene, dict(params, seed=seed(args.warmup + i)), accum=acc, threads=cores)
@@ -643,7 +739,56 @@ def main(argv=None):
                         "sample": f"{n} full frames of the same workload (same seeds as the first timed frames), "
                                   f"{dt:.1f} s, OpenMP over rows; counts every intersect() execution of the reference's algorithm",
                         "ms_per_frame": round(dt / n * 1e3, 2)}
+        # the oracle as the CHECKER of what was timed: the same n frames by the GPU (untimed, the timed kernel, frames in flight) into a cleared accumulator,
+        # compared bit for bit with the image the oracle just accumulated.  A difference aborts the run like the counting-kernel check does.
+        gpu_img = R.render_full_reference(args.warmup, n, seed, per_launch=S).cpu().numpy()
+        diff = int((gpu_img.view(np.uint32) != acc.view(np.uint32)).any(-1).sum())
+        if diff:
+            raise SystemExit(f"bench.py: the GPU's accumulator differs from the oracle's on {diff} of {W * H} pixels over timed frames "
+                             f"[{args.warmup}, {args.warmup + n}): refusing to report a time for it")
+        oracle_check = f"bit-identical over {n} frames"
+        del gpu_img, acc
+        # the llvmpipe leg (BASELINE.json: "next to the reference timed through Mesa llvmpipe on the box's own host cores in the same run"): the reference's shader
+        # file does not travel, so this is the repository's own GLSL statement of it (oracle/glsl/pt_port.frag; bit-identical to the reference's images on llvmpipe in
+        # the build container, tests/test_glsl_port.py), run through oracle/glref in a CHILD process (llvmpipe's LLVM stays out of the process that holds the GPU).
+        lp = None
+        if one > 40.0:  # (config 3's brute-force scan: a frame takes the CPU port a minute and llvmpipe about twice that)
+            lp = f"skipped: a frame of this config takes the CPU port {one:.0f} s, llvmpipe about twice that"
+        elif not args.no_llvmpipe:
+            try:
+                cmd = [sys.executable, "-m", "oracle.glport", "--config", args.config, "--frames", str(args.llvmpipe_frames if one < 5.0 else 1), "--warmup", "1",
+                       "--first-frame", str(args.warmup), "--check"]
+                r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+                lp = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"available": False, "reason": f"child exited {r.returncode}: {r.stderr[-300:]}"}
+            except Exception as e:
+                lp = {"available": False, "reason": f"{type(e).__name__}: {e}"}
+            if lp.get("available"):
+                lp["value"] = round(lp["rays"] / lp["frames"] / (lp["ms_per_frame"] * 1e-3) / 1e6, 3)
+                lp["unit"] = "Mrays/s"
+            else:
+                lp = "absent on box: " + str(lp.get("reason"))
+        cpu_baseline["llvmpipe"] = lp
 
+    if world == 1:
+        scaling_strong = {"value": round(traced_rays / elapsed_s / 1e6, 3), "unit": "Mrays/s", "ms_per_frame": round(elapsed_s / n_frames * 1e3, 4),
+                          "speedup_vs_n1_predicted": 1.0,
+                          "predicted_from_one_gpu": None if not predicted or "error" in predicted else
+                              {n: {"ms_per_frame": v.get("strong_ms_per_frame"),
+                                   "speedup_vs_n1_predicted": None if not v.get("strong_ms_per_frame") else round(elapsed_s / n_frames * 1e3 / v["strong_ms_per_frame"], 3)}
+                               for n, v in predicted.items()},
+                          "note": "N = 1: strong and weak coincide.  predicted_from_one_gpu = rank 0's share (1/N of the rows, S frames in flight) of an N-rank strong launch "
+                                  "timed on this GPU, kernel + plane accumulation, no gather: the compute side of the strong curve"}
+    else:
+        strong_ms = None if strong_s is None else strong_s / args.steps * 1e3
+        n1_ms = None if n1_s is None else n1_s / args.steps * 1e3
+        scaling_strong = {"value": None if strong_s is None else round(traced_rays / world / strong_s / 1e6, 3), "unit": "Mrays/s",
+                          "ms_per_frame": None if strong_ms is None else round(strong_ms, 4),
+                          "n1_same_run": None if n1_ms is None else {"ms_per_frame": round(n1_ms, 4), "value": round(traced_rays / world / n1_s / 1e6, 3),
+                                                                     "what": f"the same {args.steps} frames on rank 0's GPU alone, {S} frames in flight, HIP events"},
+                          "speedup_vs_n1_predicted": None if (strong_ms is None or n1_ms is None) else round(n1_ms / strong_ms, 3),
+                          "error": strong_err or n1_err,
+                          "note": "the same K frames whatever N is; speedup = this run's own one-GPU time of those frames / the N-GPU time (the driver's N = 1 line is the "
+                                  "authoritative denominator; this one makes the line readable by itself)"}
     if rank == 0:
         gather_note = "" if world == 1 else (", no gather" if args.no_gather else
                                              (f", RCCL gather of the framebuffer to rank 0 every {args.gather_every} launches and at the end of the timed region"
@@ -656,6 +801,10 @@ def main(argv=None):
             "ms_per_step": round(elapsed_s / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
+            # `value` above is the WEAK figure: every GPU always renders one full frame's worth of pixels per step, so it grows with N by construction.  The figure
+            # BASELINE.json's ">= 6x at 8 GPUs" is to be read from is this one: the SAME K frames whatever N is (S frames in flight in total per launch, the
+            # framebuffer gathered to rank 0 after every launch), against the one-GPU time of those frames measured on rank 0's GPU alone IN THIS RUN.
+            "scaling_strong": scaling_strong,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -680,9 +829,16 @@ def main(argv=None):
                        "host_ms_to_issue_timed_launches": round((t_issued - t0) * 1e3, 3),
                        # N > 1: the image RCCL gathered for min(K, 4) of the timed steps against the same frames rendered by rank 0's GPU alone
                        "gather_check": gather_check if world > 1 else None,
+                       # what torch.distributed reported after init_process_group (backend "nccl" IS RCCL on ROCm), and per rank: the render kernel's time over the
+                       # timed launches and the event-timed collectives (+ de-interleave on the root) of the timed region
+                       "rccl_ranks_seen": ranks_seen, "backend_seen": backend_seen,
+                       "per_rank": [{"rank": i, "kernel_ms": round(k, 3), "gather_ms": round(g, 3)} for i, (k, g) in enumerate(per_rank)],
+                       "gathers_in_timed_region": n_gathers,
                        "gather_check_what": None if world == 1 else f"frames [{args.warmup * world}, {(args.warmup + min(args.steps, 4)) * world}) re-rendered untimed by all ranks, gathered to "
                                                                       "rank 0 over the timed region's collective path, compared bit for bit with a one-rank render of the same frames on rank 0's GPU",
                        "timed_kernel_image_check": f"bit-identical to the counting kernel's accumulator over the {args.steps} timed steps (untimed replay)",
+                       # N = 1: the GPU's accumulator over the first n timed frames against the oracle's (the CPU restatement, pinned by the llvmpipe fixtures)
+                       "oracle_image_check": oracle_check,
                        "run_to_run": "one context = one draw: contexts of one binary differ by up to 3 % with where the 4 GB path-state buffer lands physically (profiles/r04_context_regimes.txt)",
                        # strong scaling: the same K frames whatever N is, S frames in flight IN TOTAL per launch, framebuffer gathered after every launch
                        "strong": ({"error": strong_err} if strong_err else None) if strong_s is None else

@@ -55,7 +55,7 @@ extern "C" {
 #define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
 #define GLRTX_ENOMEM (-5)
 
-#define GLRTX_ABI_VERSION 8
+#define GLRTX_ABI_VERSION 9
 
 typedef struct glrtx_ctx glrtx_ctx;
 
@@ -172,6 +172,16 @@ int glrtx_set_stream(glrtx_ctx *ctx, void *hip_stream);
  * megakernel with path regeneration, 0 = megakernel, one 16x16 tile per workgroup.  All three produce
  * bit-identical images.  The default can also be set with the environment variable GLRTX_VARIANT. */
 int glrtx_set_variant(glrtx_ctx *ctx, int variant);
+
+/* Shadow rays (sampleDirect, raytrace.frag:337-403).  Default (0): every light sample is resolved by the reference's own closest-hit search -- tHit
+ * starts at INFTY, boxes are culled by the hits found, in the reference's visiting order -- and only ends early once an occluder in front of the
+ * light is known (exact: tHit can only shrink).  1 opts in to the RANGE LIMIT of rounds 1-4: the search starts with tHit just beyond the light
+ * sample's distance, which also culls boxes beyond the light (3-4 % fewer node visits per frame).  The limit gives the reference's verdict unless a
+ * triangle test's computed t falls below the limit while the computed entry distance of one of its ancestors' boxes lies above it -- an
+ * ill-conditioned (grazing) triangle test near the edge of a light lying flush in its box; no margin in terms of the distance bounds that error,
+ * so the mode is NOT part of the bit-exact contract (csrc/pt_kernel.hip.h: shadow_limit).  Also: environment variable GLRTX_SHADOW_LIMIT=1 at
+ * glrtx_create.  Takes effect with the next launch.  Group members: through glrtx_group_ctx. */
+int glrtx_set_shadow_range_limit(glrtx_ctx *ctx, int enable);
 
 /* Enable/disable per-launch ray counting (one atomic per wavefront); default off. */
 int glrtx_count_rays(glrtx_ctx *ctx, int enable);

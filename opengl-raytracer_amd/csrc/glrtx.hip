@@ -783,6 +783,7 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
     if (const char *v = std::getenv("GLRTX_PIPE_SLOTS")) c->pipe_slots = (unsigned)std::max(1, std::min((int)kPipeSlots, std::atoi(v)));
     c->n_cu = prop.multiProcessorCount;
     if (const char *v = std::getenv("GLRTX_VARIANT")) { const int x = std::atoi(v); if (x >= 0 && x <= 2) c->variant = x; }
+    if (const char *v = std::getenv("GLRTX_SHADOW_LIMIT")) c->sc.shadow_limited = std::atoi(v) != 0 ? 1 : 0;  // default 0: the reference's own search (pt_kernel.hip.h: shadow_limit)
     *out = c;
     return GLRTX_OK;
 }
@@ -1048,6 +1049,12 @@ int glrtx_set_variant(glrtx_ctx *c, int variant) {
     if (!c) return GLRTX_EINVAL;
     if (variant < 0 || variant > 2) return fail(c, GLRTX_EINVAL, "glrtx_set_variant: unknown variant %d", variant);
     c->variant = variant;
+    return GLRTX_OK;
+}
+
+int glrtx_set_shadow_range_limit(glrtx_ctx *c, int enable) {
+    if (!c) return GLRTX_EINVAL;
+    c->sc.shadow_limited = enable != 0 ? 1 : 0;  // read by the next launch (the scene block is copied into every launch's arguments)
     return GLRTX_OK;
 }
 

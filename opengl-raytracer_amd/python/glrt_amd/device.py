@@ -35,7 +35,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_error", "glrtx_upload_scene", "glrtx_build_lbvh",
            "glrtx_resize", "glrtx_clear", "glrtx_set_partition", "glrtx_local_row_to_y", "glrtx_bind_accum",
-           "glrtx_set_stream", "glrtx_set_variant", "glrtx_count_rays", "glrtx_render", "glrtx_render_frames", "glrtx_sync", "glrtx_read_accum",
+           "glrtx_set_stream", "glrtx_set_variant", "glrtx_set_shadow_range_limit", "glrtx_count_rays", "glrtx_render", "glrtx_render_frames", "glrtx_sync", "glrtx_read_accum",
            "glrtx_accum_device_ptr", "glrtx_resolve_rgba8", "glrtx_get_stats", "glrtx_reset_stats",
            "glrtx_timer_begin", "glrtx_timer_end", "glrtx_upload_spheres", "glrtx_set_extensions",
            "glrtx_group_create", "glrtx_group_destroy", "glrtx_group_last_error", "glrtx_group_size", "glrtx_group_ctx",
@@ -74,6 +74,7 @@ def lib():
         L.glrtx_bind_accum.argtypes = [vp, vp, C.c_size_t, C.c_int]
         L.glrtx_set_stream.argtypes = [vp, vp]
         L.glrtx_set_variant.argtypes = [vp, C.c_int]
+        L.glrtx_set_shadow_range_limit.argtypes = [vp, C.c_int]
         L.glrtx_count_rays.argtypes = [vp, C.c_int]
         L.glrtx_render.argtypes = [vp, C.POINTER(Params)]
         L.glrtx_render_frames.argtypes = [vp, C.POINTER(Params), fp, C.c_int]
@@ -199,6 +200,10 @@ class Device:
 
     def set_variant(self, variant: int):
         self._ck(self.L.glrtx_set_variant(self.h, int(variant)))
+
+    def set_shadow_range_limit(self, enable: bool):
+        """False (default): shadow rays are searched like the reference's; True: with the range limit of rounds 1-4 (faster, not part of the bit-exact contract)."""
+        self._ck(self.L.glrtx_set_shadow_range_limit(self.h, int(enable)))
 
     def count_rays(self, enable=True):
         self._ck(self.L.glrtx_count_rays(self.h, int(enable)))

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(header, libname):
 
 def test_glrtx_abi_version_and_no_device_error_path():
     L = C.CDLL(str(PKG / "lib" / "libglrtx.so"))
-    assert L.glrtx_abi_version() == 8
+    assert L.glrtx_abi_version() == 9
     import torch
     if torch.cuda.is_available():
         pytest.skip("error path is for boxes without a GPU")

@@ -2,6 +2,7 @@
 settings alternating.  This removes the context-to-context spread (profiles/r04_context_regimes.txt) from the comparison altogether: differences of 0.1-0.2 % show.
 
     python tools/gpu_ab_env.py LIB ENV VALUE_A VALUE_B [--contexts 3] [--rounds 30] [--frames 20] [--config headline]
+    python tools/gpu_ab_env.py LIB call:set_shadow_range_limit 0 1        (a per-context setter of glrt_amd.device.Device instead of an environment variable)
 
 Per context: median ms per frame of each setting and the median (quartiles) of the per-round differences B against A; images and ray counts of the two settings compared first."""
 import hashlib
@@ -22,13 +23,22 @@ rest = a[4:]
 while rest:
     k = rest.pop(0).lstrip("-"); opt[k] = type(opt[k])(rest.pop(0))
 device.lib_path = lambda: pathlib.Path(os.path.join(ROOT, lib))
+
+
+def setting(d, v):
+    if env.startswith("call:"):
+        getattr(d, env[5:])(int(v))
+    else:
+        os.environ[env] = v
+
+
 sc, pr = scenes.CONFIGS[opt["config"]]()
 F = opt["frames"]
 for ci in range(opt["contexts"]):
     d = device.Device(); d.upload_scene(sc); d.resize(pr["width"], pr["height"])
     sig = []
     for v in (va, vb):
-        os.environ[env] = v
+        setting(d, v)
         d.clear(); d.count_rays(True); d.reset_stats()
         d.render_frames(pr, [host.frame_seed(i) for i in range(F)]); d.sync()
         sig.append((int(d.stats().rays), hashlib.sha1(np.ascontiguousarray(d.read_accum()).view(np.uint8)).hexdigest()))
@@ -37,7 +47,7 @@ for ci in range(opt["contexts"]):
     r = 1
     for rnd in range(opt["rounds"] + 2):
         for v in ((va, vb) if rnd % 2 == 0 else (vb, va)):
-            os.environ[env] = v
+            setting(d, v)
             d.render_frames(pr, [host.frame_seed(F * r + i) for i in range(F)]); d.sync(); r += 1
             if rnd >= 2: ms[v].append(d.stats().kernel_ms_last / F)
     A, B = np.asarray(ms[va]), np.asarray(ms[vb])
