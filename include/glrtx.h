@@ -100,6 +100,10 @@ typedef struct glrtx_stats {
                                    (default 6), less when the memory budget or a failed allocation says so, 0 when such launches run un-piped */
     int32_t pipe_resident_max;  /* ... and the most of them that had a render kernel on the device at once (counted when a launch is issued) since
                                    reset_stats: 1 means consecutive launches did not overlap, whatever the reason (queue mapping, a caller that syncs) */
+    int32_t device_error_pending; /* ABI 9: 1 while a launch that FAILED on the device sits unreported in the context's launch ring: glrtx_get_stats never blocks and
+                                     never consumes such a record (its rc stays GLRTX_OK and the timing fields stop advancing); the error itself -- kernel, size, frame
+                                     count, device -- is returned by the next glrtx_sync, or by the launch that needs the record's slot */
+    int32_t reserved1;
 } glrtx_stats;
 
 /* glrtx_stats.fallback_last: the wavefront kernel packs depth and sample index into one word of its path state */

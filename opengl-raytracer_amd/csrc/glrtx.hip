@@ -158,8 +158,10 @@ int fold_launches(glrtx_ctx *c, bool block, unsigned keep = 0) {
         if (e == hipErrorNotReady) { (void)hipGetLastError(); return GLRTX_OK; }
         // a polling caller (glrtx_get_stats) must not swallow a device error: the record stays in the ring, and the next blocking fold -- glrtx_sync,
         // or a launch that needs the slot -- reports it with the launch it belongs to
-        if (e != hipSuccess && !block) { (void)hipGetLastError(); return GLRTX_OK; }
+        // -- but the poller is TOLD: glrtx_stats.device_error_pending stays set until that blocking fold has consumed the record
+        if (e != hipSuccess && !block) { (void)hipGetLastError(); c->st.device_error_pending = 1; return GLRTX_OK; }
         c->ring_tail++;
+        if (e != hipSuccess) c->st.device_error_pending = 0;
         if (e != hipSuccess)
             return fail(c, GLRTX_EDEVICE, "render launch failed on the device (%s): %s, %dx%d (%d owned rows), %d frame(s), device %d", hipGetErrorString(e),
                         r.kernel, c->width, c->height, c->owned_rows, r.frames, c->device);
@@ -564,6 +566,14 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
                 if (slot->used) (void)hipEventSynchronize(slot->acc_done);
                 dev_free(slot->state); dev_free(slot->planes); dev_free(slot->queues);
                 slot->used = false;
+                // memory is what ran out: the slots behind this one give theirs back as well (they would never be picked again: pipe_slots shrinks to `pick`)
+                for (unsigned k = pick + 1; k < kPipeSlots; k++) {
+                    glrtx_ctx::PipeSlot &o = c->pipe[k];
+                    if (o.used) (void)hipEventSynchronize(o.acc_done);
+                    dev_free(o.state); dev_free(o.planes); dev_free(o.queues);
+                    o.used = false;
+                }
+                (void)hipGetLastError();
                 c->pipe_slots = pick;            // the slots in front of this one keep their buffers and stay in use
                 if (pick == 0) c->pipeline = false;
                 c->st.pipe_slots = (int32_t)pick;
@@ -764,12 +774,14 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
     // few hardware queues PER PRIORITY LEVEL, and streams that share a queue run one after the other: at the default priority the slots share those queues with
     // whatever streams the host application creates, and two caller streams kept busy with small kernels took one launch per frame from 1.25 to 2.7 ms
     // (tests/test_gpu_parity.py::test_overlapped_launches_next_to_a_callers_own_streams).  At a priority of their own the slots are mapped among themselves.
+    // NOTE for embedders: at "high" the library's render kernels are scheduled ahead of the host application's own normal-priority work on this GPU.
     int prio_least = 0, prio_greatest = 0, prio = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = prio_greatest = 0; }
     {
         const char *v = std::getenv("GLRTX_PIPE_PRIORITY");
         const std::string m = v ? v : "high";
         prio = m == "low" ? prio_least : (m == "normal" ? 0 : prio_greatest);
+        prio = std::max(std::min(prio, prio_least), prio_greatest);  // numerically: greatest <= prio <= least
     }
     for (auto &sl : c->pipe)
         if ((e = hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio)) != hipSuccess || (e = hipEventCreateWithFlags(&sl.render_done, hipEventDisableTiming)) != hipSuccess ||

@@ -189,6 +189,17 @@ DEV float pt_cos(float x) {
 struct Rng {
     float x, y, sx, sy;
 };
+#ifdef GLRTX_EXP_CHEAP_RAND
+// EXPERIMENT (never in a product build; the image is NOT the reference's): a random number for five instructions instead of two Cephes sines -- the upper bound
+// of what any faster statement of rand() could buy (profiles/r05_shade_bounds.txt).
+DEV float pt_rand(Rng &s) {
+    float p = s.x * 97.13f + 0.3547f;
+    s.x = p - __builtin_floorf(p);
+    p = s.y * 31.71f + s.x;
+    s.y = p - __builtin_floorf(p);
+    return s.x;
+}
+#else
 DEV float pt_rand(Rng &s) {
     const float a = 12.9898f, b = 78.233f, c = 43758.5453f;
     const float dy = (s.y - s.sy) * b;  // old state.y term, shared by both updates
@@ -200,6 +211,7 @@ DEV float pt_rand(Rng &s) {
     s.y = p - __builtin_floorf(p);
     return s.x;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------ helpers
 DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (az * bz + ay * by) + ax * bx; }
@@ -838,6 +850,21 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
     bool spec_out = false, stop_after = false;
     do {
         if (!h_hit) break;  // miss: nothing is added and the loop ends (:497-499)
+#if defined(GLRTX_EXP_SHADE_VPAD) || defined(GLRTX_EXP_SHADE_SPAD)
+        {   // EXPERIMENT (never in a product build): N more vector / scalar instructions per shaded hit, results unused -- the shade phase's elasticity to its
+            // own instruction count (profiles/r05_shade_bounds.txt)
+#ifdef GLRTX_EXP_SHADE_VPAD
+            float pad_ = bx;
+            for (int i_ = 0; i_ < GLRTX_EXP_SHADE_VPAD / 16; i_++)
+                asm volatile(GLRTX_REP8("v_fma_f32 %0, %1, %1, %0\n") GLRTX_REP8("v_fma_f32 %0, %1, %1, %0\n") : "+v"(pad_) : "v"(by));
+#endif
+#ifdef GLRTX_EXP_SHADE_SPAD
+            unsigned spad_ = 0;
+            for (int i_ = 0; i_ < GLRTX_EXP_SHADE_SPAD / 16; i_++)
+                asm volatile(GLRTX_REP8("s_add_u32 %0, %0, 1\n") GLRTX_REP8("s_add_u32 %0, %0, 1\n") : "+s"(spad_) : : "scc");
+#endif
+        }
+#endif
 
         const float nx = S.nx, ny = S.ny, nz = S.nz;
         const Mat M = load_mat(sc, lds_mats, S.mtrl);

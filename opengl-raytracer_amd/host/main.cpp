@@ -81,6 +81,6 @@ int main(int argc, char **argv) {
     scene->parse(input);
 
     window->mainloop(scene);
-    std::printf("[INFO] %d frames, last frame %.3f ms, %llu rays\n", frames, window->lastFrameMs(), window->raysTraced());
+    std::printf("[INFO] %d frames, %.3f ms per frame (wall time between the last two waits for the device, averaged over the frames issued in between), %llu rays\n", frames, window->lastFrameMs(), window->raysTraced());
     return 0;
 }

@@ -42,6 +42,8 @@ public:
     // Frames issued per launch of the render kernel (glrtx_render_frames; bit-identical to one launch per frame).
     // Used when no image is written between frames and render() is not overridden per frame; GLRT_FRAMES_IN_FLIGHT.
     void setFramesInFlight(int n) { framesInFlight_ = n < 1 ? 1 : n; }
+    // wall-clock ms PER FRAME between the last two waits for the device, averaged over the frames issued in between (with one PNG per run: the whole run, cold first
+    // launches included; with --save-every-frame: the last frame).  The device's own time of the last launch is glrtx_stats.kernel_ms_last.
     double lastFrameMs() const { return lastMs_; }
     unsigned long long raysTraced() const;
 

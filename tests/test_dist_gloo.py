@@ -81,6 +81,13 @@ def test_bench_self_spawns_its_ranks_and_gathers_to_root(tmp_path):
     assert strong["frames"] == steps and strong["frames_in_flight_total"] == spl and strong["value"] > 0 and "every launch" in strong["gather"]
     assert out["config"]["predicted"] is None and "bit-identical" in out["config"]["timed_kernel_image_check"]
     assert out["roofline"]["traffic_measured_in_run"] is False and out["roofline_aux"] is None
+    # round 5: the line explains itself: the ranks the process group reports, per-rank kernel / collective times, the strong figure at the top level
+    # (its own one-GPU denominator needs a device renderer: None in this CPU rehearsal)
+    cfg = out["config"]
+    assert cfg["rccl_ranks_seen"] == 2 and cfg["backend_seen"] == "gloo" and cfg["gathers_in_timed_region"] == 1
+    assert [r["rank"] for r in cfg["per_rank"]] == [0, 1] and all(r["gather_ms"] > 0 for r in cfg["per_rank"])
+    ss = out["scaling_strong"]
+    assert ss["value"] == strong["value"] and ss["ms_per_frame"] == strong["ms_per_frame"] and ss["n1_same_run"] is None and ss["speedup_vs_n1_predicted"] is None
     # the counting pass, its replay by the timed kernel (image check), the warm-up, the timed region, and the strong-scaling region
     # (one warm launch, then `steps` FRAMES in launches of `spl` frames in total) cover these frames, in this order, on every rank
     timed = list(range(warm * 2, (warm + steps) * 2))

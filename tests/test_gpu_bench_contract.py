@@ -72,6 +72,16 @@ def test_bench_prints_one_contract_json_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] == "port" and cb["unit"] == "Mrays/s" and cb["cores"] >= 1 and cb["value"] > 0
+    # round 5: the oracle's accumulator over the first timed frames is compared with the GPU's (a mismatch aborts the run), the llvmpipe leg runs beside it,
+    # and the strong-scaling figure sits at the top level
+    assert cfg["oracle_image_check"].startswith("bit-identical over ") and int(cfg["oracle_image_check"].split()[2]) >= 1
+    lp = cb["llvmpipe"]
+    assert isinstance(lp, str) and lp.startswith("absent on box") or (lp["available"] and "llvmpipe" in lp["renderer"] and lp["ms_per_frame"] > 0
+                                                                         and lp["image_vs_c_restatement"] == "bit-identical" and lp["cores"] >= 1)
+    ss = out["scaling_strong"]
+    assert ss["speedup_vs_n1_predicted"] == 1.0 and ss["value"] == out["value"] and set(ss["predicted_from_one_gpu"]) == {"2", "4", "8"}
+    assert all(1.0 < v["speedup_vs_n1_predicted"] <= int(n) * 1.05 for n, v in ss["predicted_from_one_gpu"].items()), ss
+    assert cfg["rccl_ranks_seen"] == 1 and len(cfg["per_rank"]) == 1 and cfg["per_rank"][0]["kernel_ms"] > 0
 
 
 def test_bench_two_ranks_on_one_gpu_check_what_the_collective_delivered():
@@ -89,3 +99,9 @@ def test_bench_two_ranks_on_one_gpu_check_what_the_collective_delivered():
     assert cfg["gather_check"] == "bit-identical", cfg["gather_check"]
     assert cfg["strong"]["gather_check"] == "bit-identical" and cfg["strong"]["frames"] == 6
     assert "bit-identical" in cfg["timed_kernel_image_check"]
+    # round 5: the line explains itself -- ranks the process group saw, per-rank kernel and collective times, and the strong figure with its own denominator
+    assert cfg["rccl_ranks_seen"] == 2 and cfg["backend_seen"] == "gloo" and cfg["gathers_in_timed_region"] == 1
+    assert [r["rank"] for r in cfg["per_rank"]] == [0, 1] and all(r["kernel_ms"] > 0 and r["gather_ms"] > 0 for r in cfg["per_rank"])
+    ss = out["scaling_strong"]
+    assert ss["value"] == cfg["strong"]["value"] and ss["ms_per_frame"] == cfg["strong"]["ms_per_frame"] and ss["error"] is None
+    assert ss["n1_same_run"]["ms_per_frame"] > 0 and abs(ss["speedup_vs_n1_predicted"] - ss["n1_same_run"]["ms_per_frame"] / ss["ms_per_frame"]) < 2e-3

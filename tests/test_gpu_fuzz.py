@@ -242,3 +242,26 @@ def test_odd_image_sizes_and_partitions(gpu_device):
             assert total == rays
     finally:
         d.set_partition(0, 1, 16)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_shadow_hostile_scenes_match_the_oracle(gpu_device, monkeypatch, seed):
+    """tests/fuzz_scenes.py: shadow_hostile -- lights flush in their ancestors' boxes, slivers, grazing light samples, |coordinates| up to 1e7 -- on the device's
+    DEFAULT search for shadow rays (the reference's own, round 5) against the oracle (which the live reference confirms on these scenes,
+    tests/test_reference_live.py); every form of the node fetch, both compilations, and the megakernel."""
+    from fuzz_scenes import shadow_hostile
+    from oracle import pt_oracle
+    tag, scene, params = shadow_hostile(seed)
+    monkeypatch.setenv("GLRTX_PAIR_FETCH", "012"[seed % 3])
+    ref, ref_rays = pt_oracle.render(scene, params)
+    d = gpu_device
+    d.upload_scene(scene); d.set_partition(0, 1, 16); d.resize(params["width"], params["height"])
+    try:
+        for variant, count in ((2, True), (2, False), (1, True)):
+            d.set_variant(variant); d.clear(); d.reset_stats(); d.count_rays(count)
+            d.render(params); d.sync()
+            assert_bit_equal(d.read_accum(), ref, f"{tag}, variant {variant}, counting {count}")
+            if count:
+                assert d.stats().rays == ref_rays
+    finally:
+        d.set_variant(2); d.count_rays(True)

@@ -1025,6 +1025,9 @@ def test_short_quotients_equal_the_ieee_quotient_on_every_float():
     assert int(m.group(3)) == (1 << 24) + 2, "... and of nothing else but NaNs: 2^24 zeros and denormals, two infinities (its callers reject |det| < EPS first)"
     assert re.search(r"^frcp: 0 mismatches$", r.stdout, re.M), r.stdout
     assert re.search(r"^div_pi: 0 mismatches$", r.stdout, re.M), r.stdout
+    # ... and the short form by itself on every pattern of its range, the inclusive ends 2^-100 and 2^120 among them (the wave-level branch of div_pi hides those)
+    m = re.search(r"^div_pi short form alone: 0 mismatches among the (\d+) patterns of its range", r.stdout, re.M)
+    assert m and int(m.group(1)) == 2 * (0x7B800000 - 0x0D800000 + 1) + 2, r.stdout
 
 
 def test_contexts_driven_from_concurrent_host_threads(gpu_device):

@@ -108,3 +108,16 @@ def test_oracle_bit_exact_vs_live_reference_on_hostile_inputs(gl):
         assert same.all(), f"{tag}: {int((~same).any(-1).sum())} pixels differ"
         n += 1
     assert n >= 50
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_oracle_bit_exact_vs_live_reference_on_shadow_hostile_scenes(gl, seed):
+    """Lights flush in the faces of their ancestors' boxes, sliver light triangles, receivers that run up to the lights' edges (grazing light samples), distances
+    1 .. 100, the scene translated to |coordinates| up to 1e7 (tests/fuzz_scenes.py: shadow_hostile) -- what the shadow rays' search is most sensitive to -- through
+    the LIVE reference: the oracle is the reference there, so the device tests of the same scenes (tests/test_gpu_fuzz.py) mean what they say."""
+    from fuzz_scenes import shadow_hostile
+    tag, sc, pr = shadow_hostile(seed)
+    rgb, cnt = gl.render_reference(sc, pr)
+    acc, _ = pt_oracle.render(sc, pr)
+    assert_bit_equal(acc[..., :3], rgb, tag)
+    assert_bit_equal(acc[..., 3], cnt, tag)
