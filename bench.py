@@ -155,6 +155,10 @@ class GpuRenderer:
         if bvh == "lbvh":  # BASELINE config 5: "linear-BVH traversal"
             nodes, depth, build_ms = self.dev.build_lbvh(scene["vert"], scene["tri"])
             self.scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"lbvh, built on the GPU in {build_ms:.2f} ms")
+        elif bvh == "sah-gpu":  # binned SAH by levels + exact sweep below, built on the device (glrtx_build_bvh_sah)
+            self.dev.build_bvh_sah(scene["vert"], scene["tri"])  # (the first build allocates)
+            nodes, depth, build_ms = self.dev.build_bvh_sah(scene["vert"], scene["tri"])
+            self.scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"SAH by levels, built on the GPU in {build_ms:.2f} ms")
         W, H = params["width"], params["height"]
         self.params = params
         self.dev.upload_scene(self.scene)
@@ -318,7 +322,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="headline", help="headline | c2 | c3 | c4 | c5 (parity-test configs)")
-    ap.add_argument("--bvh", default="default", help="default (the config's CPU SAH tree) | lbvh (linear BVH built on the GPU, glrtx_build_lbvh)")
+    ap.add_argument("--bvh", default="default", help="default (the config's CPU SAH tree) | lbvh (linear BVH built on the GPU, glrtx_build_lbvh) | sah-gpu (binned SAH built on the GPU, glrtx_build_bvh_sah)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-llvmpipe", action="store_true", help="skip the llvmpipe leg of cpu_baseline (the repository's own GLSL port through oracle/glref)")

@@ -55,9 +55,15 @@ int glrt_bvh_build_chain(const float *vert, size_t n_vert, const float *tri, siz
 #ifndef GLRT_LBVH_ROTATION_PASSES
 #define GLRT_LBVH_ROTATION_PASSES 4
 #endif
+#ifndef GLRT_LBVH_REBUILD_LEAVES
 #define GLRT_LBVH_REBUILD_LEAVES 64
+#endif
 int glrt_bvh_build_lbvh(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
                         int *max_depth_out);
+/* Binned SAH built level by level from the top (16 bins, 3 axes) down to segments of at most GLRT_LBVH_REBUILD_LEAVES triangles, which the exact sweep SAH of the
+ * LBVH pass then builds from their leaves (host/bvh.cpp: "SAH by levels").  Same node layout as glrt_bvh_build_lbvh; same output, bit for bit, as the GPU builder
+ * glrtx_build_bvh_sah (include/glrtx.h).  Quality: the CPU binned-SAH tree's or better (profiles/r05_tree_study.txt). */
+int glrt_bvh_build_sah_levels(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out, int *max_depth_out);
 
 void glrt_look_at(const float eye[3], const float center[3], const float up[3], float out[16]);
 void glrt_perspective(float fovy_deg, float aspect, float z_near, float z_far, float out[16]);

@@ -150,6 +150,12 @@ int glrtx_debug_pack_forks(const float *vert, size_t n_vert, const float *tri, s
  * (glrt_host.h).  build_ms_out (may be NULL): device time of the build without the host<->device copies. */
 int glrtx_build_lbvh(glrtx_ctx *ctx, const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
                      int *max_depth_out, float *build_ms_out);
+/* Binned SAH built on the device, level by level from the top (16 bins, 3 axes), with the exact sweep SAH of the LBVH pass for the subtrees of <= 64 triangles
+ * (csrc/sahl.hip.h; round 5).  Same contract and node layout as glrtx_build_lbvh; identical, bit for bit, to glrt_bvh_build_sah_levels (glrt_host.h).  The tree is as good
+ * as the CPU binned-SAH builder's -- config 5 takes 80.5 instead of the LBVH's 84.4 traversal steps per ray (profiles/r05_tree_study.txt) -- for about twice the LBVH's
+ * build time.  Replaces BVH::construct (src/core/bvh.cpp:59-160) like glrtx_build_lbvh does. */
+int glrtx_build_bvh_sah(glrtx_ctx *ctx, const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
+                     int *max_depth_out, float *build_ms_out);
 
 /* Full image size; (re)allocates and clears this ctx's accumulator rows. */
 int glrtx_resize(glrtx_ctx *ctx, int width, int height);

@@ -20,6 +20,7 @@
 #include "glrt_host.h"
 #include "pt_kernel.hip.h"
 #include "lbvh.hip.h"
+#include "sahl.hip.h"
 static_assert(glrtx::lbvh::kRotationPasses == GLRT_LBVH_ROTATION_PASSES, "device and CPU LBVH statements must run the same rotation sweeps");
 static_assert(glrtx::lbvh::kRebuildLeaves == GLRT_LBVH_REBUILD_LEAVES, "device and CPU LBVH statements must rebuild the same subtrees");
 
@@ -940,6 +941,33 @@ int glrtx_build_lbvh(glrtx_ctx *c, const float *vert, size_t n_vert, const float
     if (max_depth_out) *max_depth_out = depth;
     if (build_ms_out) *build_ms_out = ms;
     return depth < 63 ? GLRTX_OK : fail(c, GLRTX_EDEPTH, "glrtx_build_lbvh: tree depth %d exceeds the 64-entry traversal stack", depth);
+}
+
+int glrtx_build_bvh_sah(glrtx_ctx *c, const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out, int *max_depth_out,
+                     float *build_ms_out) {
+    if (!c) return GLRTX_EINVAL;
+    if (!vert || !tri || !nodes_out || n_tri == 0 || n_vert == 0) return fail(c, GLRTX_EINVAL, "glrtx_build_bvh_sah: empty input");
+    if (2 * n_tri - 1 > ((size_t)1 << 24) || n_vert > (size_t)INT32_MAX / 16)
+        return fail(c, GLRTX_EINVAL, "glrtx_build_bvh_sah: %zu triangles: node indices must fit a float (2^24)", n_tri);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n_nodes = 2 * n_tri - 1;
+    int rc;
+    if ((rc = dev_upload(c, c->bvhVert, vert, n_vert * 15 * sizeof(float)))) return rc;
+    if ((rc = dev_upload(c, c->bvhTri, tri, n_tri * 4 * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->bvhNodes, n_nodes * 9 * sizeof(float)))) return rc;
+    int depth = 0, bad = 0;
+    HIP_TRY(c, hipEventRecord(c->tm0, c->stream));
+    HIP_TRY(c, sahl::build(c->stream, (const float *)c->bvhVert.p, (unsigned)n_vert, (const float *)c->bvhTri.p, (unsigned)n_tri,
+                           (float *)c->bvhNodes.p, c->bvhWs, &depth, &bad, nullptr));
+    HIP_TRY(c, hipEventRecord(c->tm1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->tm1));
+    if (bad) return fail(c, GLRTX_ESCENE, "glrtx_build_bvh_sah: a triangle references a vertex out of range");
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->tm0, c->tm1));
+    HIP_TRY(c, hipMemcpy(nodes_out, c->bvhNodes.p, n_nodes * 9 * sizeof(float), hipMemcpyDeviceToHost));
+    if (max_depth_out) *max_depth_out = depth;
+    if (build_ms_out) *build_ms_out = ms;
+    return depth < 63 ? GLRTX_OK : fail(c, GLRTX_EDEPTH, "glrtx_build_bvh_sah: tree depth %d exceeds the 64-entry traversal stack", depth);
 }
 
 int glrtx_upload_spheres(glrtx_ctx *c, const float *spheres, size_t n_spheres) {

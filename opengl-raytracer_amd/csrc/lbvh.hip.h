@@ -335,14 +335,29 @@ __global__ __launch_bounds__(256) void k_subtree_roots(int n, const int *parent,
 // Lane p is position p of the subtree's leaf order.  The tree is built level by level; the nodes of a level are the SEGMENTS of the
 // order, all of them processed at once: per axis the lanes rank themselves inside their segment (a count over the segment),
 // segmented prefix / suffix unions by shuffles, one cost per lane, the segment's minimum by a loop over the segment.
-__global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, int *parent, const int *roots, const int *n_roots) {
+// EXPLICIT (round 5, sahl.hip.h): the subtrees are not read off an existing tree but given as lists -- root slot, number of leaves, where the leaves' sorted positions
+// start in `members` (ascending), and the first of the count - 2 consecutive slots of the subtree's other inner nodes.
+struct ExplicitSubtrees {
+    const int *root, *count, *member_off, *extra_base, *members;
+    int n;
+};
+template <bool EXPLICIT>
+__global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, int *parent, const int *roots, const int *n_roots, ExplicitSubtrees ex) {
     const int n_int = n - 1, lane = (int)threadIdx.x;
     __shared__ int q[2 * kRebuildLeaves], qn, slots[kRebuildLeaves], leaves[kRebuildLeaves], sorted_item[kRebuildLeaves], ord[kRebuildLeaves];
     __shared__ int ref_l[kRebuildLeaves], ref_r[kRebuildLeaves], split_k[kRebuildLeaves];
     __shared__ float box[kRebuildLeaves][6], cen[kRebuildLeaves][3], cost_l[kRebuildLeaves], key_l[kRebuildLeaves];
-  for (int ri = (int)blockIdx.x; ri < *n_roots; ri += (int)gridDim.x) {
-    const int r = roots[ri];
+  const int n_sub = EXPLICIT ? ex.n : *n_roots;
+  for (int ri = (int)blockIdx.x; ri < n_sub; ri += (int)gridDim.x) {
+    const int r = EXPLICIT ? ex.root[ri] : roots[ri];
     __syncthreads();  // the previous subtree's last reads of the shared arrays are done
+    int total, m;
+    if (EXPLICIT) {
+        m = ex.count[ri];
+        total = 2 * m - 1;
+        if (lane < m) leaves[lane] = n_int + ex.members[ex.member_off[ri] + lane];
+        if (lane < m - 2) slots[lane] = ex.extra_base[ri] + lane;
+    } else {
     // ---- gather the subtree's nodes (breadth-first), then its internal slots (without r) and leaves in ascending index order
     if (lane == 0) { q[0] = r; qn = 1; }
     __syncthreads();
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, in
         head = end;
         __syncthreads();
     }
-    const int total = qn, m = (total + 1) / 2;  // m leaves, m - 1 internal nodes
+    total = qn; m = (total + 1) / 2;  // m leaves, m - 1 internal nodes
     for (int i = lane; i < total; i += 64) {
         const int v = q[i];
         if (v == r) continue;
@@ -373,6 +388,7 @@ __global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, in
             if (w != r && (w >= n_int) == is_leaf && w < v) rank++;
         }
         if (is_leaf) leaves[rank] = v; else slots[rank] = v;
+    }
     }
     __syncthreads();
     int item = lane;  // the leaf (rank in `leaves`) at this lane's position
@@ -558,7 +574,7 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
         LBVH_TRY(hipMemsetAsync(n_roots, 0, sizeof(int), stream));
         hipLaunchKernelGGL(k_subtree_count, grid, block, 0, stream, (int)n, d_nodes, parent, count);
         hipLaunchKernelGGL(k_subtree_roots, grid, block, 0, stream, (int)n, parent, count, roots, n_roots);
-        hipLaunchKernelGGL(k_rebuild_subtrees, dim3(std::min<unsigned>(n - 1, 8192u)), dim3(64), 0, stream, (int)n, d_nodes, parent, roots, n_roots);
+        hipLaunchKernelGGL(k_rebuild_subtrees<false>, dim3(std::min<unsigned>(n - 1, 8192u)), dim3(64), 0, stream, (int)n, d_nodes, parent, (const int *)roots, (const int *)n_roots, ExplicitSubtrees{});
         LBVH_TRY(hipMemsetAsync(max_depth, 0, sizeof(int), stream));
         hipLaunchKernelGGL(k_max_depth, grid, block, 0, stream, (int)n, parent, max_depth);
         LBVH_TRY(hipGetLastError());

@@ -223,7 +223,7 @@ DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { ret
 //                  sign).  Zeros, denormals and infinities come out as NaN instead of inf / 0: the triangle tests, its only users, reject |det| < EPS before
 //                  anything reads the quotient, and an infinite det changes nothing either way (t comes out as 0 or NaN: never a hit that is closer).
 //   frcp(x):       the same, with the raw v_rcp_f32 result where x is a zero, a denormal or an infinity: = 1.0f / x for EVERY bit pattern (a NaN stays a NaN).
-//   div_pi(x):     x * RN(1 / PI) corrected by one residual step = x / PI for every x that is 0 or has 2^-100 <= |x| <= 2^120; a wave that holds any other
+//   div_pi(x):     x * RN(1 / PI) corrected by one residual step = x / PI for every x that is +0 or has 2^-100 <= |x| <= 2^120; a wave that holds any other
 //                  value takes the full division (a branch, not a select between both).
 DEV float rcp_newton(float x) {
     const float r = __builtin_amdgcn_rcpf(x);
@@ -237,7 +237,9 @@ DEV float frcp(float x) {
 constexpr float PT_INV_PI = 0.318309873342514038f;  // RN(1 / PT_PI)
 DEV float div_pi(float x) {
     const unsigned a = __float_as_uint(x) & 0x7FFFFFFFu;
-    if (__any(a != 0u && (a - 0x0D800000u) > (0x7B800000u - 0x0D800000u))) return x / PT_PI;  // 0 < |x| < 2^-100, |x| > 2^120, inf, NaN
+    // (-0 counts as out of range since round 5: the residual step turns it into +0 -- fma(-PI, -0, -0) = +0 -- found when tools/ubench/rcp_exact.hip began to check the
+    //  short form on every pattern of its range by itself; the wave-level branch had hidden it, the checker's waves being runs of consecutive patterns)
+    if (__any(__float_as_uint(x) != 0u && (a - 0x0D800000u) > (0x7B800000u - 0x0D800000u))) return x / PT_PI;  // -0, 0 < |x| < 2^-100, |x| > 2^120, inf, NaN
     const float q = x * PT_INV_PI;
     return __builtin_fmaf(__builtin_fmaf(-PT_PI, q, x), PT_INV_PI, q);
 }
@@ -601,7 +603,11 @@ DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) 
         "s_mov_b64 %[act], exec\n\t"
         GLRTX_ASM_SET_VBASE
         "v_bfrev_b32 v[GLRTX_VB+11], 1\n\t"
+#ifdef GLRTX_EXPERIMENT_LEAF_ALTERNATE
+        GLRTX_REP(GLRTX_STEPS_PER_TRIP_HALF, GLRTX_TRAV_STEP_ASM_LANE_NOLEAF GLRTX_TRAV_STEP_ASM_LANE)
+#else
         GLRTX_REP(GLRTX_STEPS_PER_TRIP, GLRTX_TRAV_STEP_ASM_LANE)
+#endif
         "99:\n\t"
         "s_mov_b64 exec, %[entry]"
         : [th] "+&v"(T.h.t), [tri] "+&v"(T.h.tri), [hu] "+&v"(T.h.u), [hv] "+&v"(T.h.v), [cur] "+&v"(T.cur), [sp] "+&v"(T.sp),

@@ -211,16 +211,17 @@ static_assert(GLRTX_STEPS_PER_TRIP % 2 == 0, "the alternating form of the node f
     "v_min_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], %[th]\n\t"                                                                                                                  \
     "v_cmp_ge_f32_e64 %[br], v[GLRTX_VB+16], v[GLRTX_VB+8]\n\t" \
     GLRTX_TRAV_STEP_TAIL
-#define GLRTX_TRAV_STEP_ASM_LANE \
-    GLRTX_TS_BEGIN \
+#define GLRTX_TRAV_LANE_LOADS \
     "v_lshl_add_u32 v[GLRTX_VB+15], %[cur], 6, %[bias]\n\t"                                                                                                      \
     "global_load_dwordx4 v[GLRTX_VB+0:GLRTX_VB+3], v[GLRTX_VB+15], %[base]\n\t"                                                                                                  \
     "global_load_dwordx4 v[GLRTX_VB+4:GLRTX_VB+7], v[GLRTX_VB+15], %[base] offset:16\n\t"                                                                                      \
     "global_load_dwordx3 v[GLRTX_VB+8:GLRTX_VB+10], v[GLRTX_VB+15], %[base] offset:32\n\t"                                                                                      \
     "global_load_dwordx3 v[GLRTX_VB+12:GLRTX_VB+14], v[GLRTX_VB+15], %[base] offset:48\n\t"                                                                                      \
-    GLRTX_X_LOADS                                                                                      \
+    GLRTX_X_LOADS
+#define GLRTX_TRAV_LANE_CLASSIFY \
     "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t"                           /* lanes at a triangle */                                                      \
-    "s_andn2_b64 exec, exec, %[leaf]\n\t"                               /* ---- fork arm: exec = lanes at a fork (may be none) */                      \
+    "s_andn2_b64 exec, exec, %[leaf]\n\t"                               /* ---- fork arm: exec = lanes at a fork (may be none) */
+#define GLRTX_TRAV_LANE_FORK \
     GLRTX_TS_WAIT0 GLRTX_W3 GLRTX_TS_WAIT1 GLRTX_X_VALU                                                                                                    \
     "v_sub_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ox]\n\t"   /* left child: (lo - o) / d as soon as the first load is in, (hi - o) / d after the second */    \
     "v_sub_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[oy]\n\t"                                                            \
@@ -268,8 +269,17 @@ static_assert(GLRTX_STEPS_PER_TRIP % 2 == 0, "the alternating form of the node f
     "v_min3_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+17], v[GLRTX_VB+18]\n\t"                                                                                                            \
     "v_max3_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], v[GLRTX_VB+9], v[GLRTX_VB+10]\n\t"                                                                                                            \
     "v_min_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], %[th]\n\t"                                                                                                                  \
-    "v_cmp_ge_f32_e64 %[br], v[GLRTX_VB+16], v[GLRTX_VB+8]\n\t" \
-    GLRTX_TRAV_STEP_TAIL
+    "v_cmp_ge_f32_e64 %[br], v[GLRTX_VB+16], v[GLRTX_VB+8]\n\t"
+#define GLRTX_TRAV_STEP_ASM_LANE GLRTX_TS_BEGIN GLRTX_TRAV_LANE_LOADS GLRTX_TRAV_LANE_CLASSIFY GLRTX_TRAV_LANE_FORK GLRTX_TRAV_STEP_TAIL
+// Measurement only (-DGLRTX_EXPERIMENT_LEAF_ALTERNATE, one record per lane, profiles/r05_lane_util.txt): a step WITHOUT the leaf arm.  The lanes at a triangle sit it out -- no fetch,
+// no arithmetic, their ray state untouched -- and are tested in the next (ordinary) step together with the lanes that reach a triangle there: the leaf arm then runs every
+// other step on about twice the lanes.  Same operations per ray in the same order (only when a lane takes its steps changes), so the image is bit-identical.
+#define GLRTX_TRAV_STEP_ASM_LANE_NOLEAF \
+    GLRTX_TS_BEGIN \
+    "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t" \
+    "s_andn2_b64 exec, exec, %[leaf]\n\t"   /* the lanes at a fork only (may be none: everything below is then a no-op) */ \
+    "s_mov_b64 %[leaf], 0\n\t"             /* ... and for the rest of this step nobody is at a leaf */ \
+    GLRTX_TRAV_LANE_LOADS GLRTX_TRAV_LANE_FORK GLRTX_TRAV_STEP_TAIL
 #define GLRTX_TRAV_STEP_TAIL \
     "v_cndmask_b32_e64 %[cur], v[GLRTX_VB+3], v[GLRTX_VB+7], %[br]\n\t"                    /* go on with the right child if it passed, else with the left */              \
     "s_or_b64 %[tmp], %[bl], %[br]\n\t"                                                                                                                \

@@ -360,48 +360,12 @@ struct TBox {  // unions of boxes without negative zeros (grow() reads x + 0.0f)
     }
 };
 constexpr int kRebuildSahLevels = 20;
-inline void rebuild_subtrees(float *nodes, int n, int max_leaves) {
-    if (n < 3 || max_leaves < 3) return;
-    const int n_int = n - 1;
-    // leaves below every internal node, capped at max_leaves + 1
-    std::vector<int> count((size_t)n_int, 0), parent((size_t)n_int, -1), order;
-    order.reserve((size_t)n_int);
-    order.push_back(0);
-    for (size_t q = 0; q < order.size(); q++) {
-        const int i = order[q];
-        for (int k = 6; k <= 7; k++) {
-            const int c = (int)nodes[9 * (size_t)i + k];
-            if (c < n_int) { parent[(size_t)c] = i; order.push_back(c); }
-        }
-    }
-    for (size_t q = order.size(); q-- > 0;) {
-        const int i = order[q];
-        int s = 0;
-        for (int k = 6; k <= 7; k++) {
-            const int c = (int)nodes[9 * (size_t)i + k];
-            s += c < n_int ? count[(size_t)c] : 1;
-        }
-        count[(size_t)i] = std::min(s, max_leaves + 1);
-    }
-    std::vector<int> slots, leaves, ord, tmp, next_ord;
+// One subtree rebuilt from its leaves with the exact sweep SAH: root slot r, the other internal slots and the leaf nodes in ascending index order.
+inline void rebuild_one(float *nodes, int r, const std::vector<int> &slots, const std::vector<int> &leaves) {
+    std::vector<int> ord, tmp, next_ord;
     struct Seg { int a, b, slot; };
     std::vector<Seg> segs, next;
     std::vector<float> cen;
-    for (int r : order) {
-        if (count[(size_t)r] > max_leaves || (parent[(size_t)r] >= 0 && count[(size_t)parent[(size_t)r]] <= max_leaves)) continue;
-        // the subtree's internal slots (without r) and leaf nodes, ascending
-        slots.clear(); leaves.clear();
-        tmp.assign(1, r);
-        while (!tmp.empty()) {
-            const int i = tmp.back();
-            tmp.pop_back();
-            if (i >= n_int) { leaves.push_back(i); continue; }
-            if (i != r) slots.push_back(i);
-            tmp.push_back((int)nodes[9 * (size_t)i + 6]);
-            tmp.push_back((int)nodes[9 * (size_t)i + 7]);
-        }
-        std::sort(slots.begin(), slots.end());
-        std::sort(leaves.begin(), leaves.end());
         const int m = (int)leaves.size();
         cen.resize(3 * (size_t)m);
         for (int k = 0; k < m; k++) {
@@ -464,6 +428,47 @@ inline void rebuild_subtrees(float *nodes, int n, int max_leaves) {
             }
             segs.swap(next);
         }
+}
+inline void rebuild_subtrees(float *nodes, int n, int max_leaves) {
+    if (n < 3 || max_leaves < 3) return;
+    const int n_int = n - 1;
+    // leaves below every internal node, capped at max_leaves + 1
+    std::vector<int> count((size_t)n_int, 0), parent((size_t)n_int, -1), order;
+    order.reserve((size_t)n_int);
+    order.push_back(0);
+    for (size_t q = 0; q < order.size(); q++) {
+        const int i = order[q];
+        for (int k = 6; k <= 7; k++) {
+            const int c = (int)nodes[9 * (size_t)i + k];
+            if (c < n_int) { parent[(size_t)c] = i; order.push_back(c); }
+        }
+    }
+    for (size_t q = order.size(); q-- > 0;) {
+        const int i = order[q];
+        int s = 0;
+        for (int k = 6; k <= 7; k++) {
+            const int c = (int)nodes[9 * (size_t)i + k];
+            s += c < n_int ? count[(size_t)c] : 1;
+        }
+        count[(size_t)i] = std::min(s, max_leaves + 1);
+    }
+    std::vector<int> slots, leaves, tmp;
+    for (int r : order) {
+        if (count[(size_t)r] > max_leaves || (parent[(size_t)r] >= 0 && count[(size_t)parent[(size_t)r]] <= max_leaves)) continue;
+        // the subtree's internal slots (without r) and leaf nodes, ascending
+        slots.clear(); leaves.clear();
+        tmp.assign(1, r);
+        while (!tmp.empty()) {
+            const int i = tmp.back();
+            tmp.pop_back();
+            if (i >= n_int) { leaves.push_back(i); continue; }
+            if (i != r) slots.push_back(i);
+            tmp.push_back((int)nodes[9 * (size_t)i + 6]);
+            tmp.push_back((int)nodes[9 * (size_t)i + 7]);
+        }
+        std::sort(slots.begin(), slots.end());
+        std::sort(leaves.begin(), leaves.end());
+        rebuild_one(nodes, r, slots, leaves);
     }
 }
 
@@ -577,6 +582,239 @@ int glrt_bvh_build_lbvh(const float *vert, size_t n_vert, const float *tri, size
     lbvh::rotate_tree(nodes_out, n, GLRT_LBVH_ROTATION_PASSES);
     lbvh::rebuild_subtrees(nodes_out, n, GLRT_LBVH_REBUILD_LEAVES);
     max_depth = lbvh::tree_depth(nodes_out, n);
+    if (max_depth_out) *max_depth_out = max_depth;
+    return max_depth < 63 ? GLRT_HOST_OK : GLRT_HOST_EDEPTH;
+}
+
+// ---------------------------------------------------------------------------------------------- SAH by levels
+// A top-down binned-SAH build that a GPU can run level by level (csrc/sahl.hip.h: glrtx_build_bvh_sah is the device statement and produces the same nodes bit for
+// bit), joined to the exact-sweep builder of the LBVH pass at the bottom.  Why it exists (round 5, profiles/r05_tree_study.txt): the Morton tree with rotations and
+// 64-leaf rebuilds renders config 5 3.6 % slower than the CPU binned-SAH tree; rebuilding larger and larger subtrees closes the gap only at >= 8192 leaves -- it is the
+// TOP of a Morton tree that is behind -- while the whole-tree exact sweep is no better than the binned tree (+-0.4 %).  So: the top by binned SAH, the bottom by exact sweep.
+//   * triangles in Morton order (the LBVH's keys): position k of that order is leaf node (n - 1) + k, as in the LBVH layout; internal nodes are 0 .. n - 2, root 0;
+//   * a SEGMENT is a set of positions; the root segment holds all of them.  Level by level every OPEN segment (more than kClosed = GLRT_LBVH_REBUILD_LEAVES members) is
+//     split: bounds of its members' box centres; per axis with a positive extent 16 bins (bin_of), a count and a box per bin; the split with the lowest
+//     area(left) * count(left) + area(right) * count(right) over the 3 x 15 bin boundaries with members on both sides, the first in (axis, bin) order among equals;
+//     members with bin <= the chosen bin go left.  If no boundary qualifies (all centres in one bin on every axis) or the segment is kDepthCap levels deep, the segment is
+//     split by POSITION instead: 16 bins over its range of positions, the boundary with the most even counts (first among equals) -- positions are distinct, so this
+//     always separates something, and it bounds the depth;
+//   * a child with one member is that leaf; with 2 .. kClosed members it is CLOSED: it gets a root node now and is built afterwards by the exact sweep SAH of the LBVH
+//     pass (lbvh::rebuild_one) from its leaves; a larger child is open in the next level.  Node numbers: the internal children of a level in segment order, left before
+//     right, continue the running count (breadth-first); the closed subtrees' other nodes follow behind all of them, subtree after subtree in the order they were closed;
+//   * boxes: a closed subtree's come from rebuild_one; the nodes above are the unions of their children's boxes, read as x + 0.0f (no negative zeros: min / max are then
+//     independent of the order of the operands, which is what lets the device form the same unions with atomics).
+namespace sahl {
+constexpr int kClosed = GLRT_LBVH_REBUILD_LEAVES;
+constexpr int kDepthCap = 40;
+struct BinSet {
+    int cnt[3][kBins];
+    lbvh::TBox box[3][kBins];
+    int rcnt[kBins];
+};
+}  // namespace sahl
+
+int glrt_bvh_build_sah_levels(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out, int *max_depth_out) {
+    if (!vert || !tri || !nodes_out || n_tri == 0) return GLRT_HOST_EINVAL;
+    if (2 * n_tri - 1 > ((size_t)1 << 24)) return GLRT_HOST_EINVAL;  // node indices travel as floats
+    struct FlushDenormals {  // the device statement runs with fp32 denormals flushed (as glrt_bvh_build_lbvh)
+#if defined(__SSE__)
+        unsigned csr = _mm_getcsr();
+        FlushDenormals() { _mm_setcsr(csr | 0x8040u); }
+        ~FlushDenormals() { _mm_setcsr(csr); }
+#endif
+    } flush_denormals;
+    (void)flush_denormals;
+    std::vector<Prim> prims;
+    if (!load_prims(vert, n_vert, tri, n_tri, prims)) return GLRT_HOST_EINDEX;
+    const int n = (int)n_tri;
+    auto put = [&](size_t idx, const float *lo, const float *hi, float cx, float cy, float cz) {
+        float *o = nodes_out + 9 * idx;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
+        o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+        o[6] = cx; o[7] = cy; o[8] = cz;
+    };
+    if (n == 1) {
+        put(0, prims[0].box.lo, prims[0].box.hi, -1.f, -1.f, 0.f);
+        if (max_depth_out) *max_depth_out = 0;
+        return GLRT_HOST_OK;
+    }
+    // Morton order, exactly as glrt_bvh_build_lbvh
+    Box cb0;
+    cb0.reset();
+    for (auto &p : prims) cb0.grow(p.c);
+    std::vector<uint64_t> keys((size_t)n);
+    for (int t = 0; t < n; t++) {
+        const Prim &p = prims[(size_t)t];
+        const uint32_t m = (lbvh::expand10(lbvh::quantize(p.c[0], cb0.lo[0], cb0.hi[0] - cb0.lo[0])) << 2) |
+                           (lbvh::expand10(lbvh::quantize(p.c[1], cb0.lo[1], cb0.hi[1] - cb0.lo[1])) << 1) |
+                           lbvh::expand10(lbvh::quantize(p.c[2], cb0.lo[2], cb0.hi[2] - cb0.lo[2]));
+        keys[(size_t)t] = ((uint64_t)m << 32) | (uint32_t)t;
+    }
+    std::sort(keys.begin(), keys.end());
+    const int n_int = n - 1;
+    auto prim_at = [&](int pos) -> const Prim & { return prims[(size_t)(uint32_t)keys[(size_t)pos]]; };
+    for (int k = 0; k < n; k++) put((size_t)(n_int + k), prim_at(k).box.lo, prim_at(k).box.hi, -1.f, -1.f, (float)(uint32_t)keys[(size_t)k]);
+
+    using sahl::kClosed;
+    // seg[pos]: index into the current level's open list, or -1 once the position's segment is closed / a leaf
+    std::vector<int> seg((size_t)n, 0), closed_of((size_t)n, -1);
+    struct Open { int node, count, depth; };
+    std::vector<Open> open, next_open;
+    struct Closed { int root, count; };
+    std::vector<Closed> closed;
+    int next_id = 1;  // node 0 is the root segment's node
+    if (n <= kClosed) {
+        closed.push_back(Closed{0, n});
+        for (int k = 0; k < n; k++) { seg[(size_t)k] = -1; closed_of[(size_t)k] = 0; }
+    } else {
+        open.push_back(Open{0, n, 0});
+    }
+    std::vector<float> cbl, cbh;          // per open segment: bounds of the centres, 3 + 3
+    std::vector<int> pmin, pmax;          // ... and of the positions
+    std::vector<sahl::BinSet> bins;
+    struct Split { int axis, bin, nl, nr; float lo, scale; int p0, prange; };  // axis 3: by position
+    std::vector<Split> split;
+    const float inf = std::numeric_limits<float>::infinity();
+    while (!open.empty()) {
+        const size_t S = open.size();
+        cbl.assign(3 * S, inf); cbh.assign(3 * S, -inf);
+        pmin.assign(S, n); pmax.assign(S, -1);
+        for (int k = 0; k < n; k++) {
+            const int s_ = seg[(size_t)k];
+            if (s_ < 0) continue;
+            const Prim &p = prim_at(k);
+            for (int a = 0; a < 3; a++) {
+                cbl[3 * (size_t)s_ + a] = std::fmin(cbl[3 * (size_t)s_ + a], p.c[a] + 0.0f);
+                cbh[3 * (size_t)s_ + a] = std::fmax(cbh[3 * (size_t)s_ + a], p.c[a] + 0.0f);
+            }
+            pmin[(size_t)s_] = std::min(pmin[(size_t)s_], k);
+            pmax[(size_t)s_] = std::max(pmax[(size_t)s_], k);
+        }
+        bins.resize(S);
+        for (auto &b : bins) {
+            for (int a = 0; a < 3; a++)
+                for (int q = 0; q < kBins; q++) { b.cnt[a][q] = 0; b.box[a][q].reset(); }
+            for (int q = 0; q < kBins; q++) b.rcnt[q] = 0;
+        }
+        auto rank_bin = [&](int k, int p0, int prange) { return (int)(((uint64_t)(uint32_t)(k - p0) * (uint64_t)kBins) / (uint64_t)(uint32_t)prange); };
+        for (int k = 0; k < n; k++) {
+            const int s_ = seg[(size_t)k];
+            if (s_ < 0) continue;
+            const Prim &p = prim_at(k);
+            sahl::BinSet &b = bins[(size_t)s_];
+            for (int a = 0; a < 3; a++) {
+                const float lo = cbl[3 * (size_t)s_ + a], ext = cbh[3 * (size_t)s_ + a] - lo;
+                if (!(ext > 0.f)) continue;
+                const int q = bin_of(p.c[a], lo, (float)kBins / ext, kBins);
+                b.cnt[a][q]++;
+                b.box[a][q].grow(p.box.lo, p.box.hi);
+            }
+            b.rcnt[rank_bin(k, pmin[(size_t)s_], pmax[(size_t)s_] - pmin[(size_t)s_] + 1)]++;
+        }
+        split.resize(S);
+        next_open.clear();
+        // every open segment's split; children numbered in segment order, left before right
+        std::vector<int> child_ref(2 * S), child_open(2 * S, -1), child_closed(2 * S, -1);
+        for (size_t s_ = 0; s_ < S; s_++) {
+            const sahl::BinSet &b = bins[s_];
+            float best = inf;
+            int best_axis = -1, best_bin = -1, best_nl = 0;
+            if (open[s_].depth < sahl::kDepthCap)
+                for (int a = 0; a < 3; a++) {
+                    const float ext = cbh[3 * s_ + a] - cbl[3 * s_ + a];
+                    if (!(ext > 0.f)) continue;
+                    float right_area[kBins];
+                    int right_cnt[kBins];
+                    lbvh::TBox acc;
+                    acc.reset();
+                    int c = 0;
+                    for (int q = kBins - 1; q > 0; q--) {
+                        if (b.cnt[a][q]) acc.grow(b.box[a][q].lo, b.box[a][q].hi);
+                        c += b.cnt[a][q];
+                        right_area[q] = c ? lbvh::half_area9(acc.lo, acc.hi) : 0.f;
+                        right_cnt[q] = c;
+                    }
+                    acc.reset();
+                    c = 0;
+                    for (int q = 0; q < kBins - 1; q++) {
+                        if (b.cnt[a][q]) acc.grow(b.box[a][q].lo, b.box[a][q].hi);
+                        c += b.cnt[a][q];
+                        if (c == 0 || right_cnt[q + 1] == 0) continue;
+                        const float cost = lbvh::half_area9(acc.lo, acc.hi) * (float)c + right_area[q + 1] * (float)right_cnt[q + 1];
+                        if (cost < best) { best = cost; best_axis = a; best_bin = q; best_nl = c; }
+                    }
+                }
+            Split &sp = split[s_];
+            sp.p0 = pmin[s_]; sp.prange = pmax[s_] - pmin[s_] + 1;
+            if (best_axis >= 0) {
+                sp.axis = best_axis; sp.bin = best_bin; sp.nl = best_nl; sp.nr = open[s_].count - best_nl;
+                sp.lo = cbl[3 * s_ + best_axis]; sp.scale = (float)kBins / (cbh[3 * s_ + best_axis] - cbl[3 * s_ + best_axis]);
+            } else {  // by position: the most even boundary, the first among equals
+                int c = 0, bb = -1, bnl = 0, bimb = 0;
+                for (int q = 0; q < kBins - 1; q++) {
+                    c += b.rcnt[q];
+                    if (c == 0 || c == open[s_].count) continue;
+                    const int imb = std::abs(2 * c - open[s_].count);
+                    if (bb < 0 || imb < bimb) { bb = q; bnl = c; bimb = imb; }
+                }
+                sp.axis = 3; sp.bin = bb; sp.nl = bnl; sp.nr = open[s_].count - bnl; sp.lo = 0.f; sp.scale = 0.f;
+            }
+            const int cnts[2] = {sp.nl, sp.nr};
+            for (int side = 0; side < 2; side++) {
+                const int c = cnts[side];
+                if (c == 1) { child_ref[2 * s_ + side] = -1; continue; }  // the member itself writes the leaf's number
+                const int id = next_id++;
+                child_ref[2 * s_ + side] = id;
+                if (c > kClosed) { child_open[2 * s_ + side] = (int)next_open.size(); next_open.push_back(Open{id, c, open[s_].depth + 1}); }
+                else { child_closed[2 * s_ + side] = (int)closed.size(); closed.push_back(Closed{id, c}); }
+            }
+            float *N = nodes_out + 9 * (size_t)open[s_].node;
+            N[6] = (float)child_ref[2 * s_]; N[7] = (float)child_ref[2 * s_ + 1]; N[8] = -1.0f;
+        }
+        for (int k = 0; k < n; k++) {
+            const int s_ = seg[(size_t)k];
+            if (s_ < 0) continue;
+            const Split &sp = split[(size_t)s_];
+            const int q = sp.axis == 3 ? rank_bin(k, sp.p0, sp.prange) : bin_of(prim_at(k).c[sp.axis], sp.lo, sp.scale, kBins);
+            const int side = q <= sp.bin ? 0 : 1;
+            const size_t ci = 2 * (size_t)s_ + (size_t)side;
+            if ((side ? sp.nr : sp.nl) == 1) {
+                nodes_out[9 * (size_t)open[(size_t)s_].node + 6 + (size_t)side] = (float)(n_int + k);
+                seg[(size_t)k] = -1;
+            } else if (child_open[ci] >= 0) seg[(size_t)k] = child_open[ci];
+            else { seg[(size_t)k] = -1; closed_of[(size_t)k] = child_closed[ci]; }
+        }
+        open.swap(next_open);
+    }
+    // the closed subtrees: their other nodes behind the ones numbered so far, then the exact sweep SAH from their leaves
+    std::vector<int> extra_base(closed.size());
+    int extra = next_id;
+    for (size_t j = 0; j < closed.size(); j++) { extra_base[j] = extra; extra += closed[j].count - 2; }
+    if (extra != n_int) return GLRT_HOST_EINVAL;  // (cannot happen: a binary tree over n leaves has n - 1 internal nodes)
+    std::vector<std::vector<int>> members(closed.size());
+    for (int k = 0; k < n; k++)
+        if (closed_of[(size_t)k] >= 0) members[(size_t)closed_of[(size_t)k]].push_back(n_int + k);  // ascending
+    std::vector<int> slots;
+    for (size_t j = 0; j < closed.size(); j++) {
+        slots.clear();
+        for (int q = 0; q < closed[j].count - 2; q++) slots.push_back(extra_base[j] + q);
+        lbvh::rebuild_one(nodes_out, closed[j].root, slots, members[j]);
+    }
+    // boxes of the nodes above the closed subtrees: children have larger numbers than their parents (breadth-first numbering)
+    std::vector<char> is_closed_root((size_t)n_int, 0);
+    for (auto &c : closed) is_closed_root[(size_t)c.root] = 1;
+    for (int i = next_id - 1; i >= 0; i--) {
+        if (is_closed_root[(size_t)i]) continue;
+        lbvh::TBox b;
+        b.reset();
+        for (int k = 6; k <= 7; k++) {
+            const float *C = nodes_out + 9 * (size_t)(int)nodes_out[9 * (size_t)i + k];
+            b.grow(C, C + 3);
+        }
+        float *N = nodes_out + 9 * (size_t)i;
+        for (int a = 0; a < 3; a++) { N[a] = b.lo[a]; N[3 + a] = b.hi[a]; }
+    }
+    const int max_depth = lbvh::tree_depth(nodes_out, n);
     if (max_depth_out) *max_depth_out = max_depth;
     return max_depth < 63 ? GLRT_HOST_OK : GLRT_HOST_EDEPTH;
 }

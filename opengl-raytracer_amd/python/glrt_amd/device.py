@@ -33,7 +33,7 @@ class Stats(C.Structure):
                 ("pipe_slots", C.c_int32), ("pipe_resident_max", C.c_int32), ("device_error_pending", C.c_int32), ("reserved1", C.c_int32)]
 
 
-EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_error", "glrtx_upload_scene", "glrtx_build_lbvh",
+EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_error", "glrtx_upload_scene", "glrtx_build_lbvh", "glrtx_build_bvh_sah",
            "glrtx_resize", "glrtx_clear", "glrtx_set_partition", "glrtx_local_row_to_y", "glrtx_bind_accum",
            "glrtx_set_stream", "glrtx_set_variant", "glrtx_set_shadow_range_limit", "glrtx_count_rays", "glrtx_render", "glrtx_render_frames", "glrtx_sync", "glrtx_read_accum",
            "glrtx_accum_device_ptr", "glrtx_resolve_rgba8", "glrtx_get_stats", "glrtx_reset_stats",
@@ -67,6 +67,7 @@ def lib():
         L.glrtx_upload_scene.argtypes = [vp, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, fp,
                                          C.c_size_t]
         L.glrtx_build_lbvh.argtypes = [vp, fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.glrtx_build_bvh_sah.argtypes = [vp, fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
         L.glrtx_resize.argtypes = [vp, C.c_int, C.c_int]
         L.glrtx_clear.argtypes = [vp]
         L.glrtx_set_partition.argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -172,6 +173,14 @@ class Device:
         nodes = np.zeros(((2 * t.shape[0] - 1) * 3, 3), np.float32)
         depth, ms = C.c_int(0), C.c_float(0)
         self._ck(self.L.glrtx_build_lbvh(self.h, _fp(v), v.shape[0], _fp(t), t.shape[0], _fp(nodes), C.byref(depth), C.byref(ms)))
+        return nodes, int(depth.value), float(ms.value)
+
+    def build_bvh_sah(self, vert, tri):
+        """Binned SAH by levels + exact sweep at the bottom, built on the GPU (glrtx_build_bvh_sah).  Returns (nodes, max_depth, device ms) like build_lbvh."""
+        v, t = _f32(vert).reshape(-1, 15), _f32(tri).reshape(-1, 4)
+        nodes = np.zeros(((2 * t.shape[0] - 1) * 3, 3), np.float32)
+        depth, ms = C.c_int(0), C.c_float(0)
+        self._ck(self.L.glrtx_build_bvh_sah(self.h, _fp(v), v.shape[0], _fp(t), t.shape[0], _fp(nodes), C.byref(depth), C.byref(ms)))
         return nodes, int(depth.value), float(ms.value)
 
     def upload_spheres(self, spheres):

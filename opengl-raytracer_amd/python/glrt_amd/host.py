@@ -28,6 +28,7 @@ def lib():
         L.glrt_bvh_node_count.argtypes = [C.c_size_t]
         L.glrt_bvh_build_sah.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_build_lbvh.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
+        L.glrt_bvh_build_sah_levels.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_build_chain.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp]
         L.glrt_look_at.argtypes = [fp, fp, fp, fp]
         L.glrt_perspective.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, fp]
@@ -58,6 +59,8 @@ def build_bvh(vert: np.ndarray, tri: np.ndarray, kind: str = "sah"):
         rc = L.glrt_bvh_build_sah(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
     elif kind == "lbvh":
         rc = L.glrt_bvh_build_lbvh(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
+    elif kind == "sahl":  # binned SAH by levels + exact sweep at the bottom: the CPU statement of the device builder glrtx_build_bvh_sah
+        rc = L.glrt_bvh_build_sah_levels(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
     elif kind == "chain":
         rc = L.glrt_bvh_build_chain(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes))
         depth.value = 2

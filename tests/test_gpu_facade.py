@@ -66,15 +66,17 @@ def test_glrt_main_with_gpu_built_lbvh_gives_the_same_image(tmp_path, gpu_device
     b = _c1_builder()
     js = scenes.export_json_obj(b, tmp_path, 96, 64, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0)
     imgs = {}
-    for kind in ("sah", "lbvh", "lbvh-cpu"):
+    for kind in ("sah", "lbvh", "lbvh-cpu", "sah-gpu", "sah-levels-cpu"):
         out = tmp_path / f"{kind}.png"
         r = subprocess.run([str(PKG / "lib" / "glrt_main"), "-i", str(js), "--max-depth", "3", "--frames", "2", "--bvh", kind,
                             "--out", str(out)], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stdout + r.stderr
-        if kind == "lbvh":
+        if kind in ("lbvh", "sah-gpu"):
             assert "built on the GPU" in r.stdout
         imgs[kind] = np.asarray(Image.open(out)).astype(np.int32)
     assert np.array_equal(imgs["lbvh"], imgs["lbvh-cpu"])
+    assert np.array_equal(imgs["sah-gpu"], imgs["sah-levels-cpu"])  # round 5: the binned SAH built on the device == its CPU statement
+    assert (np.abs(imgs["sah-gpu"] - imgs["sah"]).max(-1) > 0).mean() < 0.01
     assert (np.abs(imgs["lbvh"] - imgs["sah"]).max(-1) > 0).mean() < 0.01
 
 

@@ -20,7 +20,7 @@ DEV float frcp(float x) {
 }
 DEV float div_pi(float x) {
     const unsigned a = __float_as_uint(x) & 0x7FFFFFFFu;
-    const bool plain = a != 0u && (a - 0x0D800000u) > (0x7B800000u - 0x0D800000u);  // 0 < |x| < 2^-100, |x| > 2^120, inf, NaN
+    const bool plain = __float_as_uint(x) != 0u && (a - 0x0D800000u) > (0x7B800000u - 0x0D800000u);  // -0, 0 < |x| < 2^-100, |x| > 2^120, inf, NaN
     if (__any(plain)) return x / PT_PI;
     const float q = x * PT_INV_PI;
     return __builtin_fmaf(__builtin_fmaf(-PT_PI, q, x), PT_INV_PI, q);
@@ -28,7 +28,7 @@ DEV float div_pi(float x) {
 // the short form by itself, and its per-lane range predicate: checked on EVERY in-range pattern -- div_pi() above takes the full division for the whole wave as soon as
 // one of its 64 consecutive patterns is out of range, so the wave that holds the range's inclusive ends (|x| = 2^-100, 2^120) never runs the short form there
 DEV float div_pi_short(float x) { const float q = x * PT_INV_PI; return __builtin_fmaf(__builtin_fmaf(-PT_PI, q, x), PT_INV_PI, q); }
-DEV bool div_pi_in_range(float x) { const unsigned a = __float_as_uint(x) & 0x7FFFFFFFu; return !(a != 0u && (a - 0x0D800000u) > (0x7B800000u - 0x0D800000u)); }
+DEV bool div_pi_in_range(float x) { const unsigned a = __float_as_uint(x) & 0x7FFFFFFFu; return !(__float_as_uint(x) != 0u && (a - 0x0D800000u) > (0x7B800000u - 0x0D800000u)); }
 DEV bool same(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
 // out[6], [7]: mismatches of div_pi's short form evaluated unconditionally / patterns inside its range.  out[0]: newton mismatches with |x| >= FLT_MIN and finite; [1]: newton mismatches among zeros / denormals / infinities / NaNs; [2]: frcp mismatches (all);
 // [3]: div_pi mismatches (all); [4]: patterns visited; [5]: newton mismatches with |x| > 2^126 (the quotient is flushed: both must give a zero of det's sign)
