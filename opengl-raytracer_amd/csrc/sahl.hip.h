@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void k_init(int n, int *seg, int *closed_of, i
 // member of the scene -- the words then lie in different cache lines (atomics on one line serialise at ~90 per microsecond: with the words of a segment side by side
 // the root level alone took 0.4 ms), and a thread per segment reads them coalesced.
 // cb: 8 words -- [0..2] min / [3..5] max of the members' centres (ordered keys), [6] min / [7] max position
-__global__ __launch_bounds__(256) void k_seg_init(int S, int stride, unsigned *cb, unsigned *bins) {
+__global__ __launch_bounds__(256) void k_seg_init(const int *S_ptr, int stride, unsigned *cb, unsigned *bins) {
+    const int S = *S_ptr;  // (the launch covers the tables' capacity: the level's segment count is only known on the device)
     const int i = (int)(blockIdx.x * 256u + threadIdx.x);
     if (i >= S * kBinWords) return;
     const int w = i / S, s = i - w * S;
@@ -166,7 +167,8 @@ __device__ __forceinline__ float half_area(const float *lo, const float *hi) { r
 // (lanes 0 .. 47), the 16 position bins in lanes 48 .. 63: prefix and suffix unions of the bin boxes by shuffles inside the groups of 16, one cost per bin boundary,
 // the winner by a wave-wide minimum of (cost, lane) -- the first in (axis, bin) order among equal costs, as the CPU statement's sequential "strictly less" keeps it.
 // (min / max of values without negative zeros: the unions do not depend on the order they are formed in.)
-__global__ __launch_bounds__(64) void k_seg_split(int S, int stride, int level, const int *open_count, const unsigned *cb, const unsigned *bins, Split *split, int *need) {
+__global__ __launch_bounds__(64) void k_seg_split(const int *S_ptr, int stride, int level, const int *open_count, const unsigned *cb, const unsigned *bins, Split *split, int *need) {
+    const int S = *S_ptr;
     const int s = (int)blockIdx.x, lane = (int)threadIdx.x;
     if (s >= S) return;
     const int grp = lane >> 4, q = lane & 15;  // grp 0..2: axis, 3: position
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(64) void k_seg_split(int S, int stride, int level, 
 }
 
 // exclusive prefix sums of need[] (three interleaved columns) in segment order, ONE workgroup; the running totals continue the counters
-__global__ __launch_bounds__(1024) void k_seg_scan(int S, int *need, Counters *cnt, int reset_open) {
+__global__ __launch_bounds__(1024) void k_seg_scan(const int *S_ptr, int *need, Counters *cnt, int *S_next, int *level_first_next) {
+    const int S = *S_ptr;
     __shared__ int part[1024][3], base[3];
     const int t = (int)threadIdx.x;
     const int per = (S + 1023) / 1024;
@@ -259,13 +262,13 @@ __global__ __launch_bounds__(1024) void k_seg_scan(int S, int *need, Counters *c
     for (int s = a; s < b; s++)
         for (int w = 0; w < 3; w++) { const int v = need[s * 4 + w]; need[s * 4 + w] = run[w]; run[w] += v; }
     __syncthreads();
-    if (t == 0) { cnt->next_id = base[0]; cnt->n_open_next = base[1]; cnt->n_closed = base[2]; }
-    (void)reset_open;
+    if (t == 0) { cnt->next_id = base[0]; cnt->n_open_next = base[1]; cnt->n_closed = base[2]; *S_next = base[1]; *level_first_next = base[0]; }
 }
 
 // one thread per open segment: number its children, write its node's child links, the next level's open list and the closed list
-__global__ __launch_bounds__(64) void k_seg_assign(int S, int n, const int *open_node, const Split *split, const int *need, float *nodes, int *parent, int *next_node,
+__global__ __launch_bounds__(64) void k_seg_assign(const int *S_ptr, int n, const int *open_node, const Split *split, const int *need, float *nodes, int *parent, int *next_node,
                                                    int *next_count, int *closed_root, int *closed_count, int *child_info) {
+    const int S = *S_ptr;
     const int s = (int)(blockIdx.x * 64u + threadIdx.x);
     if (s >= S) return;
     const Split sp = split[s];
@@ -382,7 +385,7 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
     const size_t o_keys0 = take(8 * (size_t)n), o_keys1 = take(8 * (size_t)n), o_parent = take(4 * n_nodes), o_seg = take(4 * (size_t)n), o_closed_of = take(4 * (size_t)n),
                  o_small = take(1024), o_cb = take(32 * stride_sz), o_bins = take(4 * (size_t)kBinWords * stride_sz), o_split = take(sizeof(Split) * max_open),
                  o_need = take(16 * max_open), o_info = take(16 * max_open), o_open = take(4 * 4 * max_open), o_croot = take(4 * max_closed), o_ccount = take(4 * max_closed),
-                 o_moff = take(4 * max_closed), o_extra = take(4 * max_closed), o_flag = take(n_nodes), o_sort = take(sort_bytes);
+                 o_moff = take(4 * max_closed), o_extra = take(4 * max_closed), o_flag = take(n_nodes), o_lvl = take(4 * 2 * (256 + 2)), o_sort = take(sort_bytes);
     const size_t total = off;
     if (ws.bytes < total) {
         if (ws.p) (void)hipFree(ws.p);
@@ -421,10 +424,18 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
     *bad_index = bad;
     if (bad) return hipSuccess;
     if (n == 1) return hipSuccess;  // the single leaf is the root (k_leaves wrote it at node 0)
-    // ---- top-down phase
-    std::vector<int> level_first{0, 1};  // node ids [level_first[L], level_first[L + 1]) were numbered in level L - 1's split (level 0: the root)
+    // ---- top-down phase.  The host does not learn a level's segment count before it launches the next one: the per-segment kernels are launched over the tables'
+    // capacity and read the count from the device (S_of[level], written by the previous level's scan), and the host looks only every few levels whether segments are
+    // still open (a read-back per level cost a quarter of the build).  Node ranges per level (level_first) are read back once, at the end.
+    constexpr int kMaxLevels = 256;
+    int *S_of = (int *)(base + o_lvl), *level_first_dev = S_of + kMaxLevels + 2;  // S_of[L]: open segments of level L; level_first_dev[L + 1]: the running node count after level L - 1
     Counters h{1, 0, 0, 0};
-    int S = first_open ? 1 : 0, cur = 0;
+    {
+        std::vector<int> lv(2 * (kMaxLevels + 2), 0);
+        lv[0] = first_open ? 1 : 0;
+        lv[(size_t)kMaxLevels + 2 + 1] = 1;  // level_first_dev[1] = 1: ids [0, 1) are the root's
+        SAHL_TRY(hipMemcpyAsync(S_of, lv.data(), lv.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
     if (first_open) {
         const int root_open[2] = {0, ni};
         SAHL_TRY(hipMemcpyAsync(open_node[0], &root_open[0], 4, hipMemcpyHostToDevice, stream));
@@ -437,25 +448,38 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
         SAHL_TRY(hipMemcpyAsync(cnt, &h, sizeof h, hipMemcpyHostToDevice, stream));
     }
     int level = 0;
-    for (; S > 0; level++) {
-        const unsigned sw = (unsigned)S * (unsigned)kBinWords;
-        hipLaunchKernelGGL(k_seg_init, dim3((sw + 255) / 256), block, 0, stream, S, stride, cb, bins);
-        hipLaunchKernelGGL(k_seg_bounds, grid, block, 0, stream, ni, stride, (const float *)d_nodes, (const int *)seg, cb);
-        hipLaunchKernelGGL(k_seg_bin, grid, block, 0, stream, ni, stride, (const float *)d_nodes, (const int *)seg, (const unsigned *)cb, bins);
-        hipLaunchKernelGGL(k_seg_split, dim3((unsigned)S), dim3(64), 0, stream, S, stride, level, (const int *)open_count[cur], (const unsigned *)cb, (const unsigned *)bins, split, need);
-        hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, stream, S, need, cnt, 1);
-        hipLaunchKernelGGL(k_seg_assign, dim3((S + 63) / 64), dim3(64), 0, stream, S, ni, (const int *)open_node[cur], (const Split *)split, (const int *)need, d_nodes, parent,
-                           open_node[cur ^ 1], open_count[cur ^ 1], closed_root, closed_count, child_info);
-        hipLaunchKernelGGL(k_seg_partition, grid, block, 0, stream, ni, (const float *)d_nodes, d_nodes, seg, closed_of, (const int *)open_node[cur], (const Split *)split,
-                           (const int *)child_info, parent);
-        SAHL_TRY(hipGetLastError());
-        SAHL_TRY(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, stream));
-        SAHL_TRY(hipStreamSynchronize(stream));  // the next level's launch sizes depend on it
-        level_first.push_back(h.next_id);
-        S = h.n_open_next;
-        cur ^= 1;
-        if (level > 200) return hipErrorUnknown;  // (cannot happen: a split by position always separates)
+    if (first_open) {
+        // a balanced tree needs ceil(log2(n / 64)) levels; look for the first time there, then every other level
+        int first_look = 1;
+        while (((size_t)kClosed << first_look) < (size_t)n) first_look++;
+        const unsigned cap = (unsigned)max_open;
+        for (int look = first_look;; level++) {
+            if (level >= kMaxLevels) return hipErrorUnknown;  // (cannot happen: from 40 levels on every split is by position and halves its segment)
+            const int cur = level & 1;
+            const int *Sp = S_of + level;
+            hipLaunchKernelGGL(k_seg_init, dim3((cap * (unsigned)kBinWords + 255u) / 256u), block, 0, stream, Sp, stride, cb, bins);
+            hipLaunchKernelGGL(k_seg_bounds, grid, block, 0, stream, ni, stride, (const float *)d_nodes, (const int *)seg, cb);
+            hipLaunchKernelGGL(k_seg_bin, grid, block, 0, stream, ni, stride, (const float *)d_nodes, (const int *)seg, (const unsigned *)cb, bins);
+            hipLaunchKernelGGL(k_seg_split, dim3(cap), dim3(64), 0, stream, Sp, stride, level, (const int *)open_count[cur], (const unsigned *)cb, (const unsigned *)bins, split, need);
+            hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, stream, Sp, need, cnt, S_of + level + 1, level_first_dev + level + 2);
+            hipLaunchKernelGGL(k_seg_assign, dim3((cap + 63u) / 64u), dim3(64), 0, stream, Sp, ni, (const int *)open_node[cur], (const Split *)split, (const int *)need, d_nodes, parent,
+                               open_node[cur ^ 1], open_count[cur ^ 1], closed_root, closed_count, child_info);
+            hipLaunchKernelGGL(k_seg_partition, grid, block, 0, stream, ni, (const float *)d_nodes, d_nodes, seg, closed_of, (const int *)open_node[cur], (const Split *)split,
+                               (const int *)child_info, parent);
+            SAHL_TRY(hipGetLastError());
+            if (level + 1 >= look) {
+                int open_next = 0;
+                SAHL_TRY(hipMemcpyAsync(&open_next, S_of + level + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+                SAHL_TRY(hipStreamSynchronize(stream));
+                if (open_next == 0) { level++; break; }
+                look = level + 1 + 2;
+            }
+        }
     }
+    std::vector<int> level_first((size_t)level + 2);
+    SAHL_TRY(hipMemcpyAsync(level_first.data(), level_first_dev, level_first.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    SAHL_TRY(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, stream));
+    SAHL_TRY(hipStreamSynchronize(stream));
     if (build_levels) *build_levels = level;
     // ---- closed subtrees: members gathered (stable sort by subtree), inner nodes numbered, exact sweep SAH
     const int C = h.n_closed, top_nodes = h.next_id;
