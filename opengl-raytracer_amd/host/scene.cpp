@@ -232,7 +232,7 @@ bool loadObj(const std::string &filename, std::vector<Vertex> &out, std::string 
             }
         }
     }
-    bool hasNorm = !corners.empty();
+    bool hasNorm = !corners.empty(), hasUV = !corners.empty();
     out.clear();
     out.reserve(corners.size());
     for (const Corner &c : corners) {
@@ -248,6 +248,7 @@ bool loadObj(const std::string &filename, std::vector<Vertex> &out, std::string 
             hasNorm = false;
         }
         if (c.t >= 0 && (size_t)c.t * 2 + 1 < T.size()) { v.uv[0] = T[(size_t)c.t * 2]; v.uv[1] = T[(size_t)c.t * 2 + 1]; }
+        else hasUV = false;
         out.push_back(v);
     }
     if (!hasNorm) {  // face normals accumulated per vertex (trimesh.cpp:38-64); vertices are not shared
@@ -258,6 +259,33 @@ bool loadObj(const std::string &filename, std::vector<Vertex> &out, std::string 
             const float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
             for (int k = 0; k < 3; k++) n[k] = l != 0.0f ? n[k] / l : 0.0f;
             for (int q = 0; q < 3; q++) std::memcpy(out[t + q].normal, n, 12);
+        }
+    }
+    if (hasUV) {
+        // Tangent frame from the texture coordinates (trimesh.cpp:67-110), carried in texels 3 and 4 of the vertex record.  The path tracer never reads them
+        // (raytrace.frag:316-321 fetches texels 0 and 1 only); they are filled so that the vertex buffer a Scene hands over is the reference's record for record.
+        // Per face: the reference's (-dP1 dv2 + dP2 dv1) / det and (-dP2 du1 + dP1 du2) / det -- the NEGATED derivatives of the position along u and v, as written there --, each normalised; a vertex sums its faces' (here: its one face's -- vertices are not shared) and
+        // normalises the sums where both are non-zero.  A face whose texture coordinates are collinear (zero determinant) contributes nothing.
+        for (size_t t = 0; t + 2 < out.size(); t += 3) {
+            const Vertex &a = out[t], &b = out[t + 1], &c = out[t + 2];
+            const float p1[3] = {b.pos[0] - a.pos[0], b.pos[1] - a.pos[1], b.pos[2] - a.pos[2]}, p2[3] = {c.pos[0] - a.pos[0], c.pos[1] - a.pos[1], c.pos[2] - a.pos[2]};
+            const float du1 = b.uv[0] - a.uv[0], dv1 = b.uv[1] - a.uv[1], du2 = c.uv[0] - a.uv[0], dv2 = c.uv[1] - a.uv[1];
+            const float det = du1 * dv2 - dv1 * du2;
+            if (det == 0.0f) continue;
+            float tg[3], bn[3];
+            for (int k = 0; k < 3; k++) {
+                tg[k] = (-p1[k] * dv2 + p2[k] * dv1) / det;
+                bn[k] = (-p2[k] * du1 + p1[k] * du2) / det;
+            }
+            const float lt = std::sqrt(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2]), lb = std::sqrt(bn[0] * bn[0] + bn[1] * bn[1] + bn[2] * bn[2]);
+            for (int q = 0; q < 3; q++)
+                for (int k = 0; k < 3; k++) { out[t + q].tangent[k] += tg[k] / lt; out[t + q].binormal[k] += bn[k] / lb; }
+        }
+        for (Vertex &v : out) {
+            const float lt = std::sqrt(v.tangent[0] * v.tangent[0] + v.tangent[1] * v.tangent[1] + v.tangent[2] * v.tangent[2]);
+            const float lb = std::sqrt(v.binormal[0] * v.binormal[0] + v.binormal[1] * v.binormal[1] + v.binormal[2] * v.binormal[2]);
+            if (lt > 0.0f && lb > 0.0f)
+                for (int k = 0; k < 3; k++) { v.tangent[k] /= lt; v.binormal[k] /= lb; }
         }
     }
     return true;

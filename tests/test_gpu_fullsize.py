@@ -6,7 +6,7 @@ every workgroup, the chunking of a launch by the memory budget, the plane offset
 reference's arithmetic (oracle/pt_oracle.c, pinned by the llvmpipe fixtures; raytrace.frag:565-614 is what one pixel does):
 
   * whole frames, bit for bit and with the ray count: the headline (1920x1080, 8 bounces), config 2 (depth 4), config 5 (100 k
-    triangles, the CPU SAH tree and the tree the GPU builds);
+    triangles, the CPU SAH tree and the two trees the GPU builds); the headline also as eight overlapped single-frame launches;
   * row bands (first, middle and last stripes) where the oracle needs minutes for a whole frame: config 3 at 1080p (10 k triangles
     as a chain = brute force) and config 4 at 3840x2160 with 16 spp in one pass and as 16 accumulated frames;
   * every one of them as a single launch (both compilations of the kernel), as 8 (16) frames in flight, as an 8-rank partition
@@ -120,6 +120,28 @@ def test_whole_frames_at_full_size_equal_the_oracle(gpu_device, cfg):
     assert_bit_equal(_group(scene, params, seeds), refn, f"{cfg} 1080p, group of 8, frames in flight")
 
 
+def test_overlapped_single_frame_launches_at_full_size_equal_the_oracle(gpu_device):
+    """The reference's own cadence -- one glrtx_render call per frame (window.cpp:121-169) -- at the headline's full size: eight calls issued back to back overlap on the
+    device (six internal streams with buffers of their own, the planes added to the accumulator in call order); the accumulated image is the oracle's, bit for bit."""
+    d = gpu_device
+    scene, params = scenes.config_headline()
+    seeds = _seeds(N_IN_FLIGHT)
+    ref, rays = _oracle(scene, params, seeds)
+    d.upload_scene(scene)
+    d.set_partition(0, 1, 8)
+    d.resize(params["width"], params["height"])
+    for count in (True, False):
+        d.clear(); d.reset_stats(); d.count_rays(count)
+        for sd in seeds:
+            d.render(dict(params, seed=sd))
+        d.sync()
+        st = d.stats()
+        assert_bit_equal(d.read_accum(), ref, f"headline 1080p, {N_IN_FLIGHT} overlapped single-frame launches, counting={count}")
+        if count:
+            assert st.rays == rays
+        assert st.pipe_slots >= 1 and st.launches == N_IN_FLIGHT
+
+
 def test_config5_with_the_gpu_built_tree_at_full_size(gpu_device):
     """BASELINE config 5 as it is named: 100 k triangles, LINEAR BVH (built on the device), 1920x1080, 4 bounces -- against the oracle walking
     the same tree, and against the oracle on the CPU SAH tree (random triangles: no exact ties, so the tree cannot show in the image)."""
@@ -135,6 +157,14 @@ def test_config5_with_the_gpu_built_tree_at_full_size(gpu_device):
     assert_bit_equal(acc, ref, "c5 1080p, GPU-built LBVH, vs the oracle on that tree")
     ref_sah, _ = _oracle(scene, params, seeds)
     assert_bit_equal(acc, ref_sah, "c5 1080p, LBVH image vs the oracle's SAH-tree image")
+    # the binned SAH built on the device (glrtx_build_bvh_sah, round 5): the oracle walking that tree, and the same image again
+    nodes, depth, _ = d.build_bvh_sah(scene["vert"], scene["tri"])
+    sl = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind="sahl")
+    ref, rays = _oracle(sl, params, seeds)
+    acc, st = _in_flight(d, sl, params, seeds, count=True)
+    assert st.rays == rays
+    assert_bit_equal(acc, ref, "c5 1080p, device-built SAH tree, vs the oracle on that tree")
+    assert_bit_equal(acc, ref_sah, "c5 1080p, device-built SAH tree vs the oracle's CPU-SAH-tree image")
 
 
 def _bands(h, rows):

@@ -140,3 +140,27 @@ def test_mutated_inputs_end_in_a_result_or_in_the_readers_own_error(tmp_path):
         assert clean, (it, f.name, r.returncode, r.stderr[-300:])
         outcomes[r.returncode] = outcomes.get(r.returncode, 0) + 1
     assert outcomes.get(0, 0) > 0 and outcomes.get(-6, 0) > 0, outcomes
+
+
+def test_tangent_frame_from_texture_coordinates(tmp_path):
+    """OBJ meshes with texture coordinates get per-vertex tangents and binormals (trimesh.cpp:67-110) in texels 3 and 4 of the vertex records -- never read by the path
+    tracer, filled so that the vertex buffer is the reference's record for record; a mesh without (or with collinear) texture coordinates leaves them zero."""
+    js = scenes.export_json_obj(_builder(), tmp_path, 16, 16, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0)
+    doc = json.loads(js.read_text())
+    (tmp_path / "uvquad.obj").write_text(
+        "v 0 0 0\nv 2 0 0\nv 2 0 -3\nv 0 0 -3\nvn 0 1 0\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0.5 0.5\n"
+        "f 1/1/1 2/2/1 3/3/1\nf 1/1/1 3/3/1 4/4/1\n"      # u along +x, v along -z
+        "f 1/5/1 2/5/1 3/5/1\n")                          # all three corners at one uv: zero determinant
+    doc["scene"] = [dict(doc["scene"][0], filename="uvquad.obj")]
+    js.write_text(json.dumps(doc))
+    got = _probe(js)
+    v = got["vert"]
+    assert v.shape == (9, 15)
+    assert np.array_equal(v[:6, 6:8], np.array([[0, 0], [1, 0], [1, 1], [0, 0], [1, 1], [0, 1]], np.float32))
+    # (the reference's formula, (-dP1 dv2 + dP2 dv1) / det, is the NEGATED derivative of the position along u -- and along v likewise: reproduced as written)
+    assert np.allclose(v[:6, 9:12], [-1, 0, 0], atol=1e-6) and np.allclose(v[:6, 12:15], [0, 0, 1], atol=1e-6)
+    assert np.all(v[6:, 9:15] == 0.0)
+    # no texture coordinates anywhere: nothing is computed (hasUV is a property of the whole mesh, trimesh.cpp:113-190)
+    got = _probe(scenes.export_json_obj(_builder(), tmp_path / "plain", 16, 16, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0))
+    assert np.all(got["vert"][:, 6:15] == 0.0)
