@@ -542,12 +542,12 @@ def main(argv=None):
     # flight per launch -- exactly what `bench.py --gpus 1 --steps K` times -- while the other ranks wait at the barrier behind it.
     n1_s, n1_err = None, None
     if world > 1 and hasattr(R, "time_one_rank"):
-        try:
-            if rank == 0:
+        if rank == 0:
+            try:
                 n1_s = R.time_one_rank(args.warmup * world, args.steps, seed, S)
-            barrier()
-        except Exception as e:
-            n1_err = f"{type(e).__name__}: {e}"
+            except Exception as e:  # an extra: never fatal -- and never a reason for rank 0 to miss the barrier the other ranks are waiting in
+                n1_err = f"{type(e).__name__}: {e}"
+        barrier()
 
     # ---- self-check of what the collective delivered (N > 1, untimed): min(K, 4) of the timed steps are rendered again by all ranks into cleared
     # accumulators and gathered over the same collective path -- once as the weak region issues them, once as the strong region does -- and rank 0
@@ -571,13 +571,16 @@ def main(argv=None):
             img_s = run_strong(f_lo, f_n) if strong_err is None else None
             barrier()
             if rank == 0:
-                ref = R.render_full_reference(f_lo, f_n, seed)
-                d = pixels_differing(img_w, ref)
-                gather_check = "bit-identical" if d == 0 else f"{d} of {W * H} pixels differ"
-                if img_s is not None:
-                    d = pixels_differing(img_s, ref)
-                    strong_check = "bit-identical" if d == 0 else f"{d} of {W * H} pixels differ"
-                del ref
+                try:  # (rank 0 alone: whatever happens here, it must still reach the barrier the other ranks are waiting in)
+                    ref = R.render_full_reference(f_lo, f_n, seed)
+                    d = pixels_differing(img_w, ref)
+                    gather_check = "bit-identical" if d == 0 else f"{d} of {W * H} pixels differ"
+                    if img_s is not None:
+                        d = pixels_differing(img_s, ref)
+                        strong_check = "bit-identical" if d == 0 else f"{d} of {W * H} pixels differ"
+                    del ref
+                except Exception as e:
+                    gather_check = f"error: {type(e).__name__}: {e}"
             barrier()
         except Exception as e:  # reported, never fatal to the contract line
             gather_check = f"error: {type(e).__name__}: {e}"
