@@ -145,7 +145,7 @@ class GpuRenderer:
 
     def __init__(self, rank, world, local_rank, scene, params, bvh):
         import torch
-        from glrt_amd import device, dist
+        from glrt_amd import device, dist, host
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
         torch.cuda.set_device(local_rank)
@@ -154,11 +154,13 @@ class GpuRenderer:
         self.scene = scene
         if bvh == "lbvh":  # BASELINE config 5: "linear-BVH traversal"
             nodes, depth, build_ms = self.dev.build_lbvh(scene["vert"], scene["tri"])
-            self.scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"lbvh, built on the GPU in {build_ms:.2f} ms")
+            nodes, lf = host.lights_first(nodes, scene["tri"], scene["mat"])  # as glrt::Scene::parse does after any builder
+            self.scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"lbvh, built on the GPU in {build_ms:.2f} ms", bvh_lights_first=lf)
         elif bvh == "sah-gpu":  # binned SAH by levels + exact sweep below, built on the device (glrtx_build_bvh_sah)
             self.dev.build_bvh_sah(scene["vert"], scene["tri"])  # (the first build allocates)
             nodes, depth, build_ms = self.dev.build_bvh_sah(scene["vert"], scene["tri"])
-            self.scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"SAH by levels, built on the GPU in {build_ms:.2f} ms")
+            nodes, lf = host.lights_first(nodes, scene["tri"], scene["mat"])
+            self.scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"SAH by levels, built on the GPU in {build_ms:.2f} ms", bvh_lights_first=lf)
         W, H = params["width"], params["height"]
         self.params = params
         self.dev.upload_scene(self.scene)
@@ -815,7 +817,7 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n_tri} triangles (BVH {scene['bvh_kind']}), {W}x{H}, "
+            "config": {"workload": f"{args.config}: {n_tri} triangles (BVH {scene['bvh_kind']}; the light side first at {scene.get('bvh_lights_first', 0)} forks), {W}x{H}, "
                                    f"u_maxDepth={params['max_depth']}, {params['n_samples']} spp/frame",
                        "step": f"{world} consecutive frame(s) of the accumulation loop = one full frame's worth of pixels per GPU",
                        "frames_per_step": world,

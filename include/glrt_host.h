@@ -64,6 +64,12 @@ int glrt_bvh_build_lbvh(const float *vert, size_t n_vert, const float *tri, size
  * LBVH pass then builds from their leaves (host/bvh.cpp: "SAH by levels").  Same node layout as glrt_bvh_build_lbvh; same output, bit for bit, as the GPU builder
  * glrtx_build_bvh_sah (include/glrtx.h).  Quality: the CPU binned-SAH tree's or better (profiles/r05_tree_study.txt). */
 int glrt_bvh_build_sah_levels(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out, int *max_depth_out);
+/* Post-pass over a tree of ANY of the builders above (or of the device builders, include/glrtx.h): at every fork where exactly one child's subtree contains emitting
+ * triangles (material emission != 0: the rule of the light list, scene.cpp:246-248) that child is put into the slot the reference's traversal visits FIRST (children.y,
+ * raytrace.frag:299-307), so that shadow rays -- half of all rays -- meet their light before anything else and cull the rest by its distance.  Two child references per
+ * exchanged fork change, nothing else.  mat: n_mat records of 18 floats (scene.h:28-35).  Returns the number of forks exchanged (>= 0) or GLRT_HOST_E*.
+ * glrt::Scene::parse and the Python scene builder apply it after their builder (GLRT_BVH_LIGHTS_FIRST=0 leaves the builder's order). */
+int glrt_bvh_lights_first(float *nodes, size_t n_nodes, const float *tri, size_t n_tri, const float *mat, size_t n_mat);
 
 void glrt_look_at(const float eye[3], const float center[3], const float up[3], float out[16]);
 void glrt_perspective(float fovy_deg, float aspect, float z_near, float z_far, float out[16]);

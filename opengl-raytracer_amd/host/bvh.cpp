@@ -819,6 +819,57 @@ int glrt_bvh_build_sah_levels(const float *vert, size_t n_vert, const float *tri
     return max_depth < 63 ? GLRT_HOST_OK : GLRT_HOST_EDEPTH;
 }
 
+// ---------------------------------------------------------------------------------------------- light side first
+// The reference's traversal visits children.y first at every fork, whatever the ray (raytrace.frag:299-307: push x, push y, pop y).  Which child is which is the
+// BUILDER's choice -- and half of all rays are shadow rays, every one of them aimed at a light: its search is over as soon as the light is hit (every box beyond is
+// culled by tHit from then on), but until then nothing culls, and at a fork that holds the light in its x child the ray first walks the whole y subtree.  So, after any
+// of the builders: at every fork where exactly ONE child's subtree contains emitting triangles, that child goes into the y slot.  (Emitting: the triangle's material has
+// a non-zero emission -- the rule that puts a triangle on the light list, scene.cpp:246-248.)  Boxes, subtrees and node numbers stay; two child references are exchanged.
+// On the headline scene two forks near the root are exchanged and the frame is 4 % shorter (profiles/r05_lights_first.txt); closest-hit results do not depend on the
+// order (exact ties aside, as with any difference between two builders' trees: SURVEY.md H4).
+// nodes: the wire format (9 floats per node, root = node 0), modified in place.  Returns the number of forks exchanged, or a negative GLRT_HOST_E* code.
+int glrt_bvh_lights_first(float *nodes, size_t n_nodes, const float *tri, size_t n_tri, const float *mat, size_t n_mat) {
+    if (!nodes || n_nodes == 0) return 0;
+    if (!tri || !mat) return GLRT_HOST_EINVAL;
+    std::vector<char> emits(n_mat, 0);
+    for (size_t m = 0; m < n_mat; m++) {
+        const float *e = mat + 18 * m + 3;  // texel 1 of the material record: emission
+        emits[m] = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) != 0.0f;
+    }
+    // post-order over the tree (iterative; a child index out of range or met twice ends the pass: the upload reports such trees)
+    std::vector<char> has_light(n_nodes, 0), seen(n_nodes, 0);
+    std::vector<size_t> order, st{0};
+    order.reserve(n_nodes);
+    while (!st.empty()) {
+        const size_t i = st.back();
+        st.pop_back();
+        if (i >= n_nodes || seen[i]) return GLRT_HOST_EINVAL;
+        seen[i] = 1;
+        order.push_back(i);
+        const float *N = nodes + 9 * i;
+        if (N[8] < 0.0f)
+            for (int k = 6; k <= 7; k++)
+                if (N[k] >= 0.0f) st.push_back((size_t)N[k]);  // (a child of -1 is absent: bvh.cpp:73-75)
+    }
+    int swapped = 0;
+    for (size_t q = order.size(); q-- > 0;) {
+        const size_t i = order[q];
+        float *N = nodes + 9 * i;
+        if (N[8] >= 0.0f) {
+            const size_t t = (size_t)N[8];
+            if (t < n_tri) {
+                const float fm = tri[4 * t + 3];
+                has_light[i] = fm >= 0.0f && (size_t)fm < n_mat && emits[(size_t)fm];
+            }
+            continue;
+        }
+        const bool lx = N[6] >= 0.0f && has_light[(size_t)N[6]], ly = N[7] >= 0.0f && has_light[(size_t)N[7]];
+        has_light[i] = lx || ly;
+        if (lx && !ly && N[7] >= 0.0f) { std::swap(N[6], N[7]); swapped++; }
+    }
+    return swapped;
+}
+
 // Chain ("brute force") tree: fork i has the global bounds and children
 // (next fork, leaf i); the last fork holds the last two leaves.  The reference
 // traversal order (push x, push y, pop y first; raytrace.frag:299-307) then

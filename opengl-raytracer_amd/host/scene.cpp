@@ -189,6 +189,13 @@ void Scene::finalize() {
         } else {
             GLRT_FatalError("unknown BVH builder '%s' (sah | sah-gpu | lbvh | sah-levels-cpu | lbvh-cpu)", kind.c_str());
         }
+        // the light side first: at a fork where only one child holds emitting triangles that child is visited first (glrt_host.h: glrt_bvh_lights_first)
+        const char *lf = std::getenv("GLRT_BVH_LIGHTS_FIRST");
+        if (!(lf && lf[0] == '0' && lf[1] == 0) && !materials.empty()) {
+            const int sw = glrt_bvh_lights_first(&nodes[0].bboxMin[0], nodes.size(), t, triangles.size(), &materials[0].type[0], materials.size());
+            if (sw < 0) GLRT_FatalError("glrt_bvh_lights_first failed (%d)", sw);
+            if (sw > 0) GLRT_Info("BVH: the light side first at %d forks", sw);
+        }
     }
 }
 

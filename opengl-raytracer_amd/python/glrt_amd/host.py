@@ -30,6 +30,7 @@ def lib():
         L.glrt_bvh_build_lbvh.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_build_sah_levels.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_build_chain.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp]
+        L.glrt_bvh_lights_first.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t]
         L.glrt_look_at.argtypes = [fp, fp, fp, fp]
         L.glrt_perspective.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, fp]
         L.glrt_mat4_mul.argtypes = [fp, fp, fp]
@@ -69,6 +70,20 @@ def build_bvh(vert: np.ndarray, tri: np.ndarray, kind: str = "sah"):
     if rc != 0:
         raise RuntimeError(f"glrt_bvh_build_{kind} failed: {rc}")
     return nodes, depth.value
+
+
+def lights_first(nodes, tri, mat):
+    """glrt_bvh_lights_first on a copy of `nodes`: the child whose subtree holds the emitting triangles into the slot the traversal visits first, at every fork where
+    only one child has any.  Returns (nodes (nN*3, 3) float32, forks exchanged).  GLRT_BVH_LIGHTS_FIRST=0 in the environment returns the tree unchanged."""
+    import os
+    out = _f32(nodes).reshape(-1, 3).copy()
+    if os.environ.get("GLRT_BVH_LIGHTS_FIRST", "1") == "0":
+        return out, 0
+    tri, mat = _f32(tri).reshape(-1, 4), _f32(mat).reshape(-1, 18)
+    rc = lib().glrt_bvh_lights_first(_fp(out), out.shape[0] // 3, _fp(tri), tri.shape[0], _fp(mat), mat.shape[0])
+    if rc < 0:
+        raise RuntimeError(f"glrt_bvh_lights_first failed: {rc}")
+    return out, int(rc)
 
 
 def look_at(eye, center, up) -> np.ndarray:

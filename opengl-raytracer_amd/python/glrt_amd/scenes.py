@@ -134,14 +134,17 @@ class SceneBuilder:
         emissive = np.array([float(np.linalg.norm(np.asarray(m.get("emission", (0, 0, 0)), np.float64))) != 0.0
                              for m in self.materials])
         light = tri[emissive[mid.astype(np.int64)]]
-        nodes, depth = host.build_bvh(vert, tri, bvh)
+        built, depth = host.build_bvh(vert, tri, bvh)
+        # the light side first (host.lights_first: glrt_bvh_lights_first, as glrt::Scene::parse applies it); `bvh_builder` keeps the builder's own output
+        nodes, swapped = host.lights_first(built, tri, mat) if bvh != "chain" else (built, 0)
         return dict(vert=vert, tri=tri, mat=mat, light=np.ascontiguousarray(light.reshape(-1, 4)), bvh=nodes,
-                    bvh_depth=depth, bvh_kind=bvh)
+                    bvh_depth=depth, bvh_kind=bvh, bvh_builder=built, bvh_lights_first=swapped)
 
 
 def rebuild_bvh(scene, kind: str):
     s = dict(scene)
-    s["bvh"], s["bvh_depth"] = host.build_bvh(scene["vert"], scene["tri"], kind)
+    s["bvh_builder"], s["bvh_depth"] = host.build_bvh(scene["vert"], scene["tri"], kind)
+    s["bvh"], s["bvh_lights_first"] = host.lights_first(s["bvh_builder"], scene["tri"], scene["mat"]) if kind != "chain" else (s["bvh_builder"], 0)
     s["bvh_kind"] = kind
     return s
 

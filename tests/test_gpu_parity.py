@@ -622,7 +622,7 @@ def test_gpu_lbvh_equals_cpu_lbvh_bitwise(gpu_device, cfg, kw):
     CPU statement glrt_bvh_build_lbvh, and the same depth."""
     scene, _ = scenes.CONFIGS[cfg](width=16, height=16, bvh="lbvh", **kw)
     nodes, depth, ms = gpu_device.build_lbvh(scene["vert"], scene["tri"])
-    want = np.asarray(scene["bvh"], np.float32).reshape(-1, 3)
+    want = np.asarray(scene["bvh_builder"], np.float32).reshape(-1, 3)  # (the builder's own output: scene["bvh"] has the light side first)
     assert nodes.shape == want.shape and depth == scene["bvh_depth"]
     assert_bit_equal(nodes, want, f"{cfg} LBVH nodes")
     assert ms > 0.0
@@ -636,7 +636,7 @@ def test_gpu_sah_by_levels_equals_the_cpu_statement_bitwise(gpu_device, cfg, kw)
     statement glrt_bvh_build_sah_levels, and the same depth; sizes around the 64-leaf boundary included."""
     scene, _ = scenes.CONFIGS[cfg](width=16, height=16, bvh="sahl", **kw)
     nodes, depth, ms = gpu_device.build_bvh_sah(scene["vert"], scene["tri"])
-    want = np.asarray(scene["bvh"], np.float32).reshape(-1, 3)
+    want = np.asarray(scene["bvh_builder"], np.float32).reshape(-1, 3)  # (the builder's own output: scene["bvh"] has the light side first)
     assert nodes.shape == want.shape and depth == scene["bvh_depth"]
     assert_bit_equal(nodes, want, f"{cfg} SAH-by-levels nodes")
     assert ms > 0.0

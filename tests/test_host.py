@@ -462,3 +462,41 @@ def test_sah_by_levels_reaches_the_binned_sah_trees_cost():
     sc, _ = scenes.config_c5(16, 16, n=20_000)
     sahl, _ = host.build_bvh(sc["vert"], sc["tri"], "sahl")
     assert cost(sahl) <= 1.01 * cost(sc["bvh"])
+
+
+def test_lights_first_exchanges_child_references_only_and_is_what_the_scene_builder_hands_out():
+    """glrt_bvh_lights_first (round 5): at every fork where exactly one child's subtree holds emitting triangles, that child sits in the slot the reference's traversal
+    visits first (children.y); boxes, leaves and the set of parent-child links are untouched; applying it again changes nothing; the oracle's image under the ordered tree
+    is the image under the builder's tree (no exact ties in this scene); a chain (brute force) tree is left alone; GLRT_BVH_LIGHTS_FIRST=0 switches the pass off."""
+    from oracle import pt_oracle
+    for cfg, kw in (("c2", dict(width=48, height=32, subdiv=1)), ("c1", dict(width=48, height=32, subdiv=1)), ("c5", dict(width=32, height=24, n=3000))):
+        sc, pr = scenes.CONFIGS[cfg](**kw)
+        raw = np.asarray(sc["bvh_builder"], np.float32).reshape(-1, 9)
+        got = np.asarray(sc["bvh"], np.float32).reshape(-1, 9)
+        assert np.array_equal(raw[:, :6].view(np.uint32), got[:, :6].view(np.uint32)) and np.array_equal(raw[:, 8], got[:, 8])
+        assert np.array_equal(np.sort(raw[:, 6:8], 1), np.sort(got[:, 6:8], 1))
+        emits = np.linalg.norm(np.asarray(sc["mat"], np.float32).reshape(-1, 6, 3)[:, 1], axis=1) != 0
+        tri_light = emits[np.asarray(sc["tri"], np.float32).reshape(-1, 4)[:, 3].astype(int)]
+        has = np.zeros(got.shape[0], bool)
+        order, st = [], [0]
+        while st:
+            i = st.pop(); order.append(i)
+            if got[i, 8] < 0: st += [int(got[i, 6]), int(got[i, 7])]
+        for i in reversed(order):
+            has[i] = tri_light[int(got[i, 8])] if got[i, 8] >= 0 else has[int(got[i, 6])] or has[int(got[i, 7])]
+        forks = [i for i in order if got[i, 8] < 0]
+        assert not any(has[int(got[i, 6])] and not has[int(got[i, 7])] for i in forks), "a fork still holds its only light side in the x slot"
+        assert sc["bvh_lights_first"] == int((raw[:, 6] != got[:, 6]).sum())
+        again, n2 = host.lights_first(sc["bvh"], sc["tri"], sc["mat"])
+        assert n2 == 0 and np.array_equal(np.asarray(again).view(np.uint32), np.asarray(sc["bvh"], np.float32).reshape(-1, 3).view(np.uint32))
+        a, ra = pt_oracle.render(sc, pr)
+        b, rb = pt_oracle.render(dict(sc, bvh=sc["bvh_builder"]), pr)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ra == rb
+    chain, _ = scenes.config_c3(8, 8, n=50, bvh="chain")
+    assert chain["bvh_lights_first"] == 0 and np.array_equal(np.asarray(chain["bvh"]), np.asarray(chain["bvh_builder"]))
+
+
+def test_lights_first_can_be_switched_off(monkeypatch):
+    monkeypatch.setenv("GLRT_BVH_LIGHTS_FIRST", "0")
+    sc, _ = scenes.config_c2(16, 16, subdiv=1)
+    assert sc["bvh_lights_first"] == 0 and np.array_equal(np.asarray(sc["bvh"]), np.asarray(sc["bvh_builder"]))
