@@ -153,7 +153,9 @@ int glrtx_build_lbvh(glrtx_ctx *ctx, const float *vert, size_t n_vert, const flo
 /* Binned SAH built on the device, level by level from the top (16 bins, 3 axes), with the exact sweep SAH of the LBVH pass for the subtrees of <= 64 triangles
  * (csrc/sahl.hip.h; round 5).  Same contract and node layout as glrtx_build_lbvh; identical, bit for bit, to glrt_bvh_build_sah_levels (glrt_host.h).  The tree is as good
  * as the CPU binned-SAH builder's -- config 5 takes 80.5 instead of the LBVH's 84.4 traversal steps per ray (profiles/r05_tree_study.txt) -- for about twice the LBVH's
- * build time.  Replaces BVH::construct (src/core/bvh.cpp:59-160) like glrtx_build_lbvh does. */
+ * build time.  Replaces BVH::construct (src/core/bvh.cpp:59-160) like glrtx_build_lbvh does.
+ * Neither device builder knows the materials: glrt_bvh_lights_first (glrt_host.h) on the returned nodes puts the child that holds the emitting triangles into the slot the
+ * reference's traversal visits first -- worth 4 % per frame on the headline scene (profiles/r05_lights_first.txt); glrtx_upload_scene itself never reorders a tree. */
 int glrtx_build_bvh_sah(glrtx_ctx *ctx, const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
                      int *max_depth_out, float *build_ms_out);
 
