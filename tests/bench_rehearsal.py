@@ -57,11 +57,23 @@ class OracleRenderer:
 
     def render_full_reference(self, f0, n, seed_of, per_launch=16):
         import torch
+        if os.environ.get("GLRT_REHEARSAL_FAIL_RANK0") == "2":
+            raise RuntimeError("rehearsal: the one-rank reference render failed on purpose")
         W, H = self.params["width"], self.params["height"]
         full = np.zeros((H, W, 4), np.float32)
         for f in range(f0, f0 + n):
             self.o.render(self.scene, dict(self.params, seed=seed_of(f)), accum=full, threads=1)
         return torch.from_numpy(full)
+
+    def time_one_rank(self, f0, n, seed_of, per_launch):
+        """The strong-scaling denominator bench.py measures on rank 0 alone while the other ranks wait (GpuRenderer.time_one_rank).  GLRT_REHEARSAL_FAIL_RANK0=1 makes it
+        raise: the run must still finish (rank 0 must reach the barrier the others wait in) and say so in scaling_strong.error."""
+        import time
+        if os.environ.get("GLRT_REHEARSAL_FAIL_RANK0"):
+            raise RuntimeError("rehearsal: the one-GPU denominator failed on purpose")
+        t = time.perf_counter()
+        self.render_full_reference(f0, n, seed_of)
+        return time.perf_counter() - t
 
     def cleared(self):
         self.full[:] = 0.0  # bench.py zeroed `accum` without a reset_stats behind it

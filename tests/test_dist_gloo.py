@@ -82,12 +82,13 @@ def test_bench_self_spawns_its_ranks_and_gathers_to_root(tmp_path):
     assert out["config"]["predicted"] is None and "bit-identical" in out["config"]["timed_kernel_image_check"]
     assert out["roofline"]["traffic_measured_in_run"] is False and out["roofline_aux"] is None
     # round 5: the line explains itself: the ranks the process group reports, per-rank kernel / collective times, the strong figure at the top level
-    # (its own one-GPU denominator needs a device renderer: None in this CPU rehearsal)
+    # with its own one-GPU denominator, measured on rank 0 alone while rank 1 waits (the rehearsal renderer times its oracle-backed full render)
     cfg = out["config"]
     assert cfg["rccl_ranks_seen"] == 2 and cfg["backend_seen"] == "gloo" and cfg["gathers_in_timed_region"] == 1
     assert [r["rank"] for r in cfg["per_rank"]] == [0, 1] and all(r["gather_ms"] > 0 for r in cfg["per_rank"])
     ss = out["scaling_strong"]
-    assert ss["value"] == strong["value"] and ss["ms_per_frame"] == strong["ms_per_frame"] and ss["n1_same_run"] is None and ss["speedup_vs_n1_predicted"] is None
+    assert ss["value"] == strong["value"] and ss["ms_per_frame"] == strong["ms_per_frame"] and ss["error"] is None
+    assert ss["n1_same_run"]["ms_per_frame"] > 0 and abs(ss["speedup_vs_n1_predicted"] - ss["n1_same_run"]["ms_per_frame"] / ss["ms_per_frame"]) < 2e-3
     # the counting pass, its replay by the timed kernel (image check), the warm-up, the timed region, and the strong-scaling region
     # (one warm launch, then `steps` FRAMES in launches of `spl` frames in total) cover these frames, in this order, on every rank
     timed = list(range(warm * 2, (warm + steps) * 2))
@@ -201,3 +202,24 @@ def test_row_gather_index_matches_owned_rows():
         for r in range(world):
             ys = dist.owned_rows(r, world, stripe, h)
             assert np.array_equal(src[ys], r * pad + np.arange(len(ys)))
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_bench_rank0_only_failures_do_not_leave_the_other_ranks_waiting(tmp_path, mode):
+    """Round 5 added work that rank 0 does ALONE while the other ranks wait at a barrier (the one-GPU denominator of scaling_strong; before it, the one-rank reference render
+    of the gather check).  If that work raises, rank 0 must still reach the barrier -- a missed one shifts every later collective and the first real multi-GPU run would hang.
+    Mode 1: the denominator raises; mode 2: the reference render raises as well.  The run finishes, the contract line is printed, the failures are named in it."""
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GLRT_REHEARSAL_OUT=str(tmp_path), OMP_NUM_THREADS="1", GLRT_REHEARSAL_FAIL_RANK0=mode)
+    r = subprocess.run([sys.executable, str(root / "tests" / "bench_rehearsal.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--steps-per-launch", "2",
+                        "--config", "rehearsal", "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    ss = out["scaling_strong"]
+    assert ss["n1_same_run"] is None and ss["speedup_vs_n1_predicted"] is None and "on purpose" in ss["error"]
+    if mode == "2":
+        assert out["config"]["gather_check"].startswith("error:") and "on purpose" in out["config"]["gather_check"]
+    else:
+        assert out["config"]["gather_check"] == "bit-identical"
