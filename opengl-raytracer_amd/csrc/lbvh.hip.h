@@ -342,11 +342,15 @@ struct ExplicitSubtrees {
     int n;
 };
 template <bool EXPLICIT>
-__global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, int *parent, const int *roots, const int *n_roots, ExplicitSubtrees ex) {
-    const int n_int = n - 1, lane = (int)threadIdx.x;
-    __shared__ int q[2 * kRebuildLeaves], qn, slots[kRebuildLeaves], leaves[kRebuildLeaves], sorted_item[kRebuildLeaves], ord[kRebuildLeaves];
-    __shared__ int ref_l[kRebuildLeaves], ref_r[kRebuildLeaves], split_k[kRebuildLeaves];
-    __shared__ float box[kRebuildLeaves][6], cen[kRebuildLeaves][3], cost_l[kRebuildLeaves], key_l[kRebuildLeaves];
+__global__ __launch_bounds__(192) void k_rebuild_subtrees(int n, float *nodes, int *parent, const int *roots, const int *n_roots, ExplicitSubtrees ex) {
+    // Three waves per subtree, one per axis: each keeps the same per-lane state (segment, slot, leaf) and sweeps its own axis; the
+    // three candidates meet in LDS and every wave takes the same decision in axis order.  A subtree is a chain of dependent steps
+    // with two or three subtrees per SIMD at 100 k triangles, so the kernel's time IS that chain: three waves cut it to a third.
+    const int n_int = n - 1, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int q[2 * kRebuildLeaves], qn, slots[kRebuildLeaves], leaves[kRebuildLeaves], ord[kRebuildLeaves];
+    __shared__ int ref_l[kRebuildLeaves], ref_r[kRebuildLeaves], side[kRebuildLeaves], moved[3][kRebuildLeaves];
+    __shared__ float box[kRebuildLeaves][6], cen[kRebuildLeaves][3], r_cost[3][kRebuildLeaves];
+    __shared__ int r_k[3][kRebuildLeaves], r_imb[3][kRebuildLeaves];
   const int n_sub = EXPLICIT ? ex.n : *n_roots;
   for (int ri = (int)blockIdx.x; ri < n_sub; ri += (int)gridDim.x) {
     const int r = EXPLICIT ? ex.root[ri] : roots[ri];
@@ -355,17 +359,17 @@ __global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, in
     if (EXPLICIT) {
         m = ex.count[ri];
         total = 2 * m - 1;
-        if (lane < m) leaves[lane] = n_int + ex.members[ex.member_off[ri] + lane];
-        if (lane < m - 2) slots[lane] = ex.extra_base[ri] + lane;
+        if (tid < m) leaves[tid] = n_int + ex.members[ex.member_off[ri] + tid];
+        if (tid < m - 2) slots[tid] = ex.extra_base[ri] + tid;
     } else {
     // ---- gather the subtree's nodes (breadth-first), then its internal slots (without r) and leaves in ascending index order
-    if (lane == 0) { q[0] = r; qn = 1; }
+    if (tid == 0) { q[0] = r; qn = 1; }
     __syncthreads();
     for (int head = 0;;) {
         const int end = qn;
         __syncthreads();  // everyone has read the count before anyone appends
         if (head >= end) break;
-        for (int i = head + lane; i < end; i += 64) {
+        for (int i = head + tid; i < end; i += 192) {
             const int v = q[i];
             if (v < n_int) {
                 const int at = atomicAdd(&qn, 2);
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, in
         __syncthreads();
     }
     total = qn; m = (total + 1) / 2;  // m leaves, m - 1 internal nodes
-    for (int i = lane; i < total; i += 64) {
+    for (int i = tid; i < total; i += 192) {
         const int v = q[i];
         if (v == r) continue;
         const bool is_leaf = v >= n_int;
@@ -391,46 +395,43 @@ __global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, in
     }
     }
     __syncthreads();
-    int item = lane;  // the leaf (rank in `leaves`) at this lane's position
-    if (lane < m) {
+    if (tid < m) {
         const float *L = nodes + 9 * (size_t)leaves[lane];
         for (int k = 0; k < 6; k++) box[lane][k] = L[k] + 0.0f;
         for (int k = 0; k < 3; k++) cen[lane][k] = centre(L[k], L[3 + k]);
-        ord[lane] = lane;
     }
     __syncthreads();
     int a = 0, b = lane < m ? m : 0, slot = r;  // this lane's segment [a, b) and the node slot it is building; b - a < 2: nothing to do
     if (lane >= m) { a = lane; b = lane; }
+    // This wave's order: the leaves (ranks in `leaves`) sorted by (centre on the wave's axis, leaf rank), sorted ONCE by a bitonic network over the wave -- idle lanes
+    // carry a key above every leaf's and stay where they are; leaf ranks are distinct, so the result is THE sorted order.  A segment's members stay in the segment's
+    // lanes on every axis; a split moves them by a stable partition (below), which keeps each side sorted.
+    const int axis = wv;
+    int item = lane;
+    {
+        int s_idle = lane < m ? 0 : 1 + lane;
+        float s_key = lane < m ? cen[lane][axis] : 0.f;
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+            for (int jj = kk >> 1; jj >= 1; jj >>= 1) {
+                const int o_idle = __shfl_xor(s_idle, jj), o_item = __shfl_xor(item, jj);
+                const float o_key = __shfl_xor(s_key, jj);
+                const bool o_less = o_idle < s_idle || (o_idle == s_idle && (o_key < s_key || (o_key == s_key && o_item < item)));
+                const bool want_less = ((lane & jj) == 0) == ((lane & kk) == 0);  // this lane keeps the smaller of the pair
+                if (o_less == want_less) { s_idle = o_idle; s_key = o_key; item = o_item; }
+            }
+        }
+    }
     int next_slot = 0;
     for (int level = 0;; level++) {
         const bool busy = b - a >= 2;
         if (!__any(busy)) break;
-        int longest = busy ? b - a : 0;
-        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(longest, d); longest = o > longest ? o : longest; }
-        float best = __builtin_inff();
-        int best_k = 1, best_item = item, best_imb = b - a;
         float all_lo[3] = {0.f, 0.f, 0.f}, all_hi[3] = {0.f, 0.f, 0.f};
-        for (int axis = 0; axis < 3; axis++) {
-            // rank inside the segment by (centre, leaf rank); keys by POSITION, so that the loop's reads do not depend on one another
-            const float key = lane < m ? cen[item][axis] : 0.f;
-            key_l[lane] = key;
-            __syncthreads();
-            int rank = a;
-            if (busy) {
-#pragma unroll 4
-                for (int j = 0; j < longest; j++) {
-                    const int qq = a + j < b ? a + j : lane;  // (own entry: adds nothing)
-                    const float c = key_l[qq];
-                    const int it = ord[qq];
-                    rank += (c < key || (c == key && it < item)) ? 1 : 0;
-                }
-                sorted_item[rank] = item;
-            }
-            __syncthreads();
-            const int s_item = busy ? sorted_item[lane] : item;
+        {
             // segmented inclusive prefix and suffix unions of the boxes in sorted order
             float plo[3], phi[3], slo[3], shi[3];
-            for (int k = 0; k < 3; k++) { plo[k] = slo[k] = busy ? box[s_item][k] : 0.f; phi[k] = shi[k] = busy ? box[s_item][3 + k] : 0.f; }
+            for (int k = 0; k < 3; k++) { plo[k] = slo[k] = busy ? box[item][k] : 0.f; phi[k] = shi[k] = busy ? box[item][3 + k] : 0.f; }
             for (int d = 1; d < 64; d <<= 1) {
                 for (int k = 0; k < 3; k++) {
                     const float ul = __shfl_up(plo[k], d), uh = __shfl_up(phi[k], d), dl = __shfl_down(slo[k], d), dh = __shfl_down(shi[k], d);
@@ -445,42 +446,48 @@ __global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, in
                 for (int k = 0; k < 3; k++) { ql[k] = __shfl_up(plo[k], 1); qh[k] = __shfl_up(phi[k], 1); }
                 if (busy && lane > a) cost = half_area9(ql, qh) * (float)(lane - a) + half_area9(slo, shi) * (float)(b - lane);
             }
-            if (axis == 0 && lane == a) for (int k = 0; k < 3; k++) { all_lo[k] = slo[k]; all_hi[k] = shi[k]; }
-            cost_l[lane] = cost;
-            __syncthreads();
-            if (busy) {  // the segment's best split on this axis: lowest cost, then most balanced, then first
-                float bc = __builtin_inff();
-                int bk = 1, bi = b - a;
-                bool found = false;
-#pragma unroll 4
-                for (int j = 1; j < longest; j++)
-                    if (a + j < b) {
-                        const float c = cost_l[a + j];
-                        const int imb = abs(2 * j - (b - a));
-                        if (level < kRebuildSahLevels && (c < bc || (c == bc && imb < bi))) { bc = c; bk = j; bi = imb; found = true; }
-                    }
-                // (the first axis' order is taken even if no split qualifies: non-finite boxes, or past the SAH levels; as the CPU statement does)
-                if (found && (bc < best || (bc == best && bi < best_imb))) { best = bc; best_k = bk; best_imb = bi; best_item = s_item; }
-                else if (axis == 0) best_item = s_item;
+            if (lane == a) for (int k = 0; k < 3; k++) { all_lo[k] = slo[k]; all_hi[k] = shi[k]; }  // (the same box on every axis; wave 0 writes it)
+            // the segment's best split on this axis: lowest cost, then most balanced, then first -- a suffix minimum over the
+            // segment's lanes by shuffles, read back from the segment's first lane.  A NaN cost never qualifies (as `c < bc` is
+            // false for it in the CPU statement's loop); an infinite one does, on the balance rule.
+            const bool cand = busy && lane > a && level < kRebuildSahLevels && cost == cost;
+            float bc = cand ? cost : __builtin_inff();
+            int bi = cand ? abs(2 * (lane - a) - (b - a)) : 0x7fffffff, bk = cand ? lane - a : 0x7fffffff;  // (bk < 0x7fffffff: a split qualified)
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float oc = __shfl_down(bc, d);
+                const int oi = __shfl_down(bi, d), ok = __shfl_down(bk, d);
+                if (busy && lane + d < b && ok != 0x7fffffff &&
+                    (bk == 0x7fffffff || oc < bc || (oc == bc && (oi < bi || (oi == bi && ok < bk))))) { bc = oc; bi = oi; bk = ok; }
             }
-            __syncthreads();
+            r_cost[axis][lane] = __shfl(bc, a); r_imb[axis][lane] = __shfl(bi, a); r_k[axis][lane] = __shfl(bk, a);
         }
-        // the winning axis' order becomes the order; children, slots, node record
-        item = best_item;
+        __syncthreads();
+        // every wave takes the same decision: the axes in order; the first axis' order is taken even if no split qualifies (non-finite boxes, or past the SAH
+        // levels; as the CPU statement does)
+        float best = __builtin_inff();
+        int best_k = 1, best_axis = 0, best_imb = b - a;
+        if (busy)
+            for (int ax = 0; ax < 3; ax++) {
+                const float bc = r_cost[ax][lane];
+                const int bk = r_k[ax][lane], bi = r_imb[ax][lane];
+                if (bk != 0x7fffffff && (bc < best || (bc == best && bi < best_imb))) { best = bc; best_k = bk; best_imb = bi; best_axis = ax; }
+            }
         if (level >= kRebuildSahLevels) best_k = (b - a) / 2;
-        if (lane < m) ord[lane] = item;
+        // the winning axis' order is the segment's order: its wave publishes it, and which side each leaf goes to
+        if (busy && best_axis == axis) { ord[lane] = item; side[item] = lane < a + best_k ? 1 : 0; }
         const bool leader = busy && lane == a;
         const int n_l = best_k, n_r = (b - a) - best_k;
         const int need = leader ? (n_l >= 2 ? 1 : 0) + (n_r >= 2 ? 1 : 0) : 0;
         int incl = need;
         for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
         const int level_total = __shfl(incl, 63);
-        __syncthreads();  // ord complete
-        if (leader) {
+        __syncthreads();  // ord, side complete
+        if (leader && wv == 0) {
             const int at = next_slot + incl - need;
             const int rl = n_l >= 2 ? slots[at] : leaves[ord[a]];
             const int rr = n_r >= 2 ? slots[at + (n_l >= 2 ? 1 : 0)] : leaves[ord[b - 1]];
-            ref_l[a] = rl; ref_r[a] = rr; split_k[a] = best_k;
+            ref_l[a] = rl; ref_r[a] = rr;
             float *N = nodes + 9 * (size_t)slot;
             for (int k = 0; k < 3; k++) { N[k] = all_lo[k]; N[3 + k] = all_hi[k]; }
             N[6] = (float)rl; N[7] = (float)rr; N[8] = -1.0f;
@@ -488,13 +495,20 @@ __global__ __launch_bounds__(64) void k_rebuild_subtrees(int n, float *nodes, in
             parent[rr] = slot;
         }
         next_slot += level_total;
-        __syncthreads();
-        if (busy) {
-            const int k = split_k[a];
-            if (lane < a + k) { slot = ref_l[a]; b = a + k; }
-            else { slot = ref_r[a]; a = a + k; }
+        // stable partition of this wave's order by side
+        {
+            const int left = busy ? side[item] : 0;
+            int cnt = left;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cnt, d); if (busy && lane - d >= a) cnt += o; }
+            const int before = cnt - left;  // left-going members in front of this one
+            if (busy) moved[axis][left ? a + before : a + best_k + (lane - a - before)] = item;
         }
         __syncthreads();
+        if (busy) {
+            item = moved[axis][lane];
+            if (lane < a + best_k) { slot = ref_l[a]; b = a + best_k; }
+            else { slot = ref_r[a]; a = a + best_k; }
+        }
     }
   }
 }
@@ -574,7 +588,7 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
         LBVH_TRY(hipMemsetAsync(n_roots, 0, sizeof(int), stream));
         hipLaunchKernelGGL(k_subtree_count, grid, block, 0, stream, (int)n, d_nodes, parent, count);
         hipLaunchKernelGGL(k_subtree_roots, grid, block, 0, stream, (int)n, parent, count, roots, n_roots);
-        hipLaunchKernelGGL(k_rebuild_subtrees<false>, dim3(std::min<unsigned>(n - 1, 8192u)), dim3(64), 0, stream, (int)n, d_nodes, parent, (const int *)roots, (const int *)n_roots, ExplicitSubtrees{});
+        hipLaunchKernelGGL(k_rebuild_subtrees<false>, dim3(std::min<unsigned>(n - 1, 8192u)), dim3(192), 0, stream, (int)n, d_nodes, parent, (const int *)roots, (const int *)n_roots, ExplicitSubtrees{});
         LBVH_TRY(hipMemsetAsync(max_depth, 0, sizeof(int), stream));
         hipLaunchKernelGGL(k_max_depth, grid, block, 0, stream, (int)n, parent, max_depth);
         LBVH_TRY(hipGetLastError());

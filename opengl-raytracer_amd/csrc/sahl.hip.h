@@ -57,13 +57,16 @@ __global__ __launch_bounds__(256) void k_init(int n, int *seg, int *closed_of, i
 // member of the scene -- the words then lie in different cache lines (atomics on one line serialise at ~90 per microsecond: with the words of a segment side by side
 // the root level alone took 0.4 ms), and a thread per segment reads them coalesced.
 // cb: 8 words -- [0..2] min / [3..5] max of the members' centres (ordered keys), [6] min / [7] max position
+__device__ __forceinline__ void seg_tables_init(int S, int stride, unsigned *cb, unsigned *bins, long long first, long long step) {
+    for (long long i = first; i < (long long)S * kBinWords; i += step) {
+        const int w = (int)(i / S), s = (int)(i - (long long)w * S);
+        if (w < 8) cb[(size_t)w * stride + s] = (w < 3 || w == 6) ? 0xFFFFFFFFu : 0u;
+        bins[(size_t)w * stride + s] = w < 64 ? 0u : (((w - 64) % 6) < 3 ? 0xFFFFFFFFu : 0u);
+    }
+}
+// the tables of the first level (the later levels' are initialised by the level before them: k_seg_partition)
 __global__ __launch_bounds__(256) void k_seg_init(const int *S_ptr, int stride, unsigned *cb, unsigned *bins) {
-    const int S = *S_ptr;  // (the launch covers the tables' capacity: the level's segment count is only known on the device)
-    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
-    if (i >= S * kBinWords) return;
-    const int w = i / S, s = i - w * S;
-    if (w < 8) cb[(size_t)w * stride + s] = (w < 3 || w == 6) ? 0xFFFFFFFFu : 0u;
-    bins[(size_t)w * stride + s] = w < 64 ? 0u : (((w - 64) % 6) < 3 ? 0xFFFFFFFFu : 0u);
+    seg_tables_init(*S_ptr, stride, cb, bins, (long long)(blockIdx.x * 256u + threadIdx.x), (long long)gridDim.x * 256);
 }
 // A block's 256 consecutive positions belong to a handful of segments (the members are in Morton order: one segment near the top of the tree, three to six once the
 // segments are down to a hundred members).  Each block therefore keeps up to kSlots segments' tables in LDS -- a thread claims a slot for its segment with a compare-and-swap
@@ -240,10 +243,30 @@ __global__ __launch_bounds__(64) void k_seg_split(const int *S_ptr, int stride, 
     need[s * 4 + 0] = nn; need[s * 4 + 1] = no; need[s * 4 + 2] = nc; need[s * 4 + 3] = 0;
 }
 
+// exclusive prefix sums over the 1024 per-thread partial sums of a one-workgroup scan, W columns at once: shuffles inside each of the 16 waves, then over the waves'
+// totals.  part[t][w]: in the thread's sum, out the sum of the threads before it + start[w]; returns the grand total + start[w] in total[w] (every thread).
+template <int W>
+__device__ __forceinline__ void block_exclusive_1024(int (*part)[W], int (*wave_tot)[W], const int *start, int *total) {
+    const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
+    int v[W], incl[W];
+    for (int w = 0; w < W; w++) { v[w] = part[t][w]; incl[w] = v[w]; }
+    for (int d = 1; d < 64; d <<= 1)
+        for (int w = 0; w < W; w++) { const int o = __shfl_up(incl[w], d); if (lane >= d) incl[w] += o; }
+    if (lane == 63) for (int w = 0; w < W; w++) wave_tot[wv][w] = incl[w];
+    __syncthreads();
+    for (int w = 0; w < W; w++) {
+        int before = start[w], all = start[w];
+        for (int i = 0; i < 16; i++) { const int x = wave_tot[i][w]; all += x; if (i < wv) before += x; }
+        part[t][w] = before + incl[w] - v[w];
+        total[w] = all;
+    }
+    __syncthreads();
+}
+
 // exclusive prefix sums of need[] (three interleaved columns) in segment order, ONE workgroup; the running totals continue the counters
 __global__ __launch_bounds__(1024) void k_seg_scan(const int *S_ptr, int *need, Counters *cnt, int *S_next, int *level_first_next) {
     const int S = *S_ptr;
-    __shared__ int part[1024][3], base[3];
+    __shared__ int part[1024][3], wave_tot[16][3];
     const int t = (int)threadIdx.x;
     const int per = (S + 1023) / 1024;
     const int a = t * per, b = a + per < S ? a + per : S;
@@ -251,17 +274,13 @@ __global__ __launch_bounds__(1024) void k_seg_scan(const int *S_ptr, int *need, 
     for (int s = a; s < b; s++)
         for (int w = 0; w < 3; w++) sum[w] += need[s * 4 + w];
     for (int w = 0; w < 3; w++) part[t][w] = sum[w];
-    __syncthreads();
-    if (t < 3) {  // (1024 additions per column: nothing next to the launch itself)
-        int run = t == 0 ? cnt->next_id : (t == 1 ? 0 : cnt->n_closed);
-        for (int i = 0; i < 1024; i++) { const int v = part[i][t]; part[i][t] = run; run += v; }
-        base[t] = run;
-    }
-    __syncthreads();
+    const int start[3] = {cnt->next_id, 0, cnt->n_closed};
+    int base[3];
+    __syncthreads();  // (the counters are read before thread 0 writes them below)
+    block_exclusive_1024<3>(part, wave_tot, start, base);
     int run[3] = {part[t][0], part[t][1], part[t][2]};
     for (int s = a; s < b; s++)
         for (int w = 0; w < 3; w++) { const int v = need[s * 4 + w]; need[s * 4 + w] = run[w]; run[w] += v; }
-    __syncthreads();
     if (t == 0) { cnt->next_id = base[0]; cnt->n_open_next = base[1]; cnt->n_closed = base[2]; *S_next = base[1]; *level_first_next = base[0]; }
 }
 
@@ -293,9 +312,11 @@ __global__ __launch_bounds__(64) void k_seg_assign(const int *S_ptr, int n, cons
 }
 
 // every member moves to its child (or becomes its parent's leaf child)
+// (and, nobody reading this level's tables any more, initialises them for the next level's segments: a launch saved per level)
 __global__ __launch_bounds__(256) void k_seg_partition(int n, const float *nodes_c, float *nodes, int *seg, int *closed_of, const int *open_node, const Split *split,
-                                                       const int *child_info, int *parent) {
+                                                       const int *child_info, int *parent, const int *S_next_ptr, int stride, unsigned *cb, unsigned *bins) {
     const int k = (int)(blockIdx.x * 256u + threadIdx.x);
+    seg_tables_init(*S_next_ptr, stride, cb, bins, (long long)k, (long long)gridDim.x * 256);
     if (k >= n) return;
     const int s = seg[k];
     if (s < 0) return;
@@ -321,21 +342,19 @@ __global__ __launch_bounds__(256) void k_seg_partition(int n, const float *nodes
     }
 }
 
-// closed subtrees: where their members start in the sorted list and where their inner nodes go; ONE workgroup (a sequential chunked scan like k_seg_scan)
+// closed subtrees: where their members start in the sorted list and where their inner nodes go; ONE workgroup (a chunked scan like k_seg_scan)
 __global__ __launch_bounds__(1024) void k_closed_scan(int C, const int *closed_count, int first_extra, int *member_off, int *extra_base) {
-    __shared__ int part[1024][2];
+    __shared__ int part[1024][2], wave_tot[16][2];
     const int t = (int)threadIdx.x;
     const int per = (C + 1023) / 1024;
     const int a = t * per, b = a + per < C ? a + per : C;
     int s0 = 0, s1 = 0;
     for (int j = a; j < b; j++) { s0 += closed_count[j]; s1 += closed_count[j] - 2; }
     part[t][0] = s0; part[t][1] = s1;
+    const int start[2] = {0, first_extra};
+    int total[2];
     __syncthreads();
-    if (t < 2) {
-        int run = t == 0 ? 0 : first_extra;
-        for (int i = 0; i < 1024; i++) { const int v = part[i][t]; part[i][t] = run; run += v; }
-    }
-    __syncthreads();
+    block_exclusive_1024<2>(part, wave_tot, start, total);
     int r0 = part[t][0], r1 = part[t][1];
     for (int j = a; j < b; j++) { member_off[j] = r0; extra_base[j] = r1; r0 += closed_count[j]; r1 += closed_count[j] - 2; }
 }
@@ -356,6 +375,23 @@ __global__ __launch_bounds__(256) void k_top_fit(int i0, int i1, float *nodes, c
     for (int w = 0; w < 3; w++) {
         N[w] = __builtin_fminf(A[w] + 0.0f, B[w] + 0.0f);
         N[3 + w] = __builtin_fmaxf(A[3 + w] + 0.0f, B[3 + w] + 0.0f);
+    }
+}
+// the same for the levels [0, L_top] in ONE workgroup, deepest first (a level near the root has a handful of nodes: a launch each was mostly launch)
+__global__ __launch_bounds__(1024) void k_top_fit_levels(int L_top, const int *level_first, float *nodes, const unsigned char *is_closed_root) {
+    for (int L = L_top; L >= 0; L--) {
+        const int i0 = level_first[L], i1 = level_first[L + 1];
+        for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) {
+            if (is_closed_root[i]) continue;
+            float *N = nodes + 9 * (size_t)i;
+            const float *A = nodes + 9 * (size_t)(int)N[6], *B = nodes + 9 * (size_t)(int)N[7];
+            for (int w = 0; w < 3; w++) {
+                N[w] = __builtin_fminf(A[w] + 0.0f, B[w] + 0.0f);
+                N[3 + w] = __builtin_fmaxf(A[3 + w] + 0.0f, B[3 + w] + 0.0f);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();  // the level's boxes are written before the level above reads them
     }
 }
 __global__ __launch_bounds__(256) void k_mark_closed(int C, const int *closed_root, unsigned char *is_closed_root) {
@@ -457,7 +493,7 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
             if (level >= kMaxLevels) return hipErrorUnknown;  // (cannot happen: from 40 levels on every split is by position and halves its segment)
             const int cur = level & 1;
             const int *Sp = S_of + level;
-            hipLaunchKernelGGL(k_seg_init, dim3((cap * (unsigned)kBinWords + 255u) / 256u), block, 0, stream, Sp, stride, cb, bins);
+            if (level == 0) hipLaunchKernelGGL(k_seg_init, grid, block, 0, stream, Sp, stride, cb, bins);
             hipLaunchKernelGGL(k_seg_bounds, grid, block, 0, stream, ni, stride, (const float *)d_nodes, (const int *)seg, cb);
             hipLaunchKernelGGL(k_seg_bin, grid, block, 0, stream, ni, stride, (const float *)d_nodes, (const int *)seg, (const unsigned *)cb, bins);
             hipLaunchKernelGGL(k_seg_split, dim3(cap), dim3(64), 0, stream, Sp, stride, level, (const int *)open_count[cur], (const unsigned *)cb, (const unsigned *)bins, split, need);
@@ -465,7 +501,7 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
             hipLaunchKernelGGL(k_seg_assign, dim3((cap + 63u) / 64u), dim3(64), 0, stream, Sp, ni, (const int *)open_node[cur], (const Split *)split, (const int *)need, d_nodes, parent,
                                open_node[cur ^ 1], open_count[cur ^ 1], closed_root, closed_count, child_info);
             hipLaunchKernelGGL(k_seg_partition, grid, block, 0, stream, ni, (const float *)d_nodes, d_nodes, seg, closed_of, (const int *)open_node[cur], (const Split *)split,
-                               (const int *)child_info, parent);
+                               (const int *)child_info, parent, (const int *)(S_of + level + 1), stride, cb, bins);
             SAHL_TRY(hipGetLastError());
             if (level + 1 >= look) {
                 int open_next = 0;
@@ -491,12 +527,22 @@ inline hipError_t build(hipStream_t stream, const float *d_vert, unsigned n_vert
         SAHL_TRY(hipMemsetAsync(is_closed_root, 0, n_nodes, stream));
         hipLaunchKernelGGL(k_mark_closed, dim3((C + 255) / 256), block, 0, stream, C, (const int *)closed_root, is_closed_root);
         lbvh::ExplicitSubtrees ex{closed_root, closed_count, member_off, extra_base, (const int *)val_out, C};
-        hipLaunchKernelGGL(lbvh::k_rebuild_subtrees<true>, dim3((unsigned)std::min(C, 8192)), dim3(64), 0, stream, ni, d_nodes, parent, (const int *)nullptr, (const int *)nullptr, ex);
+        hipLaunchKernelGGL(lbvh::k_rebuild_subtrees<true>, dim3((unsigned)std::min(C, 8192)), dim3(192), 0, stream, ni, d_nodes, parent, (const int *)nullptr, (const int *)nullptr, ex);
         SAHL_TRY(hipGetLastError());
     }
-    for (int L = (int)level_first.size() - 2; L >= 0; L--) {
-        const int i0 = level_first[(size_t)L], i1 = level_first[(size_t)L + 1];
-        if (i1 > i0) hipLaunchKernelGGL(k_top_fit, dim3((unsigned)(i1 - i0 + 255) / 256), block, 0, stream, i0, i1, d_nodes, (const unsigned char *)is_closed_root);
+    // boxes above the closed subtrees, deepest level first: wide levels a launch each, then the narrow ones at the top (<= 4096 nodes each) in one workgroup
+    {
+        int L = (int)level_first.size() - 2;
+        for (; L >= 0; L--) {
+            const int i0 = level_first[(size_t)L], i1 = level_first[(size_t)L + 1];
+            if (i1 - i0 <= 4096) {
+                bool narrow_above = true;  // (levels only widen downwards in practice; if one above is wide after all, keep launching per level)
+                for (int M = L - 1; M >= 0; M--) narrow_above = narrow_above && level_first[(size_t)M + 1] - level_first[(size_t)M] <= 4096;
+                if (narrow_above) break;
+            }
+            if (i1 > i0) hipLaunchKernelGGL(k_top_fit, dim3((unsigned)(i1 - i0 + 255) / 256), block, 0, stream, i0, i1, d_nodes, (const unsigned char *)is_closed_root);
+        }
+        if (L >= 0) hipLaunchKernelGGL(k_top_fit_levels, dim3(1), dim3(1024), 0, stream, L, (const int *)level_first_dev, d_nodes, (const unsigned char *)is_closed_root);
     }
     SAHL_TRY(hipMemsetAsync(max_depth, 0, sizeof(int), stream));
     hipLaunchKernelGGL(lbvh::k_max_depth, grid, block, 0, stream, ni, (const int *)parent, max_depth);

@@ -870,6 +870,187 @@ int glrt_bvh_lights_first(float *nodes, size_t n_nodes, const float *tri, size_t
     return swapped;
 }
 
+// ---- Reinsertion, an optimisation pass over a finished tree (after Bittner, Hapala, Havran, "Fast insertion-based optimization of bounding volume hierarchies", CGF 2013,
+// in the per-node form of Meister & Bittner 2018).  A top-down SAH build decides every split once, greedily; afterwards each subtree N is taken out (its parent's slot P is
+// freed, the sibling moves up) and put back where the tree's summed box area grows least: a branch-and-bound search over all positions X, cost(X) = area(X u N) + the
+// growth of X's ancestors, candidates ordered by that growth, a branch abandoned once growth + area(N) cannot beat the best position found.  The old position is among
+// the candidates, so the sum of the forks' areas -- the expected number of box visits of a ray that culls nothing, which is what the reference's fixed-order traversal
+// does until its first hit -- never rises.  Passes repeat until one gains less than 0.1 %.  The children of every fork are then put in a top-down builder's order and the
+// result is renumbered in DFS pre-order (root = node 0, x child first).  Measured: config 5 -2.9 % per frame (its fork area: -2.9 %), config 4 -0.6 %, headline -0.1 %.
+// Closest-hit results do not depend on the tree (exact ties aside: SURVEY.md H4).
+// nodes: wire format, modified in place.  cost_out (may be NULL): [0] the summed fork area / root area before, [1] after.  Returns the number of subtrees that moved,
+// 0 for trees it leaves alone (fewer than 4 leaves, absent children, non-finite boxes), or a negative GLRT_HOST_E* code for a malformed tree.
+int glrt_bvh_reinsert(float *nodes, size_t n_nodes, int max_passes, int *max_depth_out, double *cost_out) {
+    if (!nodes || n_nodes == 0) return GLRT_HOST_EINVAL;
+    const int n = (int)n_nodes;
+    std::vector<int> parent((size_t)n, -1);
+    auto L = [&](int i) -> float * { return nodes + 9 * (size_t)i; };
+    auto is_fork = [&](int i) { return L(i)[8] < 0.0f; };
+    {
+        std::vector<char> seen((size_t)n, 0);
+        std::vector<int> st{0};
+        size_t met = 0;
+        bool leave = n < 7;
+        while (!st.empty()) {
+            const int i = st.back();
+            st.pop_back();
+            if (i < 0 || i >= n || seen[(size_t)i]) return GLRT_HOST_EINVAL;
+            seen[(size_t)i] = 1;
+            met++;
+            for (int k = 0; k < 6; k++)
+                if (!(L(i)[k] - L(i)[k] == 0.0f)) leave = true;
+            if (is_fork(i))
+                for (int k = 6; k <= 7; k++) {
+                    const float c = L(i)[k];
+                    if (c < 0.0f) { leave = true; continue; }
+                    if (!(c < (float)n)) return GLRT_HOST_EINVAL;
+                    parent[(size_t)c] = i;
+                    st.push_back((int)c);
+                }
+        }
+        if (met != (size_t)n) leave = true;  // (unreachable records: not ours to renumber)
+        if (leave) {
+            if (cost_out) cost_out[0] = cost_out[1] = 0.0;
+            if (max_depth_out) *max_depth_out = -1;
+            return 0;
+        }
+    }
+    auto area = [&](int i) -> double {
+        const float *b = L(i);
+        const double dx = (double)b[3] - b[0], dy = (double)b[4] - b[1], dz = (double)b[5] - b[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto union_area = [&](int x, const float *nb) -> double {
+        const float *b = L(x);
+        const double dx = (double)std::max(b[3], nb[3]) - std::min(b[0], nb[0]), dy = (double)std::max(b[4], nb[4]) - std::min(b[1], nb[1]),
+                     dz = (double)std::max(b[5], nb[5]) - std::min(b[2], nb[2]);
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto refit_up = [&](int i) {  // boxes of i and its ancestors from their children, until one does not change
+        for (; i >= 0; i = parent[(size_t)i]) {
+            float *b = L(i);
+            const float *p = L((int)b[6]), *q = L((int)b[7]);
+            bool changed = false;
+            for (int k = 0; k < 3; k++) {
+                const float lo = std::min(p[k], q[k]), hi = std::max(p[3 + k], q[3 + k]);
+                if (lo != b[k] || hi != b[3 + k]) changed = true;
+                b[k] = lo; b[3 + k] = hi;
+            }
+            if (!changed) break;
+        }
+    };
+    auto total_cost = [&]() {
+        double s = 0.0;
+        for (int i = 0; i < n; i++)
+            if (is_fork(i)) s += area(i);
+        return s / std::max(area(0), 1e-300);
+    };
+    const double cost0 = total_cost();
+    double cost_prev = cost0;
+    int moved_total = 0;
+    std::vector<int> order;
+    typedef std::pair<double, int> QE;
+    std::vector<QE> heap;
+    for (int pass = 0; pass < max_passes; pass++) {
+        order.clear();
+        for (int i = 1; i < n; i++) order.push_back(i);
+        std::vector<double> key((size_t)n);
+        for (int i = 0; i < n; i++) key[(size_t)i] = area(i);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key[(size_t)x] > key[(size_t)y]; });
+        int moved = 0;
+        for (const int N : order) {
+            const int P = parent[(size_t)N];
+            if (P <= 0) continue;  // (the root's children stay: the root keeps slot 0)
+            const int G = parent[(size_t)P];
+            const int S = (int)L(P)[6] == N ? (int)L(P)[7] : (int)L(P)[6];
+            // take N out: S takes P's place under G
+            L(G)[(int)L(G)[6] == P ? 6 : 7] = (float)S;
+            parent[(size_t)S] = G;
+            refit_up(G);
+            // the best place: X becomes the sibling of N under P
+            float nb[6];
+            for (int k = 0; k < 6; k++) nb[k] = L(N)[k];
+            const double an = area(N);
+            double best = std::numeric_limits<double>::infinity();
+            int best_x = S;
+            heap.clear();
+            const double root_growth = union_area(0, nb) - area(0);
+            heap.push_back(QE(-root_growth, (int)L(0)[6]));
+            heap.push_back(QE(-root_growth, (int)L(0)[7]));
+            std::make_heap(heap.begin(), heap.end());
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end());
+                const QE e = heap.back();
+                heap.pop_back();
+                const double induced = -e.first;
+                if (induced + an >= best) break;
+                const int X = e.second;
+                const double direct = union_area(X, nb);
+                if (induced + direct < best) { best = induced + direct; best_x = X; }
+                if (is_fork(X)) {
+                    const double below = induced + (direct - area(X));
+                    if (below + an < best) {
+                        heap.push_back(QE(-below, (int)L(X)[6])); std::push_heap(heap.begin(), heap.end());
+                        heap.push_back(QE(-below, (int)L(X)[7])); std::push_heap(heap.begin(), heap.end());
+                    }
+                }
+            }
+            const int X = best_x, XP = parent[(size_t)X];
+            L(XP)[(int)L(XP)[6] == X ? 6 : 7] = (float)P;
+            parent[(size_t)P] = XP;
+            L(P)[6] = (float)X; L(P)[7] = (float)N; L(P)[8] = -1.0f;
+            parent[(size_t)X] = P;
+            parent[(size_t)N] = P;
+            for (int k = 0; k < 3; k++) { L(P)[k] = std::min(L(X)[k], nb[k]); L(P)[3 + k] = std::max(L(X)[3 + k], nb[3 + k]); }
+            refit_up(XP);
+            if (X != S) moved++;
+        }
+        moved_total += moved;
+        const double c = total_cost();
+        const bool done = moved == 0 || c > cost_prev * 0.999;
+        cost_prev = c;
+        if (done) break;
+    }
+    // the children of every fork in the order a top-down builder leaves them (a reinserted pair is in no particular order, and the order is worth as much as the
+    // areas: profiles/r05_reinsert.txt): on the axis where the two boxes' centres differ most, the lower one is x
+    for (int i = 0; i < n; i++) {
+        if (!is_fork(i)) continue;
+        const float *X = L((int)L(i)[6]), *Y = L((int)L(i)[7]);
+        int k = 0;
+        float dmax = -1.0f, dk = 0.0f;
+        for (int a = 0; a < 3; a++) {
+            const float d = 0.5f * (X[a] + X[3 + a]) - 0.5f * (Y[a] + Y[3 + a]);
+            if (std::fabs(d) > dmax) { dmax = std::fabs(d); dk = d; k = a; }
+        }
+        (void)k;
+        if (dk > 0.0f) std::swap(L(i)[6], L(i)[7]);
+    }
+    // renumber: DFS pre-order, x child first
+    std::vector<float> out((size_t)n * 9);
+    std::vector<int> new_of((size_t)n, -1);
+    int next = 0, max_depth = 0;
+    std::vector<std::pair<int, int>> st{{0, 0}};
+    std::vector<int> old_of((size_t)n);
+    while (!st.empty()) {
+        const auto [i, d] = st.back();
+        st.pop_back();
+        new_of[(size_t)i] = next;
+        old_of[(size_t)next++] = i;
+        max_depth = std::max(max_depth, d);
+        if (is_fork(i)) { st.push_back({(int)L(i)[7], d + 1}); st.push_back({(int)L(i)[6], d + 1}); }
+    }
+    for (int j = 0; j < n; j++) {
+        const float *src = L(old_of[(size_t)j]);
+        float *dst = out.data() + 9 * (size_t)j;
+        std::memcpy(dst, src, 9 * sizeof(float));
+        if (src[8] < 0.0f) { dst[6] = (float)new_of[(size_t)src[6]]; dst[7] = (float)new_of[(size_t)src[7]]; }
+    }
+    std::memcpy(nodes, out.data(), out.size() * sizeof(float));
+    if (cost_out) { cost_out[0] = cost0; cost_out[1] = cost_prev; }
+    if (max_depth_out) *max_depth_out = max_depth;
+    return moved_total;
+}
+
 // Chain ("brute force") tree: fork i has the global bounds and children
 // (next fork, leaf i); the last fork holds the last two leaves.  The reference
 // traversal order (push x, push y, pop y first; raytrace.frag:299-307) then

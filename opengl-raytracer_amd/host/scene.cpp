@@ -166,17 +166,26 @@ void Scene::finalize() {
     if (nodes.empty() && !triangles.empty()) {
         // BVH::construct (scene.cpp:251-253 -> bvh.cpp:59-160).  Builders: "sah" (CPU, default), "sah-gpu" (binned SAH by levels + exact sweep below, built on the
         // GPU through glrtx_build_bvh_sah: the CPU SAH tree's quality in ~1.3 ms per 100 k triangles), "lbvh" (linear BVH
-        // built on the GPU through glrtx_build_lbvh: 20 % faster to build, ~3 % more traversal steps), "sah-levels-cpu" / "lbvh-cpu" (the same trees from the host library).
+        // built on the GPU through glrtx_build_lbvh: 20 % faster to build, ~3 % more traversal steps), "sah-levels-cpu" / "lbvh-cpu" (the same trees from the host library),
+        // "sah-reinsert" ("sah" + glrt_bvh_reinsert: config 5 renders 3 % faster, the build takes seconds).
         // Any of them renders the same image (only exact ties depend on tree shape).
         std::string kind = bvhBuilder_;
         if (const char *e = std::getenv("GLRT_BVH")) kind = e;
         nodes.resize(glrt_bvh_node_count(triangles.size()));
         const float *v = &vertices[0].pos[0], *t = &triangles[0].indices[0];
-        if (kind == "sah" || kind == "lbvh-cpu" || kind == "sah-levels-cpu") {
-            const int rc = kind == "sah" ? glrt_bvh_build_sah(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_)
+        if (kind == "sah" || kind == "sah-reinsert" || kind == "lbvh-cpu" || kind == "sah-levels-cpu") {
+            const int rc = kind == "sah" || kind == "sah-reinsert" ? glrt_bvh_build_sah(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_)
                          : kind == "lbvh-cpu" ? glrt_bvh_build_lbvh(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_)
                                               : glrt_bvh_build_sah_levels(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_);
             if (rc != GLRT_HOST_OK) GLRT_FatalError("BVH construction (%s) failed (%d)", kind.c_str(), rc);
+            if (kind == "sah-reinsert") {  // insertion-based optimisation of the finished tree (glrt_host.h: glrt_bvh_reinsert): ~3 % fewer box visits on config 5, seconds of CPU
+                double cost[2] = {0.0, 0.0};
+                int depth = -1;
+                const int moved = glrt_bvh_reinsert(&nodes[0].bboxMin[0], nodes.size(), 8, &depth, cost);
+                if (moved < 0) GLRT_FatalError("glrt_bvh_reinsert failed (%d)", moved);
+                if (depth >= 0) bvhDepth_ = depth;
+                GLRT_Info("BVH: %d subtrees reinserted, summed fork area %.2f -> %.2f root areas (depth %d)", moved, cost[0], cost[1], bvhDepth_);
+            }
         } else if (kind == "lbvh" || kind == "sah-gpu") {
             glrtx_ctx *ctx = nullptr;
             if (glrtx_create(&ctx, -1) != GLRTX_OK) GLRT_FatalError("GPU BVH builder: %s", glrtx_last_error(nullptr));
@@ -187,7 +196,7 @@ void Scene::finalize() {
             GLRT_Info("%s over %zu triangles built on the GPU in %.3f ms (depth %d)", kind == "lbvh" ? "LBVH" : "SAH tree", triangles.size(), ms, bvhDepth_);
             glrtx_destroy(ctx);
         } else {
-            GLRT_FatalError("unknown BVH builder '%s' (sah | sah-gpu | lbvh | sah-levels-cpu | lbvh-cpu)", kind.c_str());
+            GLRT_FatalError("unknown BVH builder '%s' (sah | sah-reinsert | sah-gpu | lbvh | sah-levels-cpu | lbvh-cpu)", kind.c_str());
         }
         // the light side first: at a fork where only one child holds emitting triangles that child is visited first (glrt_host.h: glrt_bvh_lights_first)
         const char *lf = std::getenv("GLRT_BVH_LIGHTS_FIRST");

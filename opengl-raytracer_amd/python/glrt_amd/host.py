@@ -31,6 +31,7 @@ def lib():
         L.glrt_bvh_build_sah_levels.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_build_chain.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp]
         L.glrt_bvh_lights_first.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t]
+        L.glrt_bvh_reinsert.argtypes = [fp, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.glrt_look_at.argtypes = [fp, fp, fp, fp]
         L.glrt_perspective.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, fp]
         L.glrt_mat4_mul.argtypes = [fp, fp, fp]
@@ -56,6 +57,10 @@ def build_bvh(vert: np.ndarray, tri: np.ndarray, kind: str = "sah"):
     n = int(L.glrt_bvh_node_count(tri.shape[0]))
     nodes = np.zeros((n * 3, 3), np.float32)
     depth = C.c_int(0)
+    if kind == "sah-reinsert":  # "sah" + the insertion-based optimisation pass (as glrt::Scene::parse's builder of that name)
+        nodes, depth = build_bvh(vert, tri, "sah")
+        out, d2, _, _ = reinsert(nodes)
+        return out, (d2 if d2 >= 0 else depth)
     if kind == "sah":
         rc = L.glrt_bvh_build_sah(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
     elif kind == "lbvh":
@@ -84,6 +89,18 @@ def lights_first(nodes, tri, mat):
     if rc < 0:
         raise RuntimeError(f"glrt_bvh_lights_first failed: {rc}")
     return out, int(rc)
+
+
+def reinsert(nodes, max_passes: int = 8):
+    """glrt_bvh_reinsert on a copy of `nodes`: insertion-based optimisation of a finished tree.  Returns (nodes (nN*3, 3) float32, max depth (-1: left alone),
+    subtrees moved, (cost before, cost after)) -- cost = summed area of the forks' boxes / the root's."""
+    out = _f32(nodes).reshape(-1, 3).copy()
+    depth = C.c_int(0)
+    cost = (C.c_double * 2)()
+    rc = lib().glrt_bvh_reinsert(_fp(out), out.shape[0] // 3, int(max_passes), C.byref(depth), cost)
+    if rc < 0:
+        raise RuntimeError(f"glrt_bvh_reinsert failed: {rc}")
+    return out, depth.value, int(rc), (cost[0], cost[1])
 
 
 def look_at(eye, center, up) -> np.ndarray:

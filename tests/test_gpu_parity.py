@@ -686,6 +686,21 @@ def test_render_with_the_device_built_sah_tree_matches_the_oracle(gpu_device):
     assert_bit_equal(acc, ref_sah, "SAH-by-levels image vs SAH image")
 
 
+@pytest.mark.parametrize("cfg,kw", [("c5", dict(width=160, height=90, max_depth=4)), ("c2", dict(width=128, height=72))])
+def test_render_with_the_reinserted_tree_matches_the_oracle(gpu_device, cfg, kw):
+    """The "sah-reinsert" builder (CPU SAH + glrt_bvh_reinsert + lights first): image and ray count equal the oracle's on that tree, and the image equals the builder
+    tree's (these scenes have no exact ties)."""
+    from oracle import pt_oracle
+    scene, params = scenes.CONFIGS[cfg](**kw)
+    sr = scenes.rebuild_bvh(scene, "sah-reinsert")
+    assert not np.array_equal(np.asarray(sr["bvh"]), np.asarray(scene["bvh"]))
+    acc, st = gpu_render(gpu_device, sr, params)
+    ref, ref_rays = pt_oracle.render(sr, params)
+    assert st.rays == ref_rays
+    assert_bit_equal(acc, ref, f"{cfg} with the reinserted tree")
+    assert_bit_equal(acc, pt_oracle.render(scene, params)[0], "reinserted-tree image vs builder-tree image")
+
+
 def test_gpu_lbvh_many_equal_centres_and_bad_index(gpu_device):
     sc, _ = scenes.config_c3(8, 8, n=3, bvh="sah")
     v = np.tile(sc["vert"].reshape(-1, 5, 3)[:3], (500, 1, 1)).reshape(-1, 3)          # 500 identical triangles

@@ -496,6 +496,76 @@ def test_lights_first_exchanges_child_references_only_and_is_what_the_scene_buil
     assert chain["bvh_lights_first"] == 0 and np.array_equal(np.asarray(chain["bvh"]), np.asarray(chain["bvh_builder"]))
 
 
+def _tree_facts(nodes):
+    """(fork area sum / root area, depth, sorted leaf triangles, every child's box inside its parent's, node count reached from the root)"""
+    N = np.asarray(nodes, np.float32).reshape(-1, 9)
+    def area(i):
+        d = N[i, 3:6].astype(np.float64) - N[i, :3]
+        return d[0] * d[1] + d[1] * d[2] + d[2] * d[0]
+    total, depth, leaves, nested, seen = 0.0, 0, [], True, 0
+    st = [(0, 0)]
+    while st:
+        i, d = st.pop(); seen += 1; depth = max(depth, d)
+        if N[i, 8] >= 0:
+            leaves.append(int(N[i, 8])); continue
+        total += area(i)
+        for c in (int(N[i, 6]), int(N[i, 7])):
+            nested &= bool((N[c, :3] >= N[i, :3]).all() and (N[c, 3:6] <= N[i, 3:6]).all())
+            st.append((c, d + 1))
+        lo, hi = np.minimum(N[int(N[i, 6]), :3], N[int(N[i, 7]), :3]), np.maximum(N[int(N[i, 6]), 3:6], N[int(N[i, 7]), 3:6])
+        nested &= bool(np.array_equal(lo, N[i, :3]) and np.array_equal(hi, N[i, 3:6]))  # (tight: the union of the children)
+    return total / area(0), depth, sorted(leaves), nested, seen
+
+
+def test_reinsertion_keeps_a_valid_tight_tree_and_never_raises_the_fork_area():
+    """glrt_bvh_reinsert (round 5): every triangle still in exactly one leaf, every fork's box the union of its children's, root = node 0 in DFS pre-order, the summed
+    fork area (what it reports) not above the builder's and what this test measures itself; a second run finds little left; the oracle renders the same image through
+    it; trees it has nothing to do with (fewer than four triangles, non-finite boxes) come back unchanged with depth -1; malformed ones are refused."""
+    from oracle import pt_oracle
+    for cfg, kw in (("c2", dict(width=40, height=24, subdiv=1)), ("c5", dict(width=24, height=16, n=4000)), ("c1", dict(width=32, height=32, subdiv=1))):
+        sc, pr = scenes.CONFIGS[cfg](**kw)
+        raw = np.asarray(sc["bvh_builder"], np.float32).reshape(-1, 3)
+        out, depth, moved, cost = host.reinsert(raw)
+        c0, _, leaves0, ok0, n0 = _tree_facts(raw)
+        c1, d1, leaves1, ok1, n1 = _tree_facts(out)
+        assert ok0 and ok1 and leaves0 == leaves1 and n0 == n1 == raw.shape[0] // 3
+        assert d1 == depth and moved > 0
+        assert abs(c0 - cost[0]) <= 1e-6 * c0 and abs(c1 - cost[1]) <= 1e-6 * c1 and c1 < c0
+        N = out.reshape(-1, 9)
+        forks = np.nonzero(N[:, 8] < 0)[0]
+        assert (N[forks, 6] == forks + 1).all(), "DFS pre-order: a fork's x child follows it"
+        again, _, moved2, cost2 = host.reinsert(out)
+        assert cost2[1] <= cost2[0] * (1 + 1e-12) and cost2[1] > 0.98 * cost[1]
+        ordered, _ = host.lights_first(out, sc["tri"], sc["mat"])
+        a, ra = pt_oracle.render(dict(sc, bvh=ordered), pr)
+        b, rb = pt_oracle.render(sc, pr)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ra == rb
+    # left alone
+    sc, _ = scenes.config_c5(8, 8, n=3)
+    raw = np.asarray(sc["bvh_builder"], np.float32).reshape(-1, 3)
+    out, depth, moved, cost = host.reinsert(raw)
+    assert depth == -1 and moved == 0 and np.array_equal(out, raw)
+    sc, _ = scenes.config_c5(8, 8, n=200)
+    bad = np.asarray(sc["bvh_builder"], np.float32).reshape(-1, 9).copy()
+    bad[5, 3] = np.inf
+    out, depth, moved, _ = host.reinsert(bad.reshape(-1, 3))
+    assert depth == -1 and moved == 0 and np.array_equal(out.view(np.uint32), bad.reshape(-1, 3).view(np.uint32))
+    # malformed: a child index out of range, a node referenced twice
+    for col, val in ((6, 1e6), (6, None)):
+        t = np.asarray(sc["bvh_builder"], np.float32).reshape(-1, 9).copy()
+        t[0, col] = t[0, 7] if val is None else val
+        with pytest.raises(RuntimeError):
+            host.reinsert(t.reshape(-1, 3))
+
+
+def test_the_sah_reinsert_builder_is_sah_plus_the_pass():
+    sc, _ = scenes.config_c2(16, 16, subdiv=1)
+    want, depth, _, _ = host.reinsert(host.build_bvh(sc["vert"], sc["tri"], "sah")[0])
+    got = scenes.rebuild_bvh(sc, "sah-reinsert")
+    assert np.array_equal(np.asarray(got["bvh_builder"]).view(np.uint32), want.view(np.uint32)) and got["bvh_depth"] == depth
+    assert np.array_equal(np.asarray(got["bvh"]), host.lights_first(want, sc["tri"], sc["mat"])[0])
+
+
 def test_lights_first_can_be_switched_off(monkeypatch):
     monkeypatch.setenv("GLRT_BVH_LIGHTS_FIRST", "0")
     sc, _ = scenes.config_c2(16, 16, subdiv=1)

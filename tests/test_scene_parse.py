@@ -41,12 +41,12 @@ def _builder():
     return b
 
 
-@pytest.mark.parametrize("bvh", ["sah", "lbvh-cpu", "sah-levels-cpu"])
+@pytest.mark.parametrize("bvh", ["sah", "sah-reinsert", "lbvh-cpu", "sah-levels-cpu"])
 def test_parse_matches_python_builder(tmp_path, bvh):
     b = _builder()
     js = scenes.export_json_obj(b, tmp_path, 96, 64, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0, aperture=0.1, focal=8.0)
     got = _probe(js, bvh)
-    want = b.build({"lbvh-cpu": "lbvh", "sah-levels-cpu": "sahl"}.get(bvh, "sah"))
+    want = b.build({"lbvh-cpu": "lbvh", "sah-levels-cpu": "sahl", "sah-reinsert": "sah-reinsert"}.get(bvh, "sah"))
     assert (got["width"], got["height"]) == (96, 64)
     wv = np.asarray(want["vert"], np.float32).reshape(-1, 15)
     assert_bit_equal(got["vert"][:, :3], wv[:, :3], "positions")
