@@ -31,7 +31,7 @@ namespace {
 constexpr int kStripeQuantum = 8;   // stripe heights are multiples of the 8x8 work tile
 constexpr int kGroupStripe = 8;     // stripe height glrtx_group uses: 1080 rows over 8 members = 136 / 128 rows (16-row stripes: 144 / 128)
 constexpr int kPairFetchMinRecords = 32768;  // forks + triangles (2 MiB of 64-byte records) from which the wavefront kernel fetches nodes pair-cooperatively
-constexpr int kFramesBudgetGiB = 32;  // device memory one glrtx_render_frames launch may use for path state and sample planes
+constexpr int kFramesBudgetGiB = 32;  // device memory one glrtx_render_frames launch may use for its sample planes (and the single-frame pipe slots for their buffers)
 constexpr float kInf = std::numeric_limits<float>::infinity();
 constexpr unsigned kPipeSlots = 8;    // most single-frame launches that may be in flight at once (each with its own stream, state, queues, planes); pipe_slots are used
 constexpr unsigned kLaunchRing = 16;  // launches that may be outstanding per context before a new one waits for the oldest
@@ -523,8 +523,15 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const int tiles8_x = (c->width + 7) / 8, tiles8_y = (c->owned_rows + 7) / 8;
     const size_t total = (size_t)tiles8_x * tiles8_y * 64;
     if (total * 2 >= (size_t)INT32_MAX) return fail(c, GLRTX_EINVAL, "image too large for the wgwf variant");
-    const size_t ids = total * (size_t)n_frames;  // id = frame * total + pixel
-    if (2 * ids + 1 >= (size_t)UINT32_MAX)
+    const size_t ids = total * (size_t)n_frames;  // path id = frame * total + pixel
+    // path state: two sets of six planes, an entry per workgroup and path-queue position (WfArgs::state) -- sized for the largest grid x block_paths the launch
+    // below can choose: every workgroup slot of the device with kWgPathsMax paths (0.8 GB), or, for an overlapped single-frame launch (which spreads ONE frame over
+    // all the slots, see block_paths below), with the smallest power of two that holds its share of the frame (0.4 GB at 1080p)
+    const size_t wg_slots = (size_t)c->n_cu * GLRTX_WGWF_WAVES;
+    size_t slot_paths = 256;
+    while (slot_paths < (size_t)kWgPathsMax && wg_slots * slot_paths < ids) slot_paths *= 2;
+    const size_t slot_state_bytes = (size_t)kWfStatePlanes * wg_slots * slot_paths * sizeof(float4);
+    if (ids + 1 >= (size_t)UINT32_MAX)
         return fail(c, GLRTX_EINVAL, "glrtx_render_frames: %d frames of %zu pixels exceed the 32-bit ray id space", n_frames, total);
     int rc;
     // A single-frame launch runs on one of pipe_slots side streams with buffers of its own and hands its samples over in planes, so that the
@@ -540,7 +547,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     glrtx_ctx::PipeSlot *slot = nullptr;
     int pipe_busy = 0;
     if (piped) {
-        const size_t per_slot = kWfStatePlanes * ids * sizeof(float4) + (size_t)c->n_cu * GLRTX_WGWF_WAVES * kWgQueueF4 * sizeof(float4) + (size_t)p->n_samples * plane_bytes;
+        const size_t per_slot = slot_state_bytes + (size_t)c->n_cu * GLRTX_WGWF_WAVES * kWgQueueF4 * sizeof(float4) + (size_t)p->n_samples * plane_bytes;
         size_t budget = (size_t)kFramesBudgetGiB << 30;
         if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
         budget /= (size_t)std::max(c->budget_share, 1);
@@ -559,7 +566,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
                 if (k != pick && c->pipe[k].used && hipEventQuery(c->pipe[k].render_done) == hipErrorNotReady) pipe_busy++;
             (void)hipGetLastError();
             // the slot's buffers, before anything depends on them
-            if (ensure(c, slot->state, kWfStatePlanes * ids * sizeof(float4)) != GLRTX_OK ||
+            if (ensure(c, slot->state, slot_state_bytes) != GLRTX_OK ||
                 ensure(c, slot->planes, (size_t)std::max(p->n_samples, 1) * plane_bytes) != GLRTX_OK ||
                 ensure(c, slot->queues, (size_t)c->n_cu * GLRTX_WGWF_WAVES * kWgQueueF4 * sizeof(float4)) != GLRTX_OK) {
                 (void)hipGetLastError();
@@ -589,11 +596,13 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     DevBuf &planeBuf = slot ? slot->planes : c->wfPlanes;
     unsigned *const workPtr = (unsigned *)(slot ? slot->work.p : c->work.p);
     const hipStream_t rstream = slot ? slot->stream : c->stream;  // the render kernel's stream
-    if ((rc = ensure(c, stateBuf, kWfStatePlanes * ids * sizeof(float4)))) return rc;
+    const size_t state_entries = wg_slots * (slot ? slot_paths : (size_t)kWgPathsMax);
+    const size_t state_bytes = (size_t)kWfStatePlanes * state_entries * sizeof(float4);
+    if ((rc = ensure(c, stateBuf, state_bytes))) return rc;
     WfArgs w;
     std::memset(&w, 0, sizeof w);
     w.state = (float4 *)stateBuf.p;
-    w.ids = ids;
+    w.ids = state_entries;  // (the plane stride)
     w.total = (int)total;
     w.tiles8_x = tiles8_x;
     w.refill_min = kRefillMin;
@@ -678,11 +687,13 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // (2 rays per live path: the next ray and the shadow ray) and of the path-id queue; every (frame, sample) has its plane.
     {
         const size_t max_id = ids - 1;
+        const size_t max_sidx = (size_t)kWfSetPlanes * state_entries + (size_t)grid * block_paths - 1;  // the highest state index a ray record can carry (set 1)
         const size_t slice_f4 = 2 * (size_t)2 * 2 * block_paths /* ray records */ + (2 * (size_t)block_paths * sizeof(unsigned) + 15) / 16 /* path ids [2] */;
         static_assert(kWgSuspendAt + (size_t)kSuspendF4 * kBlockThreads == kWgQueueF4, "the suspend area closes a workgroup's slice");
-        bool ok = slice_f4 <= kWgSuspendAt && max_id < ids && 2 * max_id + 1 < (size_t)WF_INVALID && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
+        bool ok = slice_f4 <= kWgSuspendAt && max_id < (size_t)WF_INVALID && 2 * max_sidx + 1 < (size_t)WF_INVALID && (size_t)grid * block_paths <= state_entries &&
+                  (size_t)kWfStatePlanes * state_entries * sizeof(float4) < ((size_t)1 << 32) && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
                   block_paths <= kWgPathsMax && slice_f4 <= kWgQueueF4 && queueBuf.bytes >= (size_t)grid * kWgQueueF4 * sizeof(float4) &&
-                  stateBuf.bytes >= kWfStatePlanes * ids * sizeof(float4) && w.ids == ids && grid >= 1 && grid <= resident &&
+                  stateBuf.bytes >= state_bytes && w.ids == state_entries && grid >= 1 && grid <= resident &&
                   p->max_depth <= kWfDepthMax && p->n_samples <= kWfSampleMax && workPtr != nullptr;
         if (n_frames > 1) ok = ok && c->wfSeeds.bytes >= (size_t)n_frames * sizeof(float2);
         if (w.planes) ok = ok && planeBuf.bytes >= (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4);
@@ -1116,18 +1127,21 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
         }
         return GLRTX_OK;
     }
-    // Frames per launch are bounded by a FIXED memory budget (path state: kWfStatePlanes float4 per owned pixel and frame, plus one
-    // float4 plane per sample) -- not by what happens to be free on the device, so that the launch shapes, and with them the timing,
-    // do not depend on what else runs there.  A longer request is issued as several launches, in order.  GLRTX_FRAMES_BUDGET_MB
-    // overrides the default (tests).  An allocation that fails is reported, not worked around.
+    // Frames per launch are bounded by a FIXED memory budget for what a launch needs PER FRAME -- one float4 plane per sample and owned pixel -- not by what happens
+    // to be free on the device, so that the launch shapes, and with them the timing, do not depend on what else runs there.  (Path state no longer counts: it is
+    // addressed by workgroup and queue position, 0.8 GB whatever the frames in flight -- WfArgs::state; by pixel it was 96 B per pixel and frame and set the limit.)
+    // A longer request is issued as several launches of equal size, in order.  GLRTX_FRAMES_BUDGET_MB overrides the default (tests).  An allocation that fails is
+    // reported, not worked around.
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t px = (size_t)((c->width + 7) / 8) * (size_t)((c->owned_rows + 7) / 8) * 64;
-    const size_t per_frame = px * kWfStatePlanes * sizeof(float4) + (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
+    const size_t per_frame = (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
     size_t budget = (size_t)kFramesBudgetGiB << 30;
     if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
     budget /= (size_t)std::max(c->budget_share, 1);
-    const size_t id_cap = (((size_t)1 << 31) - 2) / std::max<size_t>(px, 1);  // ray ids are 2 id + shadow bit, below 0xFFFFFFFF
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, id_cap), budget / std::max<size_t>(per_frame, 1)));
+    const size_t id_cap = (((size_t)1 << 31) - 2) / std::max<size_t>(px, 1);  // path ids (frame * pixels + pixel) stay below 2^31
+    const int most = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, id_cap), budget / std::max<size_t>(per_frame, 1)));
+    const int n_launches = (n_frames + most - 1) / most;
+    const int chunk = (n_frames + n_launches - 1) / n_launches;  // equal helpings: 16 frames under a limit of 14 are 8 + 8, not 14 + 2
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int n = std::min(chunk, n_frames - f0);
         int rc;

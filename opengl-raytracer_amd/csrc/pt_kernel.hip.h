@@ -1511,12 +1511,18 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
 // (A device-wide version of this pipeline -- one traverse and one shade kernel per trip over global
 // queues -- was built and measured first: 5.3 ms per headline frame, of which ~3.4 ms was nine
 // device-wide waits for each trip's longest ray.  The workgroup-local form below replaced it.)
+constexpr int kWfSetPlanes = 6;  // planes of one set of WfArgs::state (kWfStatePlanes counts both sets)
 struct WfArgs {
-    // Path state: six float4-wide planes of `ids` entries each in ONE allocation (one base pointer and one stride in scalar
-    // registers instead of six pointers), plane k of path id at state[k * ids + id]:
+    // Path state: six float4-wide planes of `ids` entries each, TWICE (one set read, one written per trip), in ONE allocation (one base pointer and one stride
+    // in scalar registers instead of twelve pointers).  A path's entry is addressed by WHERE THE PATH STANDS IN ITS WORKGROUP'S PATH QUEUE, not by its pixel:
+    // state index = set * 6 * ids + workgroup * block_paths + queue position, plane k at state[k * ids + state index].  The shade phase reads set `cur` at the
+    // positions of this trip's queue and writes set `cur ^ 1` at the positions of the next trip's: a wave's 64 loads / stores of a plane are 64 consecutive float4
+    // (1 KiB, eight lines) whatever has become of the paths in between -- addressed by pixel they spread over three times as many lines once paths had died --
+    // and the allocation is 2 x 6 x 16 B x (workgroups x block_paths) = 0.8 GB whatever the number of frames in flight (by pixel: 3.2 GB at 16 frames, 9.5 GB at 48).
     //   0: {next ray origin (= shadow ray origin), rng.x}      1: {next ray direction, rng.y}
     //   2: {beta, meta}   meta = depth | sample << 8 | flags   3: {L if the pending light sample is accepted (or L), dist}
-    //   4: {L if it is rejected, -}                             5: closest hit of the path's ray {t, tri, u, v}
+    //   4: {L if it is rejected, -}                             5: closest hit of the path's ray {t, tri, u, v}   (written by the traversal lane: the ray
+    //      record carries the state index its path will be read at; a parked ray's record is re-addressed when its path moves: wg_shade_phase)
     // (a shadow ray leaves no record in memory: the traversal lane evaluates the light test of :367 itself and sets one bit,
     //  indexed by the owning path's position in the workgroup's path queue, in LDS)
     // (ray origins/directions for the traversal travel in the workgroup's ray queue: 32-byte records
@@ -1526,8 +1532,10 @@ struct WfArgs {
     // The plane offset is recomputed where it is used (an opaque move keeps the compiler from hoisting seven derived base
     // pointers out of the persistent loop, where they would sit in scalar registers the traversal loop has to spill).
     DEV size_t plane(int k) const { size_t n = ids; asm volatile("" : "+s"(n)); return (size_t)k * n; }
-    DEV float4 *A(int k, unsigned id) const { return state + plane(k) + id; }
-    DEV float4 *H(unsigned id) const { return state + plane(5) + id; }
+    // (byte offset formed in 32 bits -- the allocation is below 4 GiB -- so that an access can take the scalar plane base plus ONE vector offset register)
+    DEV float4 *A(int k, unsigned sidx) const { return reinterpret_cast<float4 *>(reinterpret_cast<char *>(state + plane(k)) + (size_t)(sidx * 16u)); }
+    DEV float4 *H(unsigned sidx) const { return A(5, sidx); }
+    DEV unsigned set_base(int set, int wg) const { size_t n = ids; asm volatile("" : "+s"(n)); return (unsigned)((size_t)set * kWfSetPlanes * n) + (unsigned)wg * (unsigned)block_paths; }
     int total;        // tile-order ids: tiles8_x * tiles8_y * 64
     int tiles8_x;
     int refill_min;   // refill a traversal wave once this many lanes are idle
@@ -1552,7 +1560,7 @@ struct WfArgs {
 };
 // meta word of the path state: depth in bits 0-7 (it reaches max_depth before the path ends), sample index in bits 8-27.
 // The host sends launches beyond these ranges to the persistent megakernel (glrtx_render).
-constexpr int kWfStatePlanes = 6;  // float4-wide planes of WfArgs::state
+constexpr int kWfStatePlanes = 2 * kWfSetPlanes;  // float4-wide planes of WfArgs::state: two sets of six
 constexpr int kWfDepthMax = 255;
 constexpr int kWfSampleMax = (1 << 20) - 1;
 constexpr unsigned WF_PENDING = 1u << 28;    // a shadow ray of the previous bounce is in flight
@@ -1625,7 +1633,7 @@ DEV bool wf_start(const KernelArgs &a, const WfArgs &w, const float *cam, int id
 
 // Start path `id` (frame | tile-order pixel id): seed its RNG, draw sample 0's camera ray, store the path state.
 // Returns true if a ray was queued (false: outside the image, or nothing to trace).
-DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam, int id, float4 &ray_o, float4 &ray_d) {
+DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam, int id, unsigned sidx, float4 &ray_o, float4 &ray_d) {
     int lx, lrow;
     bool go = false;
     const float2 sd = wf_seed(a, w, id);
@@ -1639,11 +1647,11 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam,
         go = wf_start(a, w, cam, id, lx, lrow, rng, fcx, fcy, P, sample);
     }
     if (go) {
-        st_stream(w.A(0, id), make_float4(P.ox, P.oy, P.oz, rng.x));
-        st_stream(w.A(1, id), make_float4(P.dx, P.dy, P.dz, rng.y));
-        st_stream(w.A(2, id), make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8)));
-        st_stream(w.A(3, id), make_float4(0.f, 0.f, 0.f, 0.f));
-        ray_o = make_float4(P.ox, P.oy, P.oz, __uint_as_float((unsigned)id * 2u));
+        st_stream(w.A(0, sidx), make_float4(P.ox, P.oy, P.oz, rng.x));
+        st_stream(w.A(1, sidx), make_float4(P.dx, P.dy, P.dz, rng.y));
+        st_stream(w.A(2, sidx), make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8)));
+        st_stream(w.A(3, sidx), make_float4(0.f, 0.f, 0.f, 0.f));
+        ray_o = make_float4(P.ox, P.oy, P.oz, __uint_as_float(sidx * 2u));
         ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
     }
     return go;
@@ -1651,18 +1659,20 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam,
 
 // One path of the shade stage: resolve the light sample of the previous bounce, then either close the
 // sample (and start the pixel's next one) or run shade_hit() on the new hit.  Outputs which rays to
-// queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray.
-DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, unsigned id, bool light_accepted, bool &push_ext, bool &push_sh,
-                       bool &requeue, float4 &ray_o, float4 &ray_d, float4 &ray_sd, unsigned long long &rays) {
+// queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray -- and, when the path goes on (either of them, or requeue), its state
+// for the next trip, which the caller stores once it knows the path's next queue position: ray_o = plane 0 {origin, rng.x}, ray_d = plane 1 {direction, rng.y},
+// st2 / st3 = planes 2 / 3, st4 = plane 4 when has4.
+DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, unsigned id, unsigned sidx, bool light_accepted, bool &push_ext,
+                       bool &push_sh, bool &requeue, float4 &ray_o, float4 &ray_d, float4 &ray_sd, float4 &st2, float4 &st3, float4 &st4, bool &has4, unsigned long long &rays) {
     int lx, lrow;
     wf_pixel(a, w, (int)id, lx, lrow);
     const int gy = local_row_to_y(a, lrow);
     const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
-    const float4 s0 = ld_stream(w.A(0, id)), s1 = ld_stream(w.A(1, id)), s2 = ld_stream(w.A(2, id)), s3 = ld_stream(w.A(3, id));
+    const float4 s0 = ld_stream(w.A(0, sidx)), s1 = ld_stream(w.A(1, sidx)), s2 = ld_stream(w.A(2, sidx)), s3 = ld_stream(w.A(3, sidx));
     // the hit record is fetched with the state, not behind the meta word the state delivers: one round trip less per round of the shade loop
     // (-0.9 % per frame, profiles/r03_ab_shade_phase.txt; unused when the path has ended).  Plain load and store for the hit records:
     // -1.6 % against the non-temporal forms, profiles/r02_ab_flags.txt
-    const float4 hh = *w.H(id);
+    const float4 hh = *w.H(sidx);
     const float2 sd = wf_seed(a, w, (int)id);
     Rng rng = {s0.w, s1.w, sd.x, sd.y};
     const unsigned meta = __float_as_uint(s2.w);
@@ -1674,21 +1684,27 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
     // resolve the light sample of the previous bounce (:367, :539)
     P.Lx = s3.x; P.Ly = s3.y; P.Lz = s3.z;
     if (meta & WF_RESOLVED) light_accepted = (meta & WF_ACCEPTED) != 0u;  // the verdict was carried over a deferral
-    if (meta & WF_PENDING) {
-        if (!light_accepted) {  // the traversal lane's verdict on the shadow ray (nee_accepted), one bit per path
-            const float4 s4 = ld_stream(w.A(4, id));
-            P.Lx = s4.x; P.Ly = s4.y; P.Lz = s4.z;
-        }
+    const bool rejected = (meta & WF_PENDING) != 0u && !light_accepted;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rejected) {  // the traversal lane's verdict on the shadow ray (nee_accepted), one bit per path
+        s4 = ld_stream(w.A(4, sidx));
+        P.Lx = s4.x; P.Ly = s4.y; P.Lz = s4.z;
     }
     bool ended = (meta & WF_FINISHING) != 0u;
     Shade sh;
     sh.has_shadow = false;
     if (!ended) {
         if (hh.x == kHitSuspended) {
-            // the path's ray is parked in a traversal lane (see kSuspendMax): nothing to shade yet.  The path stays in the queue; the verdict
-            // of its shadow ray -- which did finish this trip, and whose bit is indexed by THIS trip's queue position -- moves into the state word
-            if ((meta & WF_PENDING) && !(meta & WF_RESOLVED))
-                st_stream(w.A(2, id), make_float4(s2.x, s2.y, s2.z, __uint_as_float(meta | WF_RESOLVED | (light_accepted ? WF_ACCEPTED : 0u))));
+            // the path's ray is parked in a traversal lane (see kSuspendMax): nothing to shade yet.  The path stays in the queue -- its state moves to its next
+            // position as it is -- and the verdict of its shadow ray -- which did finish this trip, and whose bit is indexed by THIS trip's queue position -- moves
+            // into the state word.  (The parked ray is told where its path has moved to: wg_shade_phase.)
+            unsigned m2 = meta;
+            if ((meta & WF_PENDING) && !(meta & WF_RESOLVED)) m2 = meta | WF_RESOLVED | (light_accepted ? WF_ACCEPTED : 0u);
+            ray_o = s0; ray_d = s1;
+            st2 = make_float4(s2.x, s2.y, s2.z, __uint_as_float(m2));
+            st3 = s3;
+            st4 = s4;
+            has4 = rejected;  // (plane 4 moves with the rest then; an accepted or absent sample never reads it)
             requeue = true;
             return;
         }
@@ -1704,25 +1720,21 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         sample++;
         push_ext = wf_start(a, w, cam, (int)id, lx, lrow, rng, fcx, fcy, P, sample);  // the pixel's next sample, if any
         if (push_ext) {
-            st_stream(w.A(0, id), make_float4(P.ox, P.oy, P.oz, rng.x));
-            st_stream(w.A(1, id), make_float4(P.dx, P.dy, P.dz, rng.y));
-            st_stream(w.A(2, id), make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8)));
-            st_stream(w.A(3, id), make_float4(0.f, 0.f, 0.f, 0.f));
-            ray_o = make_float4(P.ox, P.oy, P.oz, 0.f);
-            ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
+            ray_o = make_float4(P.ox, P.oy, P.oz, rng.x);
+            ray_d = make_float4(P.dx, P.dy, P.dz, rng.y);
+            st2 = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
+            st3 = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
         // shade_hit ran and the path goes on and/or awaits its shadow ray
         push_sh = sh.has_shadow;
         push_ext = !sh.ended;
         const unsigned m2 = (unsigned)P.depth | (sample << 8) | (push_sh ? WF_PENDING : 0u) | (sh.ended ? WF_FINISHING : 0u);
-        st_stream(w.A(0, id), make_float4(P.ox, P.oy, P.oz, rng.x));
-        st_stream(w.A(1, id), make_float4(P.dx, P.dy, P.dz, rng.y));
-        st_stream(w.A(2, id), make_float4(P.bx, P.by, P.bz, __uint_as_float(m2)));
-        st_stream(w.A(3, id), make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist));
-        if (push_sh) st_stream(w.A(4, id), make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f));
-        ray_o = make_float4(P.ox, P.oy, P.oz, 0.f);  // the next ray and the shadow ray leave from the same point
-        ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
+        ray_o = make_float4(P.ox, P.oy, P.oz, rng.x);  // the next ray and the shadow ray leave from the same point
+        ray_d = make_float4(P.dx, P.dy, P.dz, rng.y);
+        st2 = make_float4(P.bx, P.by, P.bz, __uint_as_float(m2));
+        st3 = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist);
+        if (push_sh) { st4 = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f); has4 = true; }
         ray_sd = make_float4(sh.sdx, sh.sdy, sh.sdz, sh.dist);
     }
 }
@@ -1860,7 +1872,8 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         if (s3.z != 0.0f) {
             const float4 s0 = susp[0], s1 = susp[1], s2 = susp[2];
             susp[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-            T.ox = s0.x; T.oy = s0.y; T.oz = s0.z; rid = __float_as_uint(s0.w);
+            T.ox = s0.x; T.oy = s0.y; T.oz = s0.z;
+            rid = __float_as_uint(w.H(__float_as_uint(s0.w) >> 1)->y);  // the path's state has moved since: the shade phase left the new ray id behind the mark
             T.dx = s1.x; T.dy = s1.y; T.dz = s1.z; T.stop_d = s1.w;
             T.ix = frcp(T.dx); T.iy = frcp(T.dy); T.iz = frcp(T.dz);  // :260, as at chunk time
             T.h.t = s2.x; T.h.tri = __float_as_int(s2.y); T.h.u = s2.z; T.h.v = s2.w;
@@ -2005,18 +2018,21 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
 // round 2: bit-identical, 9 % slower per frame; profiles/r02_shade_sort.txt, removed.)
 // Shadow rays: the light test's verdict for the path at queue position i is bit i of `light_bits` (LDS), set by the traversal
 // lane that finished the path's shadow ray; the shadow ray pushed here carries the position its path will have in pq_next.
+// Path state: the path at queue position i is read at state index cur_base + i and -- if it goes on -- written at next_base + (its position in pq_next); the next
+// ray's record carries that index (even ray id: where the traversal lane stores the hit), and a ray parked in a traversal lane finds it behind the mark it left.
 DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, const unsigned *light_bits, const unsigned *pq, int n_paths,
-                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned long long &rays) {
+                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned cur_base, unsigned next_base, unsigned long long &rays) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int j0 = 0; j0 < n_paths; j0 += kBlockThreads) {
         const int i = j0 + (int)threadIdx.x;
-        bool push_ext = false, push_sh = false, requeue = false;
+        bool push_ext = false, push_sh = false, requeue = false, has4 = false;
         unsigned id = WF_INVALID;
-        float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro, rsd = ro;
+        float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro, rsd = ro, st2 = ro, st3 = ro, st4 = ro;
         if (i < n_paths) id = pq[i];
         const bool light_accepted = i < n_paths && ((light_bits[i >> 5] >> (i & 31)) & 1u) != 0u;
-        if (id != WF_INVALID) wf_shade_path(a, w, lds_mats, cam, id, light_accepted, push_ext, push_sh, requeue, ro, rd, rsd, rays);
+        if (id != WF_INVALID)
+            wf_shade_path(a, w, lds_mats, cam, id, cur_base + (unsigned)i, light_accepted, push_ext, push_sh, requeue, ro, rd, rsd, st2, st3, st4, has4, rays);
         const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms | __ballot(requeue);
         unsigned br = 0, bp = 0;
         if (lane == 0) {
@@ -2027,18 +2043,29 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         }
         br = __builtin_amdgcn_readfirstlane(br);
         bp = __builtin_amdgcn_readfirstlane(bp);
+        const unsigned pos_next = bp + (unsigned)__popcll(mp & lt_mask);  // this path's position in the next trip's path queue
+        const unsigned sidx_next = next_base + pos_next;                  // ... and its state index there
+        if (push_ext || push_sh || requeue) {
+            st_stream(w.A(0, sidx_next), ro);
+            st_stream(w.A(1, sidx_next), rd);
+            st_stream(w.A(2, sidx_next), st2);
+            st_stream(w.A(3, sidx_next), st3);
+            if (has4) st_stream(w.A(4, sidx_next), st4);
+            pq_next[pos_next] = id;
+        }
+        // a parked ray's path has moved: the forwarding address goes where the ray left its mark -- the lane reads it when it resumes (wg_traverse_phase), before this
+        // set is written again -- and the ray ends the next traverse phase finished or parked again: either way it writes the hit record at the new index
+        if (requeue) *w.H(cur_base + (unsigned)i) = make_float4(kHitSuspended, __uint_as_float(sidx_next * 2u), 0.f, 0.f);
         if (push_ext) {
             float4 *r = rq_next + 2 * (size_t)(br + __popcll(me & lt_mask));
-            r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(id * 2u));
-            r[1] = rd;
+            r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(sidx_next * 2u));
+            r[1] = make_float4(rd.x, rd.y, rd.z, 0.f);
         }
-        const unsigned pos_next = bp + (unsigned)__popcll(mp & lt_mask);  // this path's position in the next trip's path queue
         if (push_sh) {
             float4 *r = rq_next + 2 * (size_t)(br + __popcll(me) + __popcll(ms & lt_mask));
             r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pos_next * 2u + 1u));  // shadow ray id: queue position, odd
             r[1] = rsd;
         }
-        if (push_ext || push_sh || requeue) pq_next[pos_next] = id;
     }
 }
 
@@ -2136,10 +2163,11 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
             float4 *rq_w = rayQ + 2 * ((size_t)cur * 2 * kWgPaths + nr);
             unsigned *pq_w = pathQ + cur * kWgPaths + np;
             const WgwfKernArgs *kt = wgwf_kernargs();
+            const unsigned new_base = kt->w.set_base(cur, (int)blockIdx.x) + (unsigned)np;  // state index of the first new path: set `cur`, behind the live ones
             for (int k = threadIdx.x; k < got; k += kBlockThreads) {
                 const int id = tile0 * 64 + k;  // tile g = tile0 + (k >> 6) of the frame-major tile order holds ids 64 g .. 64 g + 63
                 float4 ro = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID)), rd = ro;
-                const bool go = wf_generate_one(kt->a, kt->w, lds_cam, id, ro, rd);  // pixels outside the image leave skip markers
+                const bool go = wf_generate_one(kt->a, kt->w, lds_cam, id, new_base + (unsigned)k, ro, rd);  // pixels outside the image leave skip markers
                 rq_w[2 * k] = ro;  // (plain stores, like every ray record: see st_stream)
                 rq_w[2 * k + 1] = rd;
                 pq_w[k] = go ? (unsigned)id : WF_INVALID;
@@ -2189,7 +2217,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // ---- shade phase: the live paths; appends go to the other queue pair
         const WgwfKernArgs *ks = wgwf_kernargs();
         wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, light_bits, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
-                       &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], rays);
+                       &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], ks->w.set_base(cur, (int)blockIdx.x), ks->w.set_base(cur ^ 1, (int)blockIdx.x), rays);
         PH_STAMP(ps1);
         __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
         PH_STAMP(ps2);

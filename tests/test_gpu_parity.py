@@ -766,10 +766,10 @@ def test_frames_in_flight_are_chunked_by_the_memory_budget(gpu_device, monkeypat
     scene, params = scenes.config_c2(width=256, height=144, max_depth=4, subdiv=1)
     seeds = _seeds(7)
     want, _ = gpu_render(d, scene, params, frames=seeds)
-    per_frame_mb = 256 * 144 * 6 * 16 / 2**20 + 256 * 144 * 16 / 2**20   # kWfStatePlanes = 6 float4 state planes per pixel (36,864, exact stride) + one sample plane
-    assert per_frame_mb == 3.9375
-    # 8 MB: two frames per launch (with seven planes it would be one), 12 MB: three (seven planes: two)
-    for budget_mb, launches in ((1, 7), (8, 4), (12, 3), (1 << 14, 1)):
+    per_frame_mb = 256 * 144 * 16 / 2**20   # one float4 sample plane per frame (path state is addressed by workgroup and queue position: constant, not charged)
+    assert per_frame_mb == 0.5625
+    # 1 MB: one frame per launch; 2 MB: three fit, so 7 frames go as 3 + 3 + 1; 3 MB: five fit -> equal helpings of 4 + 3; 16 GB: one launch
+    for budget_mb, launches in ((1, 7), (2, 3), (3, 2), (1 << 14, 1)):
         monkeypatch.setenv("GLRTX_FRAMES_BUDGET_MB", str(budget_mb))
         d.clear(); d.reset_stats()
         d.render_frames(params, seeds); d.sync()
