@@ -78,7 +78,7 @@ VALU_CLK_PER_INST = 1.97
 #  the kernel's span, so the pipe's capacity is the span figure: 25.4 clk for 64 lanes in 64 lines, 24.1 G/s chip-wide at 2.38 GHz, as the wall clock says.)
 VMEM_CLK_NODE_LANE, VMEM_CLK_NODE_PAIR, VMEM_CLK_STREAM = 37.0, 24.5, 16.1
 STRIPE = 8  # rows per stripe: 1080 rows over 8 ranks = 136 / 128 rows per rank (16-row stripes: 144 / 128, 6.7 % off balance)
-STEPS_PER_LAUNCH = 48  # frames' worth of paths in flight on every GPU per launch (frames in flight; round 3, ms per frame: 8: 1.127, 24: 1.060, 48: 1.043; 11 GB of path state and planes at 1080p)
+STEPS_PER_LAUNCH = 48  # frames' worth of paths in flight on every GPU per launch (frames in flight; round 3, ms per frame: 8: 1.127, 24: 1.060, 48: 1.043; 2.4 GB of path state and sample planes at 1080p)
 
 # Test hook: tests/ replace this with a factory of CPU renderers (same interface as GpuRenderer) to rehearse the
 # N > 1 control flow under gloo.  The product path never sets it.
@@ -852,7 +852,7 @@ def main(argv=None):
                        "timed_kernel_image_check": f"bit-identical to the counting kernel's accumulator over the {args.steps} timed steps (untimed replay)",
                        # N = 1: the GPU's accumulator over the first n timed frames against the oracle's (the CPU restatement, pinned by the llvmpipe fixtures)
                        "oracle_image_check": oracle_check,
-                       "run_to_run": "one context = one draw: contexts of one binary differ by up to 3 % with where the 4 GB path-state buffer lands physically (profiles/r04_context_regimes.txt)",
+                       "run_to_run": "one context = one draw: contexts of one binary differ by up to 3 % with where the path-state buffer lands physically (profiles/r04_context_regimes.txt)",
                        # strong scaling: the same K frames whatever N is, S frames in flight IN TOTAL per launch, framebuffer gathered after every launch
                        "strong": ({"error": strong_err} if strong_err else None) if strong_s is None else
                            {"frames": args.steps, "frames_in_flight_total": S, "gather": "none" if args.no_gather else "to rank 0 after every launch, overlapped with the next launch",

@@ -153,6 +153,7 @@
     GLRTX_SCAN_BOX_UNIFORM \
     "s_mov_b64 %[alive], exec\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t" \
+    ".p2align 6\n\t"                                                  /* the loop's head on a 64-byte line, wherever the code in front of it ends (round 5: 1.8 % of config 3 hung on that) */ \
     ".Lscan_loop_%=:\n\t" \
     "s_load_dwordx16 s[GLRTX_SB0:GLRTX_SB0+15], s[34:35], 0x80\n\t" \
     "s_load_dwordx16 s[GLRTX_SB1:GLRTX_SB1+15], s[34:35], 0xc0\n\t" \
