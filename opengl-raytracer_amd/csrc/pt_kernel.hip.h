@@ -1664,10 +1664,6 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam,
 // st2 / st3 = planes 2 / 3, st4 = plane 4 when has4.
 DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, unsigned id, unsigned sidx, bool light_accepted, bool &push_ext,
                        bool &push_sh, bool &requeue, float4 &ray_o, float4 &ray_d, float4 &ray_sd, float4 &st2, float4 &st3, float4 &st4, bool &has4, unsigned long long &rays) {
-    int lx, lrow;
-    wf_pixel(a, w, (int)id, lx, lrow);
-    const int gy = local_row_to_y(a, lrow);
-    const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
     const float4 s0 = ld_stream(w.A(0, sidx)), s1 = ld_stream(w.A(1, sidx)), s2 = ld_stream(w.A(2, sidx)), s3 = ld_stream(w.A(3, sidx));
     // the hit record is fetched with the state, not behind the meta word the state delivers: one round trip less per round of the shade loop
     // (-0.9 % per frame, profiles/r03_ab_shade_phase.txt; unused when the path has ended).  Plain load and store for the hit records:
@@ -1716,6 +1712,11 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         ended = sh.ended && !sh.has_shadow;  // with a shadow ray in flight the sample closes next trip
     }
     if (ended) {
+        // (the pixel is worked out HERE, where a sample closes, not in front of the shading: two registers less to carry through it)
+        int lx, lrow;
+        wf_pixel(a, w, (int)id, lx, lrow);
+        const int gy = local_row_to_y(a, lrow);
+        const float fcx = (float)lx + 0.5f, fcy = (float)gy + 0.5f;
         wf_add_sample(a, w, (int)id, lx, lrow, sample, P.Lx, P.Ly, P.Lz);
         sample++;
         push_ext = wf_start(a, w, cam, (int)id, lx, lrow, rng, fcx, fcy, P, sample);  // the pixel's next sample, if any
