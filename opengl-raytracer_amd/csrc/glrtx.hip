@@ -641,9 +641,12 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // Picked by the size of the record array; GLRTX_PAIR_FETCH=0/1 overrides.  Both forms are bit-identical (same IEEE operations on the same record).
     using Kernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *);
     const bool vine = c->sc.n_vine > 0;
-    // ... and on small trees, where neither form wins, the two in alternate steps: the pipe is the busier unit in one step, the SIMDs in the next: -1.0 .. -1.3 %
-    // (every mix tried: pair-lane, lane-pair, 2:1, 1:2; config 5 prefers the pure pair form by 3-5 %).
-    int fetch = vine ? 0 : ((size_t)c->n_fork + (size_t)c->st.n_tri >= (size_t)kPairFetchMinRecords ? 1 : 2);
+    // On small trees the two forms in alternate steps (FETCH 2: the pipe is the busier unit in one step, the SIMDs in the next) beat both by 1.0 .. 1.3 % in round 4.
+    // Since the path state is read and written by queue position (WfArgs::state) the pipe has a fifth less to do and the plain form wins there: headline -0.7 %,
+    // config 2 -0.4 %, config 4 -1.0 % against the alternating one, the pure pair form +1.9 % (profiles/r05_state_by_position.txt).  The alternating form stays
+    // compiled in (GLRTX_PAIR_FETCH=2).  Random triangle soups prefer the pair form from 10 k triangles on (-2 %; 20 k: -4.5 %, 70 k: -7 %): what decides is how
+    // far apart a wave's rays are in the tree, which the record count only approximates.
+    int fetch = vine ? 0 : ((size_t)c->n_fork + (size_t)c->st.n_tri >= (size_t)kPairFetchMinRecords ? 1 : 0);
     if (const char *v = std::getenv("GLRTX_PAIR_FETCH")) fetch = vine ? 0 : std::max(0, std::min(2, std::atoi(v)));
     c->st.node_fetch_last = fetch;
     const bool cr = c->count_rays;

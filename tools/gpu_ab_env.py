@@ -1,7 +1,7 @@
 """A/B of a run-time switch (an environment variable the library reads at every launch) inside ONE context: the same buffers, the same box and clock, the launches of the two
 settings alternating.  This removes the context-to-context spread (profiles/r04_context_regimes.txt) from the comparison altogether: differences of 0.1-0.2 % show.
 
-    python tools/gpu_ab_env.py LIB ENV VALUE_A VALUE_B [--contexts 3] [--rounds 30] [--frames 20] [--config headline]
+    python tools/gpu_ab_env.py LIB ENV VALUE_A VALUE_B [--contexts 3] [--rounds 30] [--frames 20] [--config headline|c2..c5|rand:N]
     python tools/gpu_ab_env.py LIB call:set_shadow_range_limit 0 1        (a per-context setter of glrt_amd.device.Device instead of an environment variable)
 
 Per context: median ms per frame of each setting and the median (quartiles) of the per-round differences B against A; images and ray counts of the two settings compared first."""
@@ -32,7 +32,11 @@ def setting(d, v):
         os.environ[env] = v
 
 
-sc, pr = scenes.CONFIGS[opt["config"]]()
+if opt["config"].startswith("rand:"):  # rand:N -- N random triangles at config 5's density and camera distance (tree-size sweeps, as tools/gpu_abx.py)
+    n_ = int(opt["config"][5:]); ext_ = 10.0 * (n_ / 100_000.0) ** (1.0 / 3.0)
+    sc, pr = scenes._random_tri_scene(n_, 20260102, ext_, 3.4 * ext_, 1920, 1080, 4, 1, "sah")
+else:
+    sc, pr = scenes.CONFIGS[opt["config"]]()
 F = opt["frames"]
 for ci in range(opt["contexts"]):
     d = device.Device(); d.upload_scene(sc); d.resize(pr["width"], pr["height"])
