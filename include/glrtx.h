@@ -103,7 +103,8 @@ typedef struct glrtx_stats {
     int32_t device_error_pending; /* ABI 9: 1 while a launch that FAILED on the device sits unreported in the context's launch ring: glrtx_get_stats never blocks and
                                      never consumes such a record (its rc stays GLRTX_OK and the timing fields stop advancing); the error itself -- kernel, size, frame
                                      count, device -- is returned by the next glrtx_sync, or by the launch that needs the record's slot */
-    int32_t reserved1;
+    int32_t wf_state_mib;       /* (was reserved1) MiB of path state the last wavefront launch ran on: an entry per workgroup and path-queue position, two sets of six
+                                   float4 planes -- 768 on a 256-CU device whatever the frames in flight (384 for an overlapped single-frame launch at 1080p) */
 } glrtx_stats;
 
 /* glrtx_stats.fallback_last: the wavefront kernel packs depth and sample index into one word of its path state */

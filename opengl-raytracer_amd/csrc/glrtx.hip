@@ -603,6 +603,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     std::memset(&w, 0, sizeof w);
     w.state = (float4 *)stateBuf.p;
     w.ids = state_entries;  // (the plane stride)
+    c->st.wf_state_mib = (int32_t)(state_bytes >> 20);
     w.total = (int)total;
     w.tiles8_x = tiles8_x;
     w.refill_min = kRefillMin;

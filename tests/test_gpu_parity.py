@@ -778,6 +778,25 @@ def test_frames_in_flight_are_chunked_by_the_memory_budget(gpu_device, monkeypat
         assert_bit_equal(d.read_accum(), want, f"budget {budget_mb} MB")
 
 
+def test_path_state_does_not_grow_with_the_frames_in_flight(gpu_device):
+    """Round 5: the wavefront kernel's path state is addressed by workgroup and path-queue position -- glrtx_stats.wf_state_mib is what the last launch ran on: the same for
+    2 and for 24 frames in flight (two sets of six float4 planes for every workgroup slot of the device x 4096 paths: 3 MiB per CU), and both launches render what
+    consecutive single-frame launches render."""
+    d = gpu_device
+    scene, params = scenes.config_c2(width=320, height=180, max_depth=5, subdiv=1)
+    sizes = []
+    for n in (2, 24):
+        seeds = _seeds(n)
+        want, _ = gpu_render(d, scene, params, frames=seeds)  # (uploads the scene; one launch per frame)
+        d.clear(); d.reset_stats()
+        d.render_frames(params, seeds); d.sync()
+        st = d.stats()
+        assert st.kernel_launches == 1 and st.launches == n
+        sizes.append(st.wf_state_mib)
+        assert_bit_equal(d.read_accum(), want, f"{n} frames in flight")
+    assert sizes[0] == sizes[1] > 0 and sizes[0] % 3 == 0, sizes
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (3, 2), (17, 1), (1, 33), (9, 9)])
 def test_tiny_images_single_and_in_flight(gpu_device, w, h):
     """Images far smaller than a tile / a workgroup's path set: one frame per launch and four in flight vs the oracle."""
