@@ -802,42 +802,65 @@ def main(argv=None):
                           "error": strong_err or n1_err,
                           "note": "the same K frames whatever N is; speedup = this run's own one-GPU time of those frames / the N-GPU time (the driver's N = 1 line is the "
                                   "authoritative denominator; this one makes the line readable by itself)"}
+    # ---- which figure is the line's `value` (round 6).  BASELINE.json's metric is Mrays/s of ONE 1920x1080 frame size at 1, 2, 4, 8 GPUs (">= 6x at 8 GPUs"): the
+    # same K frames whatever N is -- strong scaling.  Until round 5 `value` at N > 1 was the weak figure (N frames per step: it grows with N by construction) and the
+    # strong one sat beside it; now the strong region IS the line: value = rays of K frames / the barrier-bracketed, max-over-ranks time of those K frames, S frames in
+    # flight in total per launch, the framebuffer gathered to rank 0 after every launch.  The weak figure moves to config.weak.  At N = 1 the two coincide.  If the
+    # strong region failed (config.strong.error) the line falls back to the weak figure and says so in `scaling`.
+    weak_value = traced_rays / elapsed_s / 1e6
+    weak_ms_per_step = elapsed_s / args.steps * 1e3
+    strong_is_line = world == 1 or strong_s is not None
+    line_value = weak_value if (world == 1 or strong_s is None) else traced_rays / world / strong_s / 1e6
+    line_ms_per_step = weak_ms_per_step if (world == 1 or strong_s is None) else strong_s / args.steps * 1e3
+    env_overrides = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("GLRTX_", "GLRT_"))}
+    st_final = R.stats()
+    shadow_search = {0: "exact", 1: "range-limited"}.get(int(getattr(st_final, "shadow_limited", -1)), "unknown")
     if rank == 0:
         gather_note = "" if world == 1 else (", no gather" if args.no_gather else
                                              (f", RCCL gather of the framebuffer to rank 0 every {args.gather_every} launches and at the end of the timed region"
                                               if args.gather_every > 0 else ", RCCL gather of the framebuffer to rank 0 once, at the end of the timed region"))
         out = {
             "metric": "Mrays/s at 1920x1080, 8 bounces" if args.config == "headline" else f"Mrays/s ({args.config})",
-            "value": round(traced_rays / elapsed_s / 1e6, 3),
+            "value": round(line_value, 3),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed_s / args.steps * 1e3, 4),
+            "ms_per_step": round(line_ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
-            # `value` above is the WEAK figure: every GPU always renders one full frame's worth of pixels per step, so it grows with N by construction.  The figure
-            # BASELINE.json's ">= 6x at 8 GPUs" is to be read from is this one: the SAME K frames whatever N is (S frames in flight in total per launch, the
-            # framebuffer gathered to rank 0 after every launch), against the one-GPU time of those frames measured on rank 0's GPU alone IN THIS RUN.
+            "scaling": "strong" if strong_is_line else "weak",
+            # `value` above is the STRONG figure (see line_value): the SAME K frames whatever N is.  scaling_strong repeats it with its own one-GPU denominator, measured
+            # on rank 0's GPU alone IN THIS RUN; config.weak holds the weak figure (N frames per step) that was `value` until round 5.
             "scaling_strong": scaling_strong,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {n_tri} triangles (BVH {scene['bvh_kind']}; the light side first at {scene.get('bvh_lights_first', 0)} forks), {W}x{H}, "
                                    f"u_maxDepth={params['max_depth']}, {params['n_samples']} spp/frame",
-                       "step": f"{world} consecutive frame(s) of the accumulation loop = one full frame's worth of pixels per GPU",
-                       "frames_per_step": world,
-                       "ms_per_frame": round(elapsed_s / n_frames * 1e3, 4),
+                       "step": ("1 frame of the accumulation loop (the same K frames whatever N is), its rows sharded over the N GPUs in interleaved stripes"
+                                if (world > 1 and strong_is_line) else
+                                f"{world} consecutive frame(s) of the accumulation loop = one full frame's worth of pixels per GPU"),
+                       "frames_per_step": 1 if strong_is_line else world,
+                       "ms_per_frame": round(line_ms_per_step if strong_is_line else elapsed_s / n_frames * 1e3, 4),
+                       # which shadow-ray search the device ran (glrtx_stats.shadow_limited: the exact search is the default, the range limit an opt-in outside the
+                       # bit-exact contract) and every GLRTX_* / GLRT_* variable set in this process: a line taken with a switch thrown says so
+                       "shadow_search": shadow_search,
+                       "env_overrides": env_overrides,
+                       # the weak-scaling figure (N frames per step: every GPU renders one full frame's worth of pixels per step whatever N is; one gather at the end
+                       # of the timed region) -- `value` until round 5
+                       "weak": None if world == 1 else {"value": round(weak_value, 3), "unit": "Mrays/s", "ms_per_step": round(weak_ms_per_step, 4), "frames_per_step": world,
+                                                        "ms_per_frame": round(elapsed_s / n_frames * 1e3, 4)},
                        "partition": f"{world} x interleaved {STRIPE}-row stripes" + gather_note,
                        "steps_per_launch": S,
                        "launches": [k for _, k in launch_plan(args.steps, S)],
                        "one_launch_per_frame": None if single is None else
-                           {"ms_per_step": round(single * 1e3, 4), "value": round(traced_rays / args.steps / single / 1e6, 3)},
+                           {"ms_per_step": round(single * 1e3, 4), "value": round(traced_rays / args.steps / single / 1e6, 3),
+                            "what": "glrtx_render once per frame, back to back, one sync at the end (window.cpp:121-169's cadence)"},
                        "rays_per_frame": round(traced_rays / n_frames, 1),
                        # the reference's algorithm also executes intersect() for shadow rays whose light test cannot change the
                        # radiance (both outcomes bit-identical); those are resolved without a traversal and NOT part of `value`
                        "rays_reference_equivalent_per_frame": round(ref_rays / n_frames, 1),
                        "rays_untraced_per_frame": round(total_untraced / n_frames, 1),
-                       "mrays_per_s_reference_equivalent": round(ref_rays / elapsed_s / 1e6, 3),
-                       "mpaths_per_s": round(W * H * params["n_samples"] * n_frames / elapsed_s / 1e6, 3),
+                       "mrays_per_s_reference_equivalent": round(ref_rays / n_frames / (line_ms_per_step / (1 if strong_is_line else world) * 1e-3) / 1e6, 3),
+                       "mpaths_per_s": round(W * H * params["n_samples"] / (line_ms_per_step / (1 if strong_is_line else world) * 1e-3) / 1e6, 3),
                        "event_ms_per_step": round(ev_ms / args.steps, 4),
                        "host_ms_to_issue_timed_launches": round((t_issued - t0) * 1e3, 3),
                        # N > 1: the image RCCL gathered for min(K, 4) of the timed steps against the same frames rendered by rank 0's GPU alone

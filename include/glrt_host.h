@@ -73,7 +73,8 @@ int glrt_bvh_lights_first(float *nodes, size_t n_nodes, const float *tri, size_t
 /* Optimisation pass over a finished tree of any builder: every subtree is taken out and put back where the summed area of the forks' boxes grows least (insertion-based
  * optimisation, Bittner et al. 2013; host/bvh.cpp).  At most max_passes passes, stopping when one gains < 0.1 %.  The tree is renumbered in DFS pre-order.
  * cost_out (may be NULL): summed fork area / root area before [0] and after [1].  Returns the number of subtrees moved (>= 0; 0 and max_depth -1 for trees it leaves
- * alone: < 4 leaves, absent children, non-finite boxes) or GLRT_HOST_E*.  Apply glrt_bvh_lights_first AFTER it. */
+ * alone: < 4 leaves, absent children, non-finite boxes) or GLRT_HOST_E*
+ * -- GLRT_HOST_EDEPTH when the optimised tree would be deeper than the 64-entry traversal stack allows: `nodes` is then left exactly as it came in.  Apply glrt_bvh_lights_first AFTER it. */
 int glrt_bvh_reinsert(float *nodes, size_t n_nodes, int max_passes, int *max_depth_out, double *cost_out);
 
 void glrt_look_at(const float eye[3], const float center[3], const float up[3], float out[16]);

@@ -100,6 +100,10 @@ struct glrtx_ctx {
     bool bound = false;
     int bound_rows = 0;       // rows the caller's buffer holds (glrtx_bind_accum)
 
+    // Four words of host-coherent memory the persistent kernel's trip guards report through ({code, workgroup, trips without a tile, live paths}; pt_render_wgwf):
+    // read -- and cleared -- when a launch is folded.
+    unsigned *guard_host = nullptr, *guard_dev = nullptr;
+
     bool count_rays = false;
     const char *last_kernel = "";  // name of the last render kernel launched (error reports)
     mutable bool counters_stale = false;          // a counting launch was issued since the device counters were last read
@@ -160,12 +164,20 @@ int fold_launches(glrtx_ctx *c, bool block, unsigned keep = 0) {
         // a polling caller (glrtx_get_stats) must not swallow a device error: the record stays in the ring, and the next blocking fold -- glrtx_sync,
         // or a launch that needs the slot -- reports it with the launch it belongs to
         // -- but the poller is TOLD: glrtx_stats.device_error_pending stays set until that blocking fold has consumed the record
-        if (e != hipSuccess && !block) { (void)hipGetLastError(); c->st.device_error_pending = 1; return GLRTX_OK; }
+        const bool guard = e == hipSuccess && c->guard_host && __atomic_load_n(&c->guard_host[0], __ATOMIC_ACQUIRE) != 0u;  // (a trip guard's report: below)
+        if ((e != hipSuccess || guard) && !block) { (void)hipGetLastError(); c->st.device_error_pending = 1; return GLRTX_OK; }
         c->ring_tail++;
-        if (e != hipSuccess) c->st.device_error_pending = 0;
+        if (e != hipSuccess || guard) c->st.device_error_pending = 0;
         if (e != hipSuccess)
             return fail(c, GLRTX_EDEVICE, "render launch failed on the device (%s): %s, %dx%d (%d owned rows), %d frame(s), device %d", hipGetErrorString(e),
                         r.kernel, c->width, c->height, c->owned_rows, r.frames, c->device);
+        if (guard) {  // a trip guard of the persistent kernel fired (pt_render_wgwf): the launch left paths unfinished
+            const unsigned code = c->guard_host[0], wg = c->guard_host[1], trips = c->guard_host[2], alive = c->guard_host[3];
+            std::memset(c->guard_host, 0, 16);
+            return fail(c, GLRTX_EDEVICE, "render launch aborted by a trip guard (%s): workgroup %u, %u trips since its last tile, %u paths alive; %s, %dx%d (%d owned rows), %d frame(s), device %d",
+                        code == 1u ? "two trips in which no ray was dealt and no path moved" : "trip limit exceeded", wg, trips, alive, r.kernel, c->width, c->height,
+                        c->owned_rows, r.frames, c->device);
+        }
         float ms = 0.f, ms2 = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, r.ev0, r.evm));   // render kernel
         HIP_TRY(c, hipEventElapsedTime(&ms2, r.has_eva ? r.eva : r.evm, r.ev1));  // plane accumulation (frames in flight, overlapped single frames), else ~0
@@ -451,8 +463,7 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         }
     }
     // Renumbering: the forks of the tree's top levels (breadth-first from the root, kTopForks of them) take the first indices, the
-    // others follow in the order the traversal meets them.  The top of the tree is then one contiguous, hot 8 KiB block; the
-    // -DGLRTX_LDS_TOP build of the wavefront kernel additionally keeps that block in LDS (measured: profiles/r02_lds_top.json).
+    // others follow in the order the traversal meets them.  The top of the tree is then one contiguous, hot 8 KiB block.
     if (root_ref >= 0 && forks.size() / 4 > 1) {
         const int nf = (int)(forks.size() / 4);
         std::vector<int> newid(nf, -1), order;
@@ -625,15 +636,9 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const int lds_base = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
                          16 * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block |
                          kWgPathsMax / 8;  // light-test bits, one per path-queue position
-    // Top tree levels in LDS (trav_step): OFF by default -- measured on the headline config it is worth nothing (+1.6 % per frame at
-    // 128 forks, -0.7..-1.4 % on configs 2/4/5 with 16-128, all inside the run-to-run spread; profiles/r02_lds_top.json): the lanes at
-    // the top levels share their few cache lines with many other lanes of the wave already, so taking them off the vector-memory
-    // pipe removes almost no line fetches.  In a -DGLRTX_LDS_TOP_MAX=128 build GLRTX_LDS_TOP=n stages the first n forks (as many as fit beside the traversal stacks
-    // without costing a resident workgroup are: the register budget allows GLRTX_WGWF_WAVES workgroups per CU, each 1/4 of 160 KiB).
-    int n_top = 0;
-    if (const char *v = std::getenv("GLRTX_LDS_TOP")) n_top = std::max(0, std::min(std::min(std::atoi(v), std::min(kTopForks, GLRTX_LDS_TOP_MAX)), c->n_fork));
-    const int lds = lds_base + n_top * 64;
-    a.sc.n_top = n_top;
+    // (north_star's "primitives staged into LDS": materials, camera block, root box and the per-lane stacks are; the top tree levels were built, measured worth
+    // nothing -- profiles/r02_lds_top.json -- and removed.)
+    const int lds = lds_base;
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
     // eight instantiations: ray counting on/off x (list scan of a vine (brute-force) tree | tree traversal with one record per lane | with the pair-cooperative
     // node fetch | with the two in alternate steps).  The pair fetch trades 25 vector-ALU instructions per step for a third less time in the CU's vector-memory pipe
@@ -683,6 +688,11 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     w.gss_div = slot ? 0 : 4 * grid;  // (overlapped single-frame launches: no guided self-scheduling, see `share` above)
     if (const char *v = std::getenv("GLRTX_GSS_DIV")) w.gss_div = std::max(0, std::atoi(v));
     w.suspend_max = kSuspendMax;
+    // trip guards (pt_render_wgwf): a path is alive for at most n_samples x (max_depth + 2) shaded trips; 64 times that (parked trips, the other paths' rounds) and a
+    // constant are allowed between two tiles a workgroup is given
+    w.trip_limit = (int)std::min<long long>(INT32_MAX, 64ll * std::max(p->n_samples, 1) * (p->max_depth + 2) + 64);
+    if (const char *v = std::getenv("GLRTX_TRIP_LIMIT")) w.trip_limit = std::max(1, std::atoi(v));
+    w.err = c->guard_dev;
     if (const char *v = std::getenv("GLRTX_SUSPEND_MAX")) w.suspend_max = std::max(0, std::min(64, std::atoi(v)));
     if ((rc = ensure(c, queueBuf, (size_t)grid * kWgQueueF4 * sizeof(float4)))) return rc;  // per-workgroup queues
     // Shape invariants of the hand-written kernel, checked on the host before every launch (an access past one of these
@@ -773,7 +783,9 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
         (e = hipEventCreate(&c->rs0)) != hipSuccess || (e = hipEventCreate(&c->rs1)) != hipSuccess ||
         (e = hipMalloc(&c->counter.p, 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMalloc(&c->work.p, 64)) != hipSuccess) {
+        (e = hipMalloc(&c->work.p, 64)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->guard_host, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer((void **)&c->guard_dev, c->guard_host, 0)) != hipSuccess) {
         fail(nullptr, GLRTX_EDEVICE, "context setup failed: %s", hipGetErrorString(e));
         glrtx_destroy(c);
         return GLRTX_EDEVICE;
@@ -785,6 +797,7 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
             glrtx_destroy(c);
             return GLRTX_EDEVICE;
         }
+    std::memset(c->guard_host, 0, 64);
     c->stream = c->own_stream;
     // The slots' streams are created at a priority of their own (GLRTX_PIPE_PRIORITY: high (default) | normal | low).  The runtime maps the streams of a process onto a
     // few hardware queues PER PRIORITY LEVEL, and streams that share a queue run one after the other: at the default priority the slots share those queues with
@@ -842,6 +855,7 @@ void glrtx_destroy(glrtx_ctx *c) {
     if (c->rs0) (void)hipEventDestroy(c->rs0);
     if (c->rs1) (void)hipEventDestroy(c->rs1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->guard_host) (void)hipHostFree(c->guard_host);
     delete c;
 }
 
@@ -882,7 +896,6 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     sc.n_light = (int)n_light;
     sc.n_mat = (int)n_mat;
     sc.n_fork = (int)(forks.size() / 4);
-    sc.n_top = 0;  // chosen per launch by launch_wgwf
     sc.stack_entries = stack_need;
     sc.mats_in_lds = (n_mat > 0 && n_mat <= (size_t)kMaxLdsMaterials) ? 1 : 0;
     sc.vine = P.vine.empty() ? nullptr : (const float4 *)c->vine.p;

@@ -68,7 +68,6 @@ struct DevScene {
     int n_light;
     int n_mat;
     int n_fork;
-    int n_top;          // wavefront kernel: forks [0, n_top) are also staged in LDS (0: none)
     int stack_entries;  // per-lane traversal stack entries in LDS
     int mats_in_lds;    // 1: materials staged into LDS at kernel start
     // "Vine" trees -- every fork has a leaf as children.y: the brute-force scan of BASELINE config 3 expressed in the
@@ -189,17 +188,6 @@ DEV float pt_cos(float x) {
 struct Rng {
     float x, y, sx, sy;
 };
-#ifdef GLRTX_EXP_CHEAP_RAND
-// EXPERIMENT (never in a product build; the image is NOT the reference's): a random number for five instructions instead of two Cephes sines -- the upper bound
-// of what any faster statement of rand() could buy (profiles/r05_shade_bounds.txt).
-DEV float pt_rand(Rng &s) {
-    float p = s.x * 97.13f + 0.3547f;
-    s.x = p - __builtin_floorf(p);
-    p = s.y * 31.71f + s.x;
-    s.y = p - __builtin_floorf(p);
-    return s.x;
-}
-#else
 DEV float pt_rand(Rng &s) {
     const float a = 12.9898f, b = 78.233f, c = 43758.5453f;
     const float dy = (s.y - s.sy) * b;  // old state.y term, shared by both updates
@@ -211,7 +199,6 @@ DEV float pt_rand(Rng &s) {
     s.y = p - __builtin_floorf(p);
     return s.x;
 }
-#endif
 
 // ------------------------------------------------------------------------------------------ helpers
 DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (az * bz + ay * by) + ax * bx; }
@@ -389,18 +376,13 @@ DEV bool trav_init(const DevScene &sc, const float4 *root, Trav &T, float ox, fl
 
 // One trip of the traversal loop: process T.cur (fork or leaf), then pick the next node.
 // Returns true when the ray is finished (stack empty).
-#ifndef GLRTX_LDS_TOP_MAX
-#define GLRTX_LDS_TOP_MAX 0  // experiment build: -DGLRTX_LDS_TOP_MAX=128 compiles the LDS path in, GLRTX_LDS_TOP=n selects n forks at run time
-#endif
-// lds_top / n_top (wavefront kernel; compiled in only with -DGLRTX_LDS_TOP_MAX=128, then GLRTX_LDS_TOP=n at run time): the first
-// n_top forks -- the top levels of the tree, numbered first by pack_scene -- are staged in LDS and read from there.  About half of a ray's fork visits are to those
-// levels, but it buys nothing measurable (profiles/r02_lds_top.json): the cost of a wave's node fetch is set by its number of
-// distinct cache lines (profiles/r02_ubench_gather.json), and the lanes at the top levels share theirs with many others.
-// What the experiment did find: written as below, every lane fetches its whole 56-byte record with FOUR load instructions
+// (Top tree levels staged in LDS were built and measured in round 2: worth nothing, profiles/r02_lds_top.json -- the cost of a wave's node fetch is set by its number of
+// distinct cache lines (profiles/r02_ubench_gather.json), and the lanes at the top levels share theirs with many others; removed.)
+// What that experiment did find: written as below, every lane fetches its whole 56-byte record with FOUR load instructions
 // (dwordx4, dwordx4, dwordx3, dwordx3) issued together; the previous form -- three loads for all lanes, then one more and the
 // two refs as single dwords on the fork arm, six instructions -- was 8 % slower per frame for fewer bytes.
 template <bool CLOSEST>
-DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] const float4 *lds_top = nullptr, [[maybe_unused]] int n_top = 0) {
+DEV bool trav_step(const DevScene &sc, int *stack, Trav &T) {
 #ifdef GLRTX_TRAV_STATS
     trav_stats_iter(T.cur, (const void *)(sc.forks + 4 * (ptrdiff_t)T.cur), T.stop_d == -__builtin_inff(), T.sp);
     T.iters++;
@@ -424,16 +406,7 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
     // compiler drops the unused C.w / D.w).  The vector-memory pipe charges per instruction and per distinct cache line, not per
     // byte: fetching the fork arm's second box and refs separately (six instructions, 20 bytes less for a triangle lane) was 8 %
     // slower per frame (profiles/r02_lds_top.json, r02_ubench_gather.json).
-    float4 A, B, C, D;
-#if GLRTX_LDS_TOP_MAX > 0
-    if ((unsigned)cur < (unsigned)n_top) {  // a fork of the top levels: its record is in LDS
-        const lds_cf4 q = (lds_cf4)lds_top + 4 * cur;
-        A = to_f4(q[0]); B = to_f4(q[1]); C = to_f4(q[2]); D = to_f4(q[3]);
-    } else
-#endif
-    {
-        A = N[0]; B = N[1]; C = N[2]; D = N[3];
-    }
+    float4 A = N[0], B = N[1], C = N[2], D = N[3];
     // Pin the fork-only words (the two refs, the second child's far corner) here, in front of the arms: without it the compiler
     // sinks their loads into the fork arm and the fetch becomes six instructions instead of four (8 % slower per frame).
     asm volatile("" : "+v"(A.w), "+v"(B.w), "+v"(D.x), "+v"(D.y), "+v"(D.z));
@@ -449,22 +422,11 @@ DEV bool trav_step(const DevScene &sc, int *stack, Trav &T, [[maybe_unused]] con
         // record ~n_tri -- carries the box (-inf, +inf), which passes by itself with t0 = -inf (pack_scene)
         const bool pl = bl;
         const bool pr = br;
-#ifdef GLRTX_NEAR_FIRST_EXPERIMENT
-        // MEASUREMENT ONLY (never shipped: ties may resolve differently from the reference): a path ray visits the nearer child first
-        const float kl = l < 0 ? -PT_INFTY : t0l, kr = r < 0 ? -PT_INFTY : t0r;
-        const bool lf = pl && pr && T.stop_d == -__builtin_inff() && kl < kr;
-        if (pl && pr) {
-            reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = lf ? make_int2(__float_as_int(kr), r) : make_int2(__float_as_int(kl), l);
-            T.sp++;
-        }
-        T.cur = lf ? l : (pr ? r : l);
-#else
         if (pl && pr) {  // continue with the right child, the left one waits on the stack
             reinterpret_cast<int2 *>(stack)[T.sp * kBlockThreads] = make_int2(__float_as_int(t0l), l);  // {t0, ref}: one ds_write_b64
             T.sp++;
         }
         T.cur = pr ? r : l;
-#endif
         need_pop = !(pl || pr);
     }
     if (!is_fork) {
@@ -603,11 +565,7 @@ DEV void trav_steps_asm(const DevScene &sc, int *stack, Trav &T GLRTX_TS_PARAM) 
         "s_mov_b64 %[act], exec\n\t"
         GLRTX_ASM_SET_VBASE
         "v_bfrev_b32 v[GLRTX_VB+11], 1\n\t"
-#ifdef GLRTX_EXPERIMENT_LEAF_ALTERNATE
-        GLRTX_REP(GLRTX_STEPS_PER_TRIP_HALF, GLRTX_TRAV_STEP_ASM_LANE_NOLEAF GLRTX_TRAV_STEP_ASM_LANE)
-#else
         GLRTX_REP(GLRTX_STEPS_PER_TRIP, GLRTX_TRAV_STEP_ASM_LANE)
-#endif
         "99:\n\t"
         "s_mov_b64 exec, %[entry]"
         : [th] "+&v"(T.h.t), [tri] "+&v"(T.h.tri), [hu] "+&v"(T.h.u), [hv] "+&v"(T.h.v), [cur] "+&v"(T.cur), [sp] "+&v"(T.sp),
@@ -856,22 +814,6 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
     bool spec_out = false, stop_after = false;
     do {
         if (!h_hit) break;  // miss: nothing is added and the loop ends (:497-499)
-#if defined(GLRTX_EXP_SHADE_VPAD) || defined(GLRTX_EXP_SHADE_SPAD)
-        {   // EXPERIMENT (never in a product build): N more vector / scalar instructions per shaded hit, results unused -- the shade phase's elasticity to its
-            // own instruction count (profiles/r05_shade_bounds.txt)
-#ifdef GLRTX_EXP_SHADE_VPAD
-            float pad_ = bx;
-            for (int i_ = 0; i_ < GLRTX_EXP_SHADE_VPAD / 16; i_++)
-                asm volatile(GLRTX_REP8("v_fma_f32 %0, %1, %1, %0\n") GLRTX_REP8("v_fma_f32 %0, %1, %1, %0\n") : "+v"(pad_) : "v"(by));
-#endif
-#ifdef GLRTX_EXP_SHADE_SPAD
-            unsigned spad_ = 0;
-            for (int i_ = 0; i_ < GLRTX_EXP_SHADE_SPAD / 16; i_++)
-                asm volatile(GLRTX_REP8("s_add_u32 %0, %0, 1\n") GLRTX_REP8("s_add_u32 %0, %0, 1\n") : "+s"(spad_) : : "scc");
-#endif
-        }
-#endif
-
         const float nx = S.nx, ny = S.ny, nz = S.nz;
         const Mat M = load_mat(sc, lds_mats, S.mtrl);
         const int type = __float_as_int(M.m0.w);
@@ -1542,6 +1484,11 @@ struct WfArgs {
     int block_paths;  // paths a workgroup keeps alive (power of two, 256 .. kWgPathsMax)
     int gss_div;      // top-up requests are capped at ceil(tiles left / gss_div); 0 = uncapped
     int suspend_max;  // a wave parks its last path rays at the end of a trip when at most this many lanes still run (0: never; kSuspendMax)
+    // Bounds of the persistent loop (pt_render_wgwf: "trip guards").  A workgroup that runs more than trip_limit trips without being given a tile, or two trips in a row
+    // in which nothing moved, reports {code, workgroup, trips, live paths} through err -- four words of host-coherent memory the context reads when it folds the launch
+    // (GLRTX_EDEVICE) -- and leaves the loop, so that a slip in the queue bookkeeping ends as a failed launch, not as a kernel that never ends.
+    int trip_limit;
+    unsigned *err;
     // Frames in flight (glrtx_render_frames): n_frames consecutive frames that differ only in u_seed run in ONE launch.
     // Path ids are frame * total + tile-order pixel id; every finished sample is stored in its own plane
     // (frame * n_samples + sample) and accumulate_planes_kernel adds the planes to the accumulator in frame order, so
@@ -1578,6 +1525,9 @@ constexpr int kSuspendMax = 24;
 constexpr float kHitSuspended = -1.0f;       // Hit::t of a suspended path ray (a real t exceeds PT_EPS, a miss is PT_INFTY)
 constexpr int kSuspendF4 = 4;                // float4s per lane in the suspend area: {o, rid} {d, stop_d} {tHit, tri, u, v} {cur, sp, slot in use, -}
 constexpr int kRefillMin = 16;               // refill a traversal wave once this many lanes are idle
+#ifdef GLRTX_FAULT_INJECT
+constexpr unsigned kFaultPoison = 0xFFFFFFFEu;
+#endif
 
 DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lrow) {
     int frame, pid;
@@ -1800,7 +1750,7 @@ __device__ unsigned g_ray_log_trips;        // trips appended
 DEV int wgwf_suspend_max();  // WfArgs::suspend_max of the running pt_render_wgwf launch, from its kernarg segment (defined below)
 
 template <bool VINE, int FETCH>
-DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, [[maybe_unused]] const float4 *lds_top, int *stack, const float4 *rq, int n_rays,
+DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *root, int *stack, const float4 *rq, int n_rays,
                            unsigned *ray_head, unsigned *light_bits, unsigned long long &rays, float4 *suspend_area) {
     const int lane = threadIdx.x & 63;
     if (VINE) {  // list scan: every ray takes the same number of steps, so waves simply take 64 rays at a time
@@ -1824,7 +1774,6 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         return;
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    [[maybe_unused]] const int n_top = a.sc.n_top;
     const float4 none = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID));
     float4 cur_o = none, cur_d = none;  // this lane's record of the wave's current chunk
     float cur_ix = 0.f, cur_iy = 0.f, cur_iz = 0.f;  // ... and 1 / direction (:260), computed when the chunk arrives
@@ -1875,6 +1824,9 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
             susp[3] = make_float4(0.f, 0.f, 0.f, 0.f);
             T.ox = s0.x; T.oy = s0.y; T.oz = s0.z;
             rid = __float_as_uint(w.H(__float_as_uint(s0.w) >> 1)->y);  // the path's state has moved since: the shade phase left the new ray id behind the mark
+#ifdef GLRTX_FAULT_INJECT
+            const bool fault_dropped = rid == kFaultPoison;  // (see wg_shade_phase)
+#endif
             T.dx = s1.x; T.dy = s1.y; T.dz = s1.z; T.stop_d = s1.w;
             T.ix = frcp(T.dx); T.iy = frcp(T.dy); T.iz = frcp(T.dz);  // :260, as at chunk time
             T.h.t = s2.x; T.h.tri = __float_as_int(s2.y); T.h.u = s2.z; T.h.v = s2.w;
@@ -1883,6 +1835,9 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
             T.iters = 0;
 #endif
             active = true;
+#ifdef GLRTX_FAULT_INJECT
+            if (fault_dropped) active = false;
+#endif
         }
     }
     auto save_hit = [&]() {
@@ -1958,7 +1913,10 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
                     susp[1] = make_float4(T.dx, T.dy, T.dz, T.stop_d);
                     susp[2] = make_float4(T.h.t, __int_as_float(T.h.tri), T.h.u, T.h.v);
                     susp[3] = make_float4(__int_as_float(T.cur), __int_as_float(T.sp), 1.0f, 0.f);  // .z: the slot holds a ray
-                    *w.H(rid >> 1) = make_float4(kHitSuspended, 0.f, 0.f, 0.f);  // the shade phase defers this path
+                    // (the mark's words are formed HERE: hoisted out of the persistent loop as a constant the compiler kept them in four registers it then spilled)
+                    float mark = kHitSuspended, zero = 0.f;
+                    asm volatile("" : "+v"(mark), "+v"(zero));
+                    *w.H(rid >> 1) = make_float4(mark, zero, zero, zero);  // the shade phase defers this path
                     active = false;
                 }
                 break;
@@ -1977,11 +1935,11 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
         }
 #endif
         if (active) {
-#if defined(GLRTX_TRAV_STATS) || GLRTX_LDS_TOP_MAX > 0 || defined(GLRTX_CXX_STEP)  // diagnostic / experiment builds: the C++ statement of the step
-            bool fin = trav_step<true>(a.sc, stack, T, lds_top, n_top);
+#if defined(GLRTX_TRAV_STATS) || defined(GLRTX_CXX_STEP)  // diagnostic / experiment builds: the C++ statement of the step
+            bool fin = trav_step<true>(a.sc, stack, T);
 #pragma unroll
             for (int k = 1; k < GLRTX_STEPS_PER_TRIP; k++)
-                if (!fin) fin = trav_step<true>(a.sc, stack, T, lds_top, n_top);
+                if (!fin) fin = trav_step<true>(a.sc, stack, T);
 #else
 #ifdef GLRTX_STEP_TIMING
             trav_steps_asm<FETCH>(a.sc, stack, T, step_timing);
@@ -2022,7 +1980,8 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
 // Path state: the path at queue position i is read at state index cur_base + i and -- if it goes on -- written at next_base + (its position in pq_next); the next
 // ray's record carries that index (even ray id: where the traversal lane stores the hit), and a ray parked in a traversal lane finds it behind the mark it left.
 DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, const unsigned *light_bits, const unsigned *pq, int n_paths,
-                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned cur_base, unsigned next_base, unsigned long long &rays) {
+                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned cur_base, unsigned next_base, unsigned long long &rays,
+                        unsigned *moved) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int j0 = 0; j0 < n_paths; j0 += kBlockThreads) {
@@ -2034,9 +1993,11 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         const bool light_accepted = i < n_paths && ((light_bits[i >> 5] >> (i & 31)) & 1u) != 0u;
         if (id != WF_INVALID)
             wf_shade_path(a, w, lds_mats, cam, id, cur_base + (unsigned)i, light_accepted, push_ext, push_sh, requeue, ro, rd, rsd, st2, st3, st4, has4, rays);
-        const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mp = me | ms | __ballot(requeue);
+        const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mq = __ballot(requeue), mp = me | ms | mq;
+        const unsigned long long mv = __ballot(id != WF_INVALID);
         unsigned br = 0, bp = 0;
         if (lane == 0) {
+            if (mv & ~mq) *moved = 1u;  // a path was shaded or closed (not merely carried over behind a parked ray): the trip guard's sign of life
             if (mp) {
                 br = atomicAdd(n_rays_next, (unsigned)(__popcll(me) + __popcll(ms)));
                 bp = atomicAdd(n_paths_next, (unsigned)__popcll(mp));
@@ -2056,7 +2017,17 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         }
         // a parked ray's path has moved: the forwarding address goes where the ray left its mark -- the lane reads it when it resumes (wg_traverse_phase), before this
         // set is written again -- and the ray ends the next traverse phase finished or parked again: either way it writes the hit record at the new index
+#ifdef GLRTX_FAULT_INJECT
+        // Test build only (libglrtx_fault.so, tests/test_gpu_guard.py): the forwarding address is LOST -- the parked ray finds a poison value and is dropped without
+        // writing anything (wg_traverse_phase), and the path finds the parked-ray mark at its new position for ever.  Every access stays inside the buffers; what
+        // the build shows is that the trip guards of pt_render_wgwf turn such a slip into a failed launch instead of a kernel that never ends.
+        if (requeue) {
+            *w.H(cur_base + (unsigned)i) = make_float4(kHitSuspended, __uint_as_float(kFaultPoison), 0.f, 0.f);
+            *w.H(sidx_next) = make_float4(kHitSuspended, 0.f, 0.f, 0.f);
+        }
+#else
         if (requeue) *w.H(cur_base + (unsigned)i) = make_float4(kHitSuspended, __uint_as_float(sidx_next * 2u), 0.f, 0.f);
+#endif
         if (push_ext) {
             float4 *r = rq_next + 2 * (size_t)(br + __popcll(me & lt_mask));
             r[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(sidx_next * 2u));
@@ -2099,13 +2070,12 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
     unsigned *ctl = reinterpret_cast<unsigned *>(pl);            // 0: first new tile, 1: ray head, 2..3: nRays[2], 4..5: nPaths[2], 6: new tiles, 7: frame exhausted
+                                                                 // trip guards -- 10: a path moved this trip, 11: trips in a row in which nothing did, 12: trips since the last tile, 13: abort
     // launch constants that only the refill / camera code reads: kept in LDS, not in scalar registers (the kernel arguments alone
     // would occupy ~100 of the 102 SGPRs and spill into VGPR lanes inside the traversal loop)
     float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));      // {root_lo, root_hi}
     float *lds_cam = reinterpret_cast<float *>(pl + 16 * sizeof(unsigned) + 32);     // {c2w, s2c, aperture, focal}
     unsigned *light_bits = reinterpret_cast<unsigned *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);  // kWgPathsMax bits
-    float4 *lds_top = reinterpret_cast<float4 *>(light_bits + kWgPathsMax / 32);
-    for (int i = threadIdx.x; i < 4 * a.sc.n_top; i += kBlockThreads) lds_top[i] = a.sc.forks[i];  // top tree levels (trav_step)
     if (threadIdx.x < kCamFloats) lds_cam[threadIdx.x] = a.cam[threadIdx.x];
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
     if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
@@ -2120,7 +2090,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.x / 64 < 16)
         g_trip_log[blockIdx.x / 64][0].y = (unsigned)(__builtin_amdgcn_s_memtime() >> 4);
 #endif
-    if (threadIdx.x == 0) { ctl[2] = 0u; ctl[3] = 0u; ctl[4] = 0u; ctl[5] = 0u; ctl[7] = 0u; }
+    if (threadIdx.x == 0) { ctl[2] = 0u; ctl[3] = 0u; ctl[4] = 0u; ctl[5] = 0u; ctl[7] = 0u; ctl[10] = 0u; ctl[11] = 0u; ctl[12] = 0u; ctl[13] = 0u; }
     if (!VINE) rayQ[kWgSuspendAt + (size_t)kSuspendF4 * threadIdx.x + 3] = make_float4(0.f, 0.f, 0.f, 0.f);  // no lane holds a parked ray yet (wg_traverse_phase)
     int cur = 0;
     __syncthreads();  // materials staged, ctl initialised
@@ -2145,14 +2115,16 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
                 const int share = left > 0 ? (left + gss_div - 1) / gss_div : 1;
                 want = want < share ? want : share;
             }
-            if (want > 0 && ctl[7] == 0u) {
+            if (want > 0 && ctl[7] == 0u && ctl[13] == 0u) {
                 base = (int)atomicAdd(work_counter, (unsigned)want);
                 got = base < n_tiles ? (want < n_tiles - base ? want : n_tiles - base) : 0;
                 if (base + want >= n_tiles) ctl[7] = 1u;  // the frame has no more tiles
             }
             ctl[0] = (unsigned)base; ctl[6] = (unsigned)got;
+            ctl[12] = got > 0 ? 0u : ctl[12] + 1u;
         }
         __syncthreads();
+        if (ctl[13] != 0u) break;  // a trip guard fired at the end of the previous trip (below): the launch is reported as failed, whatever is still alive is dropped
         {
             const int got = (int)ctl[6] * 64, tile0 = (int)ctl[0];
             {   // (an opaque copy of the thread index: the compare is then formed here, not kept as a lane mask in two scalar registers across the whole loop)
@@ -2207,7 +2179,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // waves in the (memory-latency-bound) traverse phase issue ahead of waves of other workgroups that are shading:
         // their loads get going earlier (measured 1-2 %)
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_TRAVERSE);
-        wg_traverse_phase<VINE, FETCH>(a, w, lds_root, lds_top, stack, rq, n_rays, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
+        wg_traverse_phase<VINE, FETCH>(a, w, lds_root, stack, rq, n_rays, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_SHADE);
         PH_STAMP(pt1);
         __syncthreads();  // all hit records of this trip written
@@ -2218,7 +2190,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // ---- shade phase: the live paths; appends go to the other queue pair
         const WgwfKernArgs *ks = wgwf_kernargs();
         wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, light_bits, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
-                       &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], ks->w.set_base(cur, (int)blockIdx.x), ks->w.set_base(cur ^ 1, (int)blockIdx.x), rays);
+                       &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], ks->w.set_base(cur, (int)blockIdx.x), ks->w.set_base(cur ^ 1, (int)blockIdx.x), rays, &ctl[10]);
         PH_STAMP(ps1);
         __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
         PH_STAMP(ps2);
@@ -2231,7 +2203,28 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
             if (n < 64u) { lg[n] = make_uint4((unsigned)n_rays, (unsigned)n_paths, (unsigned)(pt2 - pt0), (unsigned)(ps2 - pt2)); lg[0].x = n; }
         }
 #endif
-        if (threadIdx.x == 0) { ctl[2 + cur] = 0u; ctl[4 + cur] = 0u; }
+        if (threadIdx.x == 0) {
+            ctl[2 + cur] = 0u; ctl[4 + cur] = 0u;
+            // Trip guards: every trip of a sound launch consumes queued rays or shades / closes a path (a path that waits for a parked ray is the only thing that is
+            // carried over untouched, and its ray is finished in the first trip that deals no new rays), and a path is alive for at most
+            // n_samples x (max_depth + 2) shaded trips plus the trips it spends parked -- the host's trip_limit allows 64 times that without a new tile.
+            const bool idle = n_rays == 0 && ctl[10] == 0u;
+            ctl[10] = 0u;
+            const unsigned idle_trips = idle ? ctl[11] + 1u : 0u;
+            ctl[11] = idle_trips;
+            const WgwfKernArgs *kg = wgwf_kernargs();
+            const unsigned code = idle_trips >= 2u ? 1u : (ctl[12] > (unsigned)kg->w.trip_limit ? 2u : 0u);
+            if (code != 0u) {
+                unsigned *e = kg->w.err;
+                unsigned wg;  // (moved into a vector register HERE: left to the compiler the copy is made in front of the persistent loop and costs the shade phase a register)
+                asm volatile("v_mov_b32 %0, %1" : "=v"(wg) : "s"((unsigned)blockIdx.x));
+                __hip_atomic_store(e + 1, wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(e + 2, ctl[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(e + 3, ctl[4 + (cur ^ 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(e, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                ctl[13] = 1u;
+            }
+        }
         cur ^= 1;
     }
 #ifdef GLRTX_PHASE_STATS
@@ -2256,7 +2249,6 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_tra
     unsigned *ctl = reinterpret_cast<unsigned *>(pl);
     float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));
     unsigned *light_bits = reinterpret_cast<unsigned *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
-    float4 *lds_top = reinterpret_cast<float4 *>(light_bits + kWgPathsMax / 32);
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
     if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
@@ -2271,7 +2263,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_tra
         if (t >= (unsigned)n_trips) break;
         const uint2 tr = trips[t];
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_TRAVERSE);
-        wg_traverse_phase<false, FETCH>(a, w, lds_root, lds_top, stack, log + 2 * (size_t)tr.x, (int)tr.y, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
+        wg_traverse_phase<false, FETCH>(a, w, lds_root, stack, log + 2 * (size_t)tr.x, (int)tr.y, &ctl[1], light_bits, rays, rayQ + kWgSuspendAt);
         __builtin_amdgcn_s_setprio(GLRTX_PRIO_SHADE);
         __syncthreads();
     }

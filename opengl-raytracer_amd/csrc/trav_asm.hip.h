@@ -82,30 +82,13 @@ static_assert(GLRTX_STEPS_PER_TRIP % 2 == 0, "the alternating form of the node f
 #define GLRTX_TS_END
 #endif
 
-// Measurement only (-DGLRTX_EXPERIMENT_EXTRA_LOADS=1|2): one or two MORE loads of the same record into scratch registers -- what a step
-// pays per additional vector-memory instruction on lines it fetches anyway (profiles/r03_traverse_bound.txt).
-#if defined(GLRTX_EXPERIMENT_EXTRA_LOADS) && GLRTX_EXPERIMENT_EXTRA_LOADS == 1
-#define GLRTX_X_LOADS "global_load_dwordx4 v[GLRTX_VB+16:GLRTX_VB+19], v[GLRTX_VB+15], %[base]\n\t"
-#elif defined(GLRTX_EXPERIMENT_EXTRA_LOADS) && GLRTX_EXPERIMENT_EXTRA_LOADS == 2
-#define GLRTX_X_LOADS "global_load_dwordx4 v[GLRTX_VB+16:GLRTX_VB+19], v[GLRTX_VB+15], %[base]\n\tglobal_load_dwordx2 v[GLRTX_VB+20:GLRTX_VB+21], v[GLRTX_VB+15], %[base] offset:16\n\t"
-#else
-#define GLRTX_X_LOADS
-#endif
-
-// Measurement only (-DGLRTX_EXPERIMENT_EXTRA_VALU=16|32): that many more vector multiplies per step on a scratch register.
-#define GLRTX_X_V8 "v_mul_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+16]\n\tv_mul_f32 v[GLRTX_VB+17], v[GLRTX_VB+17], v[GLRTX_VB+17]\n\tv_mul_f32 v[GLRTX_VB+18], v[GLRTX_VB+18], v[GLRTX_VB+18]\n\tv_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+19]\n\tv_mul_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], v[GLRTX_VB+16]\n\tv_mul_f32 v[GLRTX_VB+17], v[GLRTX_VB+17], v[GLRTX_VB+17]\n\tv_mul_f32 v[GLRTX_VB+18], v[GLRTX_VB+18], v[GLRTX_VB+18]\n\tv_mul_f32 v[GLRTX_VB+19], v[GLRTX_VB+19], v[GLRTX_VB+19]\n\t"
-#if defined(GLRTX_EXPERIMENT_EXTRA_VALU) && GLRTX_EXPERIMENT_EXTRA_VALU == 16
-#define GLRTX_X_VALU GLRTX_X_V8 GLRTX_X_V8
-#elif defined(GLRTX_EXPERIMENT_EXTRA_VALU) && GLRTX_EXPERIMENT_EXTRA_VALU == 32
-#define GLRTX_X_VALU GLRTX_X_V8 GLRTX_X_V8 GLRTX_X_V8 GLRTX_X_V8
-#else
-#define GLRTX_X_VALU
-#endif
+// (The step's elasticity to one or two more loads per record, or 16 / 32 more vector multiplies, was measured with hooks at this place in round 3 --
+// profiles/r03_traverse_bound.txt, r03_ab_elasticity.txt --; the hooks are gone, `git show 56bc2be:opengl-raytracer_amd/csrc/trav_asm.hip.h` has them.)
 
 // The four loads of a record return in order, a gather instruction apart (~17-25 clk each on a busy CU): the slab arithmetic of each
 // 16-byte piece starts as soon as that piece is in -- left lo, left hi, right lo, right hi -- instead of behind the last one
 // (-1.1 % per frame with two stages; GLRTX_SINGLE_WAIT restores the single s_waitcnt vmcnt(0) for A/B runs).
-#if defined(GLRTX_EXPERIMENT_EXTRA_LOADS) || defined(GLRTX_STEP_TIMING)  // (more loads in flight / the tool measures the whole wait)
+#if defined(GLRTX_STEP_TIMING)  // (the tool measures the whole wait)
 #define GLRTX_SINGLE_WAIT
 #endif
 #ifndef GLRTX_SINGLE_WAIT
@@ -186,7 +169,6 @@ static_assert(GLRTX_STEPS_PER_TRIP % 2 == 0, "the alternating form of the node f
     "v_mov_b32_dpp v[GLRTX_VB+12], v[GLRTX_VB+12] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   /* D = piece 3, from the partner */ \
     "v_mov_b32_dpp v[GLRTX_VB+13], v[GLRTX_VB+13] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
     "v_mov_b32_dpp v[GLRTX_VB+14], v[GLRTX_VB+14] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
-    GLRTX_X_VALU \
     "s_andn2_b64 exec, %[act], %[leaf]\n\t"   /* fork lanes again */ \
     "v_sub_f32 v[GLRTX_VB+8], v[GLRTX_VB+8], %[ox]\n\t"   /* right child: lo v[GLRTX_VB+8..10], hi v[GLRTX_VB+12..14] */    \
     "v_sub_f32 v[GLRTX_VB+9], v[GLRTX_VB+9], %[oy]\n\t"                                                            \
@@ -216,13 +198,12 @@ static_assert(GLRTX_STEPS_PER_TRIP % 2 == 0, "the alternating form of the node f
     "global_load_dwordx4 v[GLRTX_VB+0:GLRTX_VB+3], v[GLRTX_VB+15], %[base]\n\t"                                                                                                  \
     "global_load_dwordx4 v[GLRTX_VB+4:GLRTX_VB+7], v[GLRTX_VB+15], %[base] offset:16\n\t"                                                                                      \
     "global_load_dwordx3 v[GLRTX_VB+8:GLRTX_VB+10], v[GLRTX_VB+15], %[base] offset:32\n\t"                                                                                      \
-    "global_load_dwordx3 v[GLRTX_VB+12:GLRTX_VB+14], v[GLRTX_VB+15], %[base] offset:48\n\t"                                                                                      \
-    GLRTX_X_LOADS
+    "global_load_dwordx3 v[GLRTX_VB+12:GLRTX_VB+14], v[GLRTX_VB+15], %[base] offset:48\n\t"
 #define GLRTX_TRAV_LANE_CLASSIFY \
     "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t"                           /* lanes at a triangle */                                                      \
     "s_andn2_b64 exec, exec, %[leaf]\n\t"                               /* ---- fork arm: exec = lanes at a fork (may be none) */
 #define GLRTX_TRAV_LANE_FORK \
-    GLRTX_TS_WAIT0 GLRTX_W3 GLRTX_TS_WAIT1 GLRTX_X_VALU                                                                                                    \
+    GLRTX_TS_WAIT0 GLRTX_W3 GLRTX_TS_WAIT1                                                                                                    \
     "v_sub_f32 v[GLRTX_VB+0], v[GLRTX_VB+0], %[ox]\n\t"   /* left child: (lo - o) / d as soon as the first load is in, (hi - o) / d after the second */    \
     "v_sub_f32 v[GLRTX_VB+1], v[GLRTX_VB+1], %[oy]\n\t"                                                            \
     "v_sub_f32 v[GLRTX_VB+2], v[GLRTX_VB+2], %[oz]\n\t"                                                            \
@@ -271,15 +252,7 @@ static_assert(GLRTX_STEPS_PER_TRIP % 2 == 0, "the alternating form of the node f
     "v_min_f32 v[GLRTX_VB+16], v[GLRTX_VB+16], %[th]\n\t"                                                                                                                  \
     "v_cmp_ge_f32_e64 %[br], v[GLRTX_VB+16], v[GLRTX_VB+8]\n\t"
 #define GLRTX_TRAV_STEP_ASM_LANE GLRTX_TS_BEGIN GLRTX_TRAV_LANE_LOADS GLRTX_TRAV_LANE_CLASSIFY GLRTX_TRAV_LANE_FORK GLRTX_TRAV_STEP_TAIL
-// Measurement only (-DGLRTX_EXPERIMENT_LEAF_ALTERNATE, one record per lane, profiles/r05_lane_util.txt): a step WITHOUT the leaf arm.  The lanes at a triangle sit it out -- no fetch,
-// no arithmetic, their ray state untouched -- and are tested in the next (ordinary) step together with the lanes that reach a triangle there: the leaf arm then runs every
-// other step on about twice the lanes.  Same operations per ray in the same order (only when a lane takes its steps changes), so the image is bit-identical.
-#define GLRTX_TRAV_STEP_ASM_LANE_NOLEAF \
-    GLRTX_TS_BEGIN \
-    "v_cmp_gt_i32_e64 %[leaf], 0, %[cur]\n\t" \
-    "s_andn2_b64 exec, exec, %[leaf]\n\t"   /* the lanes at a fork only (may be none: everything below is then a no-op) */ \
-    "s_mov_b64 %[leaf], 0\n\t"             /* ... and for the rest of this step nobody is at a leaf */ \
-    GLRTX_TRAV_LANE_LOADS GLRTX_TRAV_LANE_FORK GLRTX_TRAV_STEP_TAIL
+// (A step without the leaf arm in every other step -- the leaf arm on twice the lanes -- was built in round 5: bit-identical, +6.25 %, profiles/r05_lane_util.txt; removed.)
 #define GLRTX_TRAV_STEP_TAIL \
     "v_cndmask_b32_e64 %[cur], v[GLRTX_VB+3], v[GLRTX_VB+7], %[br]\n\t"                    /* go on with the right child if it passed, else with the left */              \
     "s_or_b64 %[tmp], %[bl], %[br]\n\t"                                                                                                                \

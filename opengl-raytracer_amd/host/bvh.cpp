@@ -883,6 +883,7 @@ int glrt_bvh_lights_first(float *nodes, size_t n_nodes, const float *tri, size_t
 int glrt_bvh_reinsert(float *nodes, size_t n_nodes, int max_passes, int *max_depth_out, double *cost_out) {
     if (!nodes || n_nodes == 0) return GLRT_HOST_EINVAL;
     const int n = (int)n_nodes;
+    const std::vector<float> original(nodes, nodes + 9 * n_nodes);  // (the passes work in place)
     std::vector<int> parent((size_t)n, -1);
     auto L = [&](int i) -> float * { return nodes + 9 * (size_t)i; };
     auto is_fork = [&](int i) { return L(i)[8] < 0.0f; };
@@ -1045,9 +1046,15 @@ int glrt_bvh_reinsert(float *nodes, size_t n_nodes, int max_passes, int *max_dep
         std::memcpy(dst, src, 9 * sizeof(float));
         if (src[8] < 0.0f) { dst[6] = (float)new_of[(size_t)src[6]]; dst[7] = (float)new_of[(size_t)src[7]]; }
     }
-    std::memcpy(nodes, out.data(), out.size() * sizeof(float));
     if (cost_out) { cost_out[0] = cost0; cost_out[1] = cost_prev; }
     if (max_depth_out) *max_depth_out = max_depth;
+    // Insertion can deepen the tree.  Like every builder here the pass refuses a result the 64-entry traversal stack cannot hold (it used to hand it on, and
+    // the upload rejected it seconds later without naming the pass): the caller's tree is put back as it came in.
+    if (max_depth >= 63) {
+        std::memcpy(nodes, original.data(), original.size() * sizeof(float));
+        return GLRT_HOST_EDEPTH;
+    }
+    std::memcpy(nodes, out.data(), out.size() * sizeof(float));
     return moved_total;
 }
 

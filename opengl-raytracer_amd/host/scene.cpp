@@ -182,9 +182,12 @@ void Scene::finalize() {
                 double cost[2] = {0.0, 0.0};
                 int depth = -1;
                 const int moved = glrt_bvh_reinsert(&nodes[0].bboxMin[0], nodes.size(), 8, &depth, cost);
-                if (moved < 0) GLRT_FatalError("glrt_bvh_reinsert failed (%d)", moved);
+                if (moved == GLRT_HOST_EDEPTH) {  // the optimised tree would not fit the traversal stack: the pass has put the SAH tree back (glrt_host.h)
+                    GLRT_Info("BVH: reinsertion would deepen the tree to %d levels (the traversal stack holds 64 entries): keeping the SAH tree", depth);
+                    depth = -1;
+                } else if (moved < 0) GLRT_FatalError("glrt_bvh_reinsert failed (%d)", moved);
                 if (depth >= 0) bvhDepth_ = depth;
-                GLRT_Info("BVH: %d subtrees reinserted, summed fork area %.2f -> %.2f root areas (depth %d)", moved, cost[0], cost[1], bvhDepth_);
+                if (moved >= 0) GLRT_Info("BVH: %d subtrees reinserted, summed fork area %.2f -> %.2f root areas (depth %d)", moved, cost[0], cost[1], bvhDepth_);
             }
         } else if (kind == "lbvh" || kind == "sah-gpu") {
             glrtx_ctx *ctx = nullptr;

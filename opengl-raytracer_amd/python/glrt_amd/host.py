@@ -98,6 +98,8 @@ def reinsert(nodes, max_passes: int = 8):
     depth = C.c_int(0)
     cost = (C.c_double * 2)()
     rc = lib().glrt_bvh_reinsert(_fp(out), out.shape[0] // 3, int(max_passes), C.byref(depth), cost)
+    if rc == -3:  # GLRT_HOST_EDEPTH: the optimised tree would be deeper than the traversal stack allows; `out` is the input tree again
+        return out, -1, 0, (cost[0], cost[1])
     if rc < 0:
         raise RuntimeError(f"glrt_bvh_reinsert failed: {rc}")
     return out, depth.value, int(rc), (cost[0], cost[1])

@@ -72,9 +72,14 @@ def test_bench_self_spawns_its_ranks_and_gathers_to_root(tmp_path):
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak"
-    assert out["config"]["frames_per_step"] == 2 and out["config"]["launches"] == [2, 2, 1]
-    assert abs(out["config"]["ms_per_frame"] * 2 - out["ms_per_step"]) < 1e-3 * out["ms_per_step"] + 1e-4
+    # round 6: at N > 1 the line's `value` IS the strong figure (the same K frames whatever N is); the weak figure (N frames per step) sits in config.weak
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "strong"
+    assert out["config"]["frames_per_step"] == 1 and out["config"]["launches"] == [2, 2, 1]
+    assert out["value"] == out["scaling_strong"]["value"] and out["ms_per_step"] == out["scaling_strong"]["ms_per_frame"] == out["config"]["ms_per_frame"]
+    weak = out["config"]["weak"]
+    assert weak["frames_per_step"] == 2 and weak["value"] > 0 and abs(weak["ms_per_frame"] * 2 - weak["ms_per_step"]) < 1e-3 * weak["ms_per_step"] + 1e-4
+    assert out["config"]["shadow_search"] in ("exact", "range-limited", "unknown") and isinstance(out["config"]["env_overrides"], dict)
+    assert out["config"]["env_overrides"].get("GLRT_REHEARSAL_OUT") == str(tmp_path)  # every GLRTX_* / GLRT_* variable of the process is in the line
     assert out["value"] > 0 and out["cpu_baseline"] is None
     # weak and strong figures are both in the line; the one-GPU predictions only exist at N = 1 on a GPU
     strong = out["config"]["strong"]
@@ -127,8 +132,8 @@ def test_bench_at_eight_ranks_under_gloo(tmp_path):
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == world and out["steps"] == steps and out["scaling"] == "weak" and out["value"] > 0
-    assert out["config"]["frames_per_step"] == world and out["config"]["launches"] == [2, 1]
+    assert out["n_gpus"] == world and out["steps"] == steps and out["scaling"] == "strong" and out["value"] == out["scaling_strong"]["value"] > 0
+    assert out["config"]["frames_per_step"] == 1 and out["config"]["weak"]["frames_per_step"] == world and out["config"]["launches"] == [2, 1]
     assert out["config"]["gather_check"] == "bit-identical", out["config"]["gather_check"]
     assert out["config"]["strong"]["gather_check"] == "bit-identical" and out["config"]["strong"]["frames"] == steps
     from glrt_amd import host

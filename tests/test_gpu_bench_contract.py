@@ -1,6 +1,7 @@
 """bench.py's output contract: one JSON line with the driver's keys plus `roofline` (and the vector-memory, vector-ALU and auxiliary-kernel
 rooflines), `cpu_baseline`, the strong-scaling / predicted figures, and the check of the timed kernel's image."""
 import json
+import os
 import pathlib
 import subprocess
 import sys
@@ -23,13 +24,15 @@ def test_bench_prints_one_contract_json_line():
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 6 and out["warmup"] == 2
     assert out["unit"] == "Mrays/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
-    assert out["dtype"] == "f32" and out["data"] == "synthetic" and out["scaling"] == "weak"
+    assert out["dtype"] == "f32" and out["data"] == "synthetic" and out["scaling"] == "strong"
     assert "1920x1080" in out["metric"] and "workload" in out["config"] and "model" not in out["config"]
     assert out["value"] > 0 and out["ms_per_step"] > 0
     # value = rays of the timed frames / elapsed: consistent with ms_per_step and the exact ray count
     assert abs(out["value"] - out["config"]["rays_per_frame"] / out["ms_per_step"] / 1e3) / out["value"] < 1e-3
     cfg = out["config"]
     assert cfg["frames_per_step"] == 1 and cfg["launches"] == [3, 3] and abs(cfg["ms_per_frame"] - out["ms_per_step"]) < 1e-6
+    # round 6: which shadow search ran (glrtx_stats.shadow_limited) and every GLRTX_* / GLRT_* variable set in the process
+    assert cfg["shadow_search"] == "exact" and cfg["weak"] is None and cfg["env_overrides"] == {k: v for k, v in os.environ.items() if k.startswith(("GLRTX_", "GLRT_"))}
     # `value` counts traversed rays only; the reference's algorithm executes intersect() for the untraced ones too
     assert 0 <= cfg["rays_untraced_per_frame"] < cfg["rays_per_frame"]
     assert abs(cfg["rays_reference_equivalent_per_frame"] - cfg["rays_per_frame"] - cfg["rays_untraced_per_frame"]) < 1.0
@@ -95,7 +98,9 @@ def test_bench_two_ranks_on_one_gpu_check_what_the_collective_delivered():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     cfg = out["config"]
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and cfg["frames_per_step"] == 2 and out["value"] > 0
+    # round 6: the line's value is the strong figure; the weak one is in config.weak; the line names the shadow search and the environment switches it ran with
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and cfg["frames_per_step"] == 1 and out["value"] == out["scaling_strong"]["value"] > 0
+    assert cfg["weak"]["frames_per_step"] == 2 and cfg["weak"]["value"] > 0 and cfg["shadow_search"] == "exact" and isinstance(cfg["env_overrides"], dict)
     assert cfg["gather_check"] == "bit-identical", cfg["gather_check"]
     assert cfg["strong"]["gather_check"] == "bit-identical" and cfg["strong"]["frames"] == 6
     assert "bit-identical" in cfg["timed_kernel_image_check"]
