@@ -310,6 +310,12 @@ class GpuRenderer:
             self.dev.bind_accum(self.accum.data_ptr(), W * 16, self.accum.shape[0])
         return full
 
+    def use_own_stream(self, on):
+        """Render launches on the context's own stream (where consecutive calls feed one running launch) or back on the torch stream everything else here
+        is ordered on.  The device is idle at both switches."""
+        self.dev.sync(); self.torch.cuda.synchronize()
+        self.dev.set_stream(0 if on else self.stream.cuda_stream)
+
     def resolve_ms(self):
         """Device time of one resolve pass over the owned rows (screen.frag), ms."""
         self.dev.resolve_rgba8(2.2, True)
@@ -500,15 +506,42 @@ def main(argv=None):
         raise SystemExit("bench.py: the timed kernel's image differs from the counting kernel's image for the same steps: refusing to report a time for it")
 
     # ---- the same steps once more, one frame per launch (reported next to the headline figure; N = 1 only)
-    single = None
+    # Round 6: on the context's OWN stream -- where nothing but library calls can order work against the accumulator -- such a burst of calls runs as one fed launch (the
+    # calls behind the first publish their frames to the launch that is already running: glrtx.hip feed_append); with GLRTX_NO_FEED=1 every call is a launch of its own,
+    # overlapped with its neighbours (round 3), which is also what a render-resolve-save loop and a caller's stream get.  Both are measured, the same frames each.
+    single, single_overlapped, single_feed = None, None, None
     if world == 1 and S > 1 and not args.no_single:
-        n1 = min(args.steps, 20)
-        run(0, 8, per_launch=1)  # (untimed: every internal slot of the overlapped single-frame path has its buffers)
-        barrier()
-        t2 = time.perf_counter()
-        run(args.warmup, n1, per_launch=1)
-        barrier()
-        single = (time.perf_counter() - t2) / n1
+        n1 = max(args.steps, 48)  # (a burst: its one ramp and one drain are spread over this many frames)
+        own = hasattr(R, "use_own_stream")
+        if own:
+            R.use_own_stream(True)
+        try:
+            for leg in ("fed", "overlapped"):
+                if leg == "overlapped":
+                    if not own or "GLRTX_NO_FEED" in os.environ:
+                        continue
+                    os.environ["GLRTX_NO_FEED"] = "1"
+                try:
+                    run(0, 8, per_launch=1)  # (untimed: every internal slot has its buffers)
+                    barrier()
+                    st_a = R.stats()
+                    t2 = time.perf_counter()
+                    run(args.warmup, n1, per_launch=1)
+                    barrier()
+                    dt = (time.perf_counter() - t2) / n1
+                    st_b = R.stats()
+                finally:
+                    if leg == "overlapped":
+                        del os.environ["GLRTX_NO_FEED"]
+                if leg == "fed":
+                    single = dt
+                    single_feed = {"kernel_launches": int(st_b.kernel_launches - st_a.kernel_launches),
+                                   "frames_appended_to_a_running_launch": int(getattr(st_b, "feed_appended", 0) - getattr(st_a, "feed_appended", 0))}
+                else:
+                    single_overlapped = dt
+        finally:
+            if own:
+                R.use_own_stream(False)
 
     # ---- strong scaling (N > 1): the SAME K frames as a one-GPU run of K steps -- S frames in flight in total per launch, i.e. S / N
     # frames' worth of paths on every GPU -- and the framebuffer gathered to rank 0 after EVERY launch
@@ -852,8 +885,14 @@ def main(argv=None):
                        "steps_per_launch": S,
                        "launches": [k for _, k in launch_plan(args.steps, S)],
                        "one_launch_per_frame": None if single is None else
-                           {"ms_per_step": round(single * 1e3, 4), "value": round(traced_rays / args.steps / single / 1e6, 3),
-                            "what": "glrtx_render once per frame, back to back, one sync at the end (window.cpp:121-169's cadence)"},
+                           {"ms_per_step": round(single * 1e3, 4), "value": round(traced_rays / args.steps / single / 1e6, 3), "frames": max(args.steps, 48),
+                            "what": "glrtx_render once per frame, back to back on the context's own stream, one sync at the end (window.cpp:121-169's cadence without its per-frame "
+                                    "read-back): the calls behind the first feed the launch that is already running",
+                            **(single_feed or {}),
+                            "overlapped_launches": None if single_overlapped is None else
+                                {"ms_per_step": round(single_overlapped * 1e3, 4), "value": round(traced_rays / args.steps / single_overlapped / 1e6, 3),
+                                 "what": "the same calls with GLRTX_NO_FEED=1: one launch per call, overlapped with its neighbours (round 3) -- what a loop that resolves "
+                                         "every frame, or a caller's stream, gets"}},
                        "rays_per_frame": round(traced_rays / n_frames, 1),
                        # the reference's algorithm also executes intersect() for shadow rays whose light test cannot change the
                        # radiance (both outcomes bit-identical); those are resolved without a traversal and NOT part of `value`

@@ -55,7 +55,7 @@ extern "C" {
 #define GLRTX_EDEPTH (-4)   /* BVH needs more than the 64-entry traversal stack (raytrace.frag:284) */
 #define GLRTX_ENOMEM (-5)
 
-#define GLRTX_ABI_VERSION 9
+#define GLRTX_ABI_VERSION 10
 
 typedef struct glrtx_ctx glrtx_ctx;
 
@@ -103,8 +103,15 @@ typedef struct glrtx_stats {
     int32_t device_error_pending; /* ABI 9: 1 while a launch that FAILED on the device sits unreported in the context's launch ring: glrtx_get_stats never blocks and
                                      never consumes such a record (its rc stays GLRTX_OK and the timing fields stop advancing); the error itself -- kernel, size, frame
                                      count, device -- is returned by the next glrtx_sync, or by the launch that needs the record's slot */
-    int32_t wf_state_mib;       /* (was reserved1) MiB of path state the last wavefront launch ran on: an entry per workgroup and path-queue position, two sets of six
-                                   float4 planes -- 768 on a 256-CU device whatever the frames in flight (384 for an overlapped single-frame launch at 1080p) */
+    int32_t wf_state_mib;       /* (was reserved1) MiB of path state the last wavefront launch ran on: an entry per workgroup OF THAT LAUNCH and path-queue position, two
+                                   sets of six float4 planes -- 768 for a full grid on a 256-CU device whatever the frames in flight (384 for an overlapped single-frame
+                                   launch at 1080p), 1 for a 9x9 image (ABI 10: sized by the launch, not by the device) */
+    /* ABI 10 */
+    int32_t shadow_limited;     /* which shadow-ray search the context's launches run: 0 the reference's own closest-hit search (default: bit-exact contract), 1 the
+                                   range-limited one (glrtx_set_shadow_range_limit / GLRTX_SHADOW_LIMIT=1: outside the bit-exact contract).  bench.py prints it */
+    int32_t reserved2;
+    uint64_t feed_launches;     /* fed launches since reset_stats: launches that stayed open for the calls behind them (see glrtx_render) */
+    uint64_t feed_appended;     /* frames of glrtx_render / glrtx_render_frames calls that a launch already running took by itself instead of a launch of their own */
 } glrtx_stats;
 
 /* glrtx_stats.fallback_last: the wavefront kernel packs depth and sample index into one word of its path state */

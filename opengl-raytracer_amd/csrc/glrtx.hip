@@ -76,7 +76,27 @@ struct glrtx_ctx {
         hipEvent_t render_done = nullptr, acc_done = nullptr;
         bool used = false;
         DevBuf state, queues, planes, work;
+        // fed launches (pt_kernel.hip.h: FeedHost / FeedDev): the host-coherent block the host publishes frames in, its device address, the launch's device mirror,
+        // and the sample planes in chunks of kFeedChunkFrames frames, allocated as a burst grows and kept for the next one (chunk_bytes: what each was allocated with)
+        FeedHost *feed_h = nullptr, *feed_h_dev = nullptr;
+        DevBuf feed_d;
+        DevBuf chunks[kFeedChunks];
+        size_t chunk_bytes = 0;
     } pipe[kPipeSlots];
+    // The launch that is still OPEN: a fed launch of this context that may still be running and that the next glrtx_render / glrtx_render_frames call with the same
+    // camera appends its frames to (feed_append) instead of starting a launch of its own.  Every other entry point that orders something against the accumulator
+    // or changes what a launch depends on SEALS it (seal_feed): nothing is appended any more, the launch finishes what it has.
+    struct OpenFeed {
+        PipeSlot *slot = nullptr;
+        glrtx_params p{};       // the camera / sampling parameters the launch was started with (seed ignored)
+        int frames = 0, cap = 0;  // frames published so far / the most this launch can take
+        LaunchRec *rec = nullptr;
+        size_t frame_bytes = 0;   // sample planes of one frame
+    } open;
+    bool feed_ok = true;            // cleared when the host-coherent blocks cannot be had; GLRTX_NO_FEED=1 (read at every launch, like the other switches) turns fed launches off (A/B, tests)
+    bool last_was_render = false;   // the previous call on this context was glrtx_render / glrtx_render_frames (nothing has observed the accumulator since)
+    glrtx_params last_p{};          // ... with these parameters
+    hipEvent_t last_render_done = nullptr;  // ... and this is its render kernel's completion event (a slot's; not owned)
     unsigned pipe_next = 0;
     bool pipeline = true;           // GLRTX_NO_PIPELINE=1 switches it off (A/B)
     int pipe_share = 1;             // an overlapped launch issued while others still render takes 1 / pipe_share of the workgroup slots (GLRTX_PIPE_SHARE; 1: all)
@@ -175,7 +195,7 @@ int fold_launches(glrtx_ctx *c, bool block, unsigned keep = 0) {
             const unsigned code = c->guard_host[0], wg = c->guard_host[1], trips = c->guard_host[2], alive = c->guard_host[3];
             std::memset(c->guard_host, 0, 16);
             return fail(c, GLRTX_EDEVICE, "render launch aborted by a trip guard (%s): workgroup %u, %u trips since its last tile, %u paths alive; %s, %dx%d (%d owned rows), %d frame(s), device %d",
-                        code == 1u ? "two trips in which no ray was dealt and no path moved" : "trip limit exceeded", wg, trips, alive, r.kernel, c->width, c->height,
+                        code == 1u ? "two trips in which no ray was dealt and no path moved" : (code == 3u ? "a fed launch could neither claim a tile nor close its feed" : "trip limit exceeded"), wg, trips, alive, r.kernel, c->width, c->height,
                         c->owned_rows, r.frames, c->device);
         }
         float ms = 0.f, ms2 = 0.f;
@@ -525,44 +545,165 @@ struct DbgLastLaunch { KernelArgs a; WfArgs w; int lds, grid; float4 *queues; in
 DevBuf g_dbg_log_rays, g_dbg_log_trips;
 #endif
 
+// Frames one launch may cover: bounded by a FIXED memory budget for what a launch needs PER FRAME -- one float4 plane per sample and owned pixel -- not by what happens
+// to be free on the device, so that the launch shapes, and with them the timing, do not depend on what else runs there (path state does not count: it is addressed by
+// workgroup and queue position, 0.8 GB whatever the frames in flight), and by the 31-bit path ids (frame * pixels + pixel).  GLRTX_FRAMES_BUDGET_MB overrides the default (tests).
+// `slots`: the budget is shared by that many launches that may be in flight at once (fed launches: kFedSlots).
+int frames_cap(const glrtx_ctx *c, const glrtx_params *p, int slots) {
+    const size_t px = (size_t)((c->width + 7) / 8) * (size_t)((c->owned_rows + 7) / 8) * 64;
+    const size_t per_frame = (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
+    size_t budget = (size_t)kFramesBudgetGiB << 30;
+    if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
+    budget /= (size_t)std::max(c->budget_share, 1) * (size_t)std::max(slots, 1);
+    const size_t id_cap = (((size_t)1 << 31) - 2) / std::max<size_t>(px, 1);  // path ids (frame * pixels + pixel) stay below 2^31
+    return (int)std::max<size_t>(1, std::min<size_t>(id_cap, budget / std::max<size_t>(per_frame, 1)));
+}
+
+constexpr unsigned kFedSlots = 3;  // fed launches alternate between this many of the context's pipe slots (one renders, one drains into its accumulation pass, one is being fed)
+
+// Nothing is appended to the open launch any more (glrtx_ctx::OpenFeed).  Host side only: the launch itself closes its feed when it runs dry.
+void seal_feed(glrtx_ctx *c) {
+    c->open.slot = nullptr;
+    c->last_was_render = false;
+}
+
+bool same_camera(const glrtx_params &a, const glrtx_params &b) {
+    return std::memcmp(a.c2w, b.c2w, sizeof a.c2w) == 0 && std::memcmp(a.s2c, b.s2c, sizeof a.s2c) == 0 && std::memcmp(&a.aperture, &b.aperture, 4) == 0 &&
+           std::memcmp(&a.focal, &b.focal, 4) == 0 && a.n_samples == b.n_samples && a.max_depth == b.max_depth;
+}
+
+// The sample planes of frames [first, first + n) of the open launch: chunks of kFeedChunkFrames frames, allocated on demand -- also while the launch is running (an
+// allocation does not wait for the device; nothing is ever freed here) -- and published through the feed block.
+int feed_ensure_chunks(glrtx_ctx *c, glrtx_ctx::PipeSlot &sl, int first, int n, int cap, size_t frame_bytes) {
+    for (int k = first / kFeedChunkFrames; k <= (first + n - 1) / kFeedChunkFrames; k++) {
+        const int frames_in_chunk = std::min(kFeedChunkFrames, cap - k * kFeedChunkFrames);
+        const size_t need = (size_t)std::max(frames_in_chunk, 1) * frame_bytes;
+        if (!sl.chunks[k].p || sl.chunks[k].bytes < need) {
+            if (sl.chunks[k].p) return fail(c, GLRTX_EDEVICE, "internal: plane chunk %d of a fed launch is too small (%zu < %zu bytes)", k, sl.chunks[k].bytes, need);
+            HIP_TRY(c, hipMalloc(&sl.chunks[k].p, std::max<size_t>(need, 64)));
+            sl.chunks[k].bytes = std::max<size_t>(need, 64);
+        }
+        sl.feed_h->chunks[k] = (float4 *)sl.chunks[k].p;
+    }
+    return GLRTX_OK;
+}
+
+// Append n frames to the open launch.  Returns 1 if the launch has taken them (nothing else to do), 0 if the caller must start a launch of its own (no open launch, another
+// camera, the launch is full -- or it has closed its feed: the compare-and-swap on the published count fails).  Never an error: whatever goes wrong here, a launch can still be made.
+int feed_append(glrtx_ctx *c, const glrtx_params *p, const float *seeds_xy, int n) {
+    glrtx_ctx::OpenFeed &o = c->open;
+    if (!o.slot) return 0;
+    if (!same_camera(o.p, *p) || o.frames + n > o.cap) { o.slot = nullptr; return 0; }
+    if (feed_ensure_chunks(c, *o.slot, o.frames, n, o.cap, o.frame_bytes) != GLRTX_OK) { (void)hipGetLastError(); c->err.clear(); o.slot = nullptr; return 0; }
+    FeedHost *fh = o.slot->feed_h;
+    for (int i = 0; i < n; i++) fh->seeds[o.frames + i] = make_float2(seeds_xy[2 * i], seeds_xy[2 * i + 1]);
+    unsigned expect = (unsigned)o.frames;  // (release: seeds and chunk pointers before the count that announces them)
+    if (!__atomic_compare_exchange_n(&fh->frames_pub, &expect, (unsigned)(o.frames + n), false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) { o.slot = nullptr; return 0; }
+    o.frames += n;
+    o.rec->frames = o.frames;
+    c->st.frames_last = o.frames;
+    c->st.feed_appended += (uint64_t)n;
+    c->st.launches += (uint64_t)n;
+    c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples * (uint64_t)n;
+    c->counters_stale = c->counters_stale || c->count_rays;
+    return 1;
+}
+
 // Variant 2: one persistent launch; every workgroup runs the wavefront trips of the pixels it takes from the frame's tile counter.
 // n_frames > 1 ("frames in flight"): the launch covers n_frames consecutive frames that differ only in u_seed (seeds_xy);
 // the per-sample planes are added to the accumulator in frame order afterwards, so the result is bit-identical to
-// n_frames separate launches.
+// n_frames separate launches.  Three forms (chosen here):
+//   fed        -- on one of the context's pipe slots (own stream, state, queues, tile counter, plane chunks); the launch stays OPEN: later calls with the same camera
+//                 append their frames to it while it runs (feed_append).  Every multi-frame launch on the context's own stream, and a single-frame launch that
+//                 follows another one directly (a burst)
+//   overlapped -- a single-frame launch on a pipe slot, the frame spread over all workgroup slots in one helping, slots handed over progressively (round 3): what a
+//                 caller gets that renders, resolves and saves every frame -- the reference's loop, window.cpp:121-169 -- and any single frame on a caller's stream
+//   plain      -- on the context's stream, nothing overlaps: multi-frame launches on a caller's stream (stream order is the caller's), GLRTX_NO_PIPELINE=1
 int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, const float *seeds_xy, int n_frames) {
     KernelArgs a = a_in;
     const int tiles8_x = (c->width + 7) / 8, tiles8_y = (c->owned_rows + 7) / 8;
     const size_t total = (size_t)tiles8_x * tiles8_y * 64;
     if (total * 2 >= (size_t)INT32_MAX) return fail(c, GLRTX_EINVAL, "image too large for the wgwf variant");
-    const size_t ids = total * (size_t)n_frames;  // path id = frame * total + pixel
-    // path state: two sets of six planes, an entry per workgroup and path-queue position (WfArgs::state) -- sized for the largest grid x block_paths the launch
-    // below can choose: every workgroup slot of the device with kWgPathsMax paths (0.8 GB), or, for an overlapped single-frame launch (which spreads ONE frame over
-    // all the slots, see block_paths below), with the smallest power of two that holds its share of the frame (0.4 GB at 1080p)
-    const size_t wg_slots = (size_t)c->n_cu * GLRTX_WGWF_WAVES;
-    size_t slot_paths = 256;
-    while (slot_paths < (size_t)kWgPathsMax && wg_slots * slot_paths < ids) slot_paths *= 2;
-    const size_t slot_state_bytes = (size_t)kWfStatePlanes * wg_slots * slot_paths * sizeof(float4);
+    const size_t plane_bytes = (size_t)a.pitch_f4 * (size_t)c->owned_rows * sizeof(float4);
+    const size_t frame_bytes = (size_t)std::max(p->n_samples, 1) * plane_bytes;
+    int rc;
+    // ---- which form
+    const bool burst = c->last_was_render && c->last_render_done && same_camera(c->last_p, *p) && hipEventQuery(c->last_render_done) == hipErrorNotReady;
+    (void)hipGetLastError();
+    bool fed = c->feed_ok && std::getenv("GLRTX_NO_FEED") == nullptr && c->pipeline && c->stream == c->own_stream && p->n_samples >= 1 && seeds_xy != nullptr && (n_frames > 1 || burst);
+    int fed_cap = fed ? std::min(frames_cap(c, p, (int)kFedSlots), kFeedMaxFrames) : 0;
+    if (const char *v = std::getenv("GLRTX_FEED_CAP")) fed_cap = std::max(1, std::min(fed_cap, std::atoi(v)));  // (tests: launches that fill up)
+    if (fed && n_frames > fed_cap) fed = false;
+    bool piped = fed || (n_frames == 1 && c->pipeline && p->n_samples >= 1 && (size_t)p->n_samples * plane_bytes <= ((size_t)1 << 30));
+    const size_t ids = total * (size_t)(fed ? fed_cap : n_frames);  // path id = frame * total + pixel
     if (ids + 1 >= (size_t)UINT32_MAX)
         return fail(c, GLRTX_EINVAL, "glrtx_render_frames: %d frames of %zu pixels exceed the 32-bit ray id space", n_frames, total);
-    int rc;
-    // A single-frame launch runs on one of pipe_slots side streams with buffers of its own and hands its samples over in planes, so that the
-    // tail of one launch overlaps the head of the next (a persistent grid that holds a whole frame fills and drains slowly): what a
-    // caller that renders, resolves and saves every frame -- the reference's loop, window.cpp:121-169 -- gets without batching frames.
-    // Per pixel the additions happen in the same order (the plane-accumulation passes run on the context's stream, in launch order).
-    const size_t plane_bytes = (size_t)a.pitch_f4 * (size_t)c->owned_rows * sizeof(float4);
-    const bool piped = n_frames == 1 && c->pipeline && p->n_samples >= 1 && (size_t)p->n_samples * plane_bytes <= ((size_t)1 << 30);
-    // Which slot, and how many there may be.  A slot owns path state, per-workgroup queues and sample planes of its own (~0.8 GB at 1080p): the slots are charged to
-    // the same memory budget as the frames in flight (kFramesBudgetGiB, split between the members of a group that share this GPU), a slot whose buffers cannot
-    // be allocated is given up -- the launch then runs un-piped on the context's stream instead of failing -- and among the slots in use the next one whose
-    // previous launch has completed is taken (round robin only when none has), so that a launch never queues behind a busy slot while an idle one exists.
+
+    // ---- the kernel and how many of its workgroups fit the device.  Eight instantiations: ray counting on/off x (list scan of a vine (brute-force) tree | tree traversal
+    // with one record per lane | with the pair-cooperative node fetch | with the two in alternate steps).  The pair fetch trades 25 vector-ALU instructions per step for a
+    // third less time in the CU's vector-memory pipe (trav_asm.hip.h): it pays where a wave's lanes are spread over many records -- large trees, incoherent rays: config 5
+    // (100 k triangles) -9 % per frame -- and costs ~1 % where they share the top of a small tree (headline, 10 k triangles: the step is paced by instruction issue there),
+    // profiles/r04_ab_pair_fetch.txt.  Picked by the size of the record array; GLRTX_PAIR_FETCH=0/1 overrides.  All forms are bit-identical (same IEEE operations on the same record).
+    // On small trees the two forms in alternate steps (FETCH 2: the pipe is the busier unit in one step, the SIMDs in the next) beat both by 1.0 .. 1.3 % in round 4.
+    // Since the path state is read and written by queue position (WfArgs::state) the pipe has a fifth less to do and the plain form wins there: headline -0.7 %,
+    // config 2 -0.4 %, config 4 -1.0 % against the alternating one, the pure pair form +1.9 % (profiles/r05_state_by_position.txt).  The alternating form stays
+    // compiled in (GLRTX_PAIR_FETCH=2).  Random triangle soups prefer the pair form from 10 k triangles on (-2 %; 20 k: -4.5 %, 70 k: -7 %): what decides is how
+    // far apart a wave's rays are in the tree, which the record count only approximates.
+    using Kernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *);
+    const bool vine = c->sc.n_vine > 0;
+    int fetch = vine ? 0 : ((size_t)c->n_fork + (size_t)c->st.n_tri >= (size_t)kPairFetchMinRecords ? 1 : 0);
+    if (const char *v = std::getenv("GLRTX_PAIR_FETCH")) fetch = vine ? 0 : std::max(0, std::min(2, std::atoi(v)));
+    c->st.node_fetch_last = fetch;
+    const bool cr = c->count_rays;
+    const Kernel kernel = vine ? (cr ? (Kernel)pt_render_wgwf<true, true> : (Kernel)pt_render_wgwf<false, true>)
+                        : fetch == 2 ? (cr ? (Kernel)pt_render_wgwf<true, false, 2> : (Kernel)pt_render_wgwf<false, false, 2>)
+                        : fetch == 1 ? (cr ? (Kernel)pt_render_wgwf<true, false, 1> : (Kernel)pt_render_wgwf<false, false, 1>)
+                                     : (cr ? (Kernel)pt_render_wgwf<true, false, 0> : (Kernel)pt_render_wgwf<false, false, 0>);
+    // (north_star's "primitives staged into LDS": materials, camera block, root box and the per-lane stacks are; the top tree levels were built, measured worth
+    // nothing -- profiles/r02_lds_top.json -- and removed.)
+    const int lds = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
+                    kWgCtlWords * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block |
+                    kWgPathsMax / 8;  // light-test bits, one per path-queue position
+    if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
+    if (lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    int per_cu = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockThreads, lds));
+    // (launch_bounds' second argument is a minimum, not a cap: an instantiation with little LDS may be reported with more workgroups per CU than the buffers below are
+    //  sized for -- ADVICE round 5)
+    per_cu = std::max(1, std::min(per_cu, GLRTX_WGWF_WAVES));
+    if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));  // occupancy experiments
+    const size_t wg_slots = (size_t)c->n_cu * (size_t)per_cu;
+    const size_t queue_bytes_max = wg_slots * kWgQueueF4 * sizeof(float4);
+
+    // ---- a pipe slot (fed and overlapped launches).  A slot owns path state, per-workgroup queues and sample planes of its own (~0.8 GB at 1080p for an overlapped
+    // single frame, 1.4 GB + planes for a fed launch): the slots are charged to the same memory budget as the frames in flight (kFramesBudgetGiB, split between the members
+    // of a group that share this GPU), a slot whose buffers cannot be allocated is given up -- the launch then runs plain on the context's stream instead of failing -- and
+    // among the slots in use the next one whose previous launch has completed is taken (round robin only when none has), so that a launch never queues behind a busy slot
+    // while an idle one exists.
+    // Shapes.  plain / fed: every workgroup keeps up to kWgPathsMax paths alive, less when the launch cannot give every resident workgroup that many pixels (a fed launch is
+    // sized as if it were to take 16 frames: it may).  overlapped: the frame in ONE helping per workgroup, spread over all the slots (the smallest power of two that holds
+    // work / resident paths: 2048 at 1080p; with 1024 the workgroups come back for a second helping, 1.31 instead of 1.24 ms per frame, with 4096 half of them get
+    // nothing, 1.67), every launch has the full grid and takes its tiles without guided self-scheduling, so its workgroups do not finish together -- one that finds the
+    // tile counter exhausted and its paths dead leaves, and a workgroup of the next launch (queued on another stream) takes the slot (profiles/r03_ab_pipeline.txt).
+    auto shape = [&](bool overlapped, bool is_fed, int share, int &block_paths, int &grid) {
+        const int resident = std::max(1, per_cu / std::max(share, 1)) * c->n_cu;
+        const size_t work = total * (size_t)(is_fed ? std::max(n_frames, std::min(16, fed_cap)) : n_frames);
+        block_paths = kWgPathsMax;
+        if (overlapped) { block_paths = 256; while (block_paths < kWgPathsMax && (size_t)resident * block_paths < work) block_paths *= 2; }
+        else while (block_paths > 256 && work < (size_t)resident * block_paths) block_paths /= 2;
+        if (const char *v = std::getenv("GLRTX_BLOCK_PATHS")) { const int x = std::atoi(v); if (x >= 256 && x <= kWgPathsMax && (x & (x - 1)) == 0) block_paths = x; }
+        grid = std::max(1, (int)std::min<size_t>((size_t)resident, (work + block_paths - 1) / block_paths));
+    };
     glrtx_ctx::PipeSlot *slot = nullptr;
-    int pipe_busy = 0;
+    int pipe_busy = 0, block_paths = 0, grid = 0;
     if (piped) {
-        const size_t per_slot = slot_state_bytes + (size_t)c->n_cu * GLRTX_WGWF_WAVES * kWgQueueF4 * sizeof(float4) + (size_t)p->n_samples * plane_bytes;
+        shape(!fed, fed, 1, block_paths, grid);
+        const size_t per_slot = (size_t)kWfStatePlanes * (size_t)grid * block_paths * sizeof(float4) + (size_t)grid * kWgQueueF4 * sizeof(float4) + (fed ? 0 : frame_bytes);
         size_t budget = (size_t)kFramesBudgetGiB << 30;
         if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
         budget /= (size_t)std::max(c->budget_share, 1);
-        const unsigned allowed = (unsigned)std::min<size_t>(c->pipe_slots, budget / std::max<size_t>(per_slot, 1));
+        unsigned allowed = (unsigned)std::min<size_t>(c->pipe_slots, budget / std::max<size_t>(per_slot, 1));
+        if (fed) allowed = std::min(allowed, kFedSlots);
         c->st.pipe_slots = (int32_t)allowed;
         if (allowed >= 1) {
             unsigned pick = c->pipe_next % allowed;
@@ -573,23 +714,38 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
             (void)hipGetLastError();
             c->pipe_next = pick + 1;
             slot = &c->pipe[pick];
-            for (unsigned k = 0; k < allowed; k++)
+            for (unsigned k = 0; k < kPipeSlots; k++)
                 if (k != pick && c->pipe[k].used && hipEventQuery(c->pipe[k].render_done) == hipErrorNotReady) pipe_busy++;
             (void)hipGetLastError();
-            // the slot's buffers, before anything depends on them
-            if (ensure(c, slot->state, slot_state_bytes) != GLRTX_OK ||
-                ensure(c, slot->planes, (size_t)std::max(p->n_samples, 1) * plane_bytes) != GLRTX_OK ||
-                ensure(c, slot->queues, (size_t)c->n_cu * GLRTX_WGWF_WAVES * kWgQueueF4 * sizeof(float4)) != GLRTX_OK) {
+            if (c->pipe_share > 1 && pipe_busy > 0 && !fed) shape(true, false, c->pipe_share, block_paths, grid);  // (GLRTX_PIPE_SHARE: the round-3 form, A/B only)
+            // the slot's buffers, before anything depends on them.  A fed launch's plane chunks hold a given number of bytes per frame: another size starts afresh
+            // (the slot's last launch is waited for first: freeing memory waits for the device anyway)
+            bool ok = true;
+            // a fed launch writes the slot's feed block from the host: the slot's previous launch, which reads it, must have ended (with every fed slot busy the host
+            // waits here: it is three launches ahead of the device)
+            if (fed && slot->used) (void)hipEventSynchronize(slot->render_done);
+            if (fed && slot->chunk_bytes != frame_bytes) {
+                if (slot->used) (void)hipEventSynchronize(slot->acc_done);
+                for (auto &ch : slot->chunks) dev_free(ch);
+                std::memset(slot->feed_h->chunks, 0, sizeof slot->feed_h->chunks);
+                slot->chunk_bytes = frame_bytes;
+            }
+            ok = ok && ensure(c, slot->state, (size_t)kWfStatePlanes * (size_t)grid * block_paths * sizeof(float4)) == GLRTX_OK;
+            ok = ok && ensure(c, slot->queues, (size_t)grid * kWgQueueF4 * sizeof(float4)) == GLRTX_OK;
+            if (fed) ok = ok && ensure(c, slot->feed_d, sizeof(FeedDev)) == GLRTX_OK && feed_ensure_chunks(c, *slot, 0, n_frames, fed_cap, frame_bytes) == GLRTX_OK;
+            else ok = ok && ensure(c, slot->planes, frame_bytes) == GLRTX_OK;
+            if (!ok) {
                 (void)hipGetLastError();
                 c->err.clear();
                 if (slot->used) (void)hipEventSynchronize(slot->acc_done);
-                dev_free(slot->state); dev_free(slot->planes); dev_free(slot->queues);
-                slot->used = false;
-                // memory is what ran out: the slots behind this one give theirs back as well (they would never be picked again: pipe_slots shrinks to `pick`)
-                for (unsigned k = pick + 1; k < kPipeSlots; k++) {
+                // memory is what ran out: this slot and the ones behind it give theirs back (they would never be picked again: pipe_slots shrinks to `pick`)
+                for (unsigned k = pick; k < kPipeSlots; k++) {
                     glrtx_ctx::PipeSlot &o = c->pipe[k];
                     if (o.used) (void)hipEventSynchronize(o.acc_done);
-                    dev_free(o.state); dev_free(o.planes); dev_free(o.queues);
+                    dev_free(o.state); dev_free(o.planes); dev_free(o.queues); dev_free(o.feed_d);
+                    for (auto &ch : o.chunks) dev_free(ch);
+                    if (o.feed_h) std::memset(o.feed_h->chunks, 0, sizeof o.feed_h->chunks);
+                    o.chunk_bytes = 0;
                     o.used = false;
                 }
                 (void)hipGetLastError();
@@ -600,6 +756,11 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
                 pipe_busy = 0;
             }
         }
+        if (!slot) { piped = false; fed = false; }
+    }
+    if (!slot) {
+        if (n_frames > frames_cap(c, p, 1)) return fail(c, GLRTX_ENOMEM, "glrtx_render_frames: %d frames exceed the frames-in-flight memory budget", n_frames);
+        shape(false, false, 1, block_paths, grid);
     }
     if (slot) c->st.pipe_resident_max = std::max<int32_t>(c->st.pipe_resident_max, pipe_busy + 1);
     DevBuf &stateBuf = slot ? slot->state : c->wfState;
@@ -607,94 +768,55 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     DevBuf &planeBuf = slot ? slot->planes : c->wfPlanes;
     unsigned *const workPtr = (unsigned *)(slot ? slot->work.p : c->work.p);
     const hipStream_t rstream = slot ? slot->stream : c->stream;  // the render kernel's stream
-    const size_t state_entries = wg_slots * (slot ? slot_paths : (size_t)kWgPathsMax);
+    // path state: two sets of six planes, an entry per workgroup of THIS launch and path-queue position (WfArgs::state): 0.8 GB for a full grid with kWgPathsMax paths
+    // each, kilobytes for a small image (it used to be sized for the largest launch the device can hold, whatever the launch)
+    const size_t state_entries = (size_t)grid * (size_t)block_paths;
     const size_t state_bytes = (size_t)kWfStatePlanes * state_entries * sizeof(float4);
     if ((rc = ensure(c, stateBuf, state_bytes))) return rc;
+    if ((rc = ensure(c, queueBuf, (size_t)grid * kWgQueueF4 * sizeof(float4)))) return rc;  // per-workgroup queues
     WfArgs w;
     std::memset(&w, 0, sizeof w);
     w.state = (float4 *)stateBuf.p;
     w.ids = state_entries;  // (the plane stride)
-    c->st.wf_state_mib = (int32_t)(state_bytes >> 20);
+    c->st.wf_state_mib = (int32_t)((state_bytes + ((size_t)1 << 20) - 1) >> 20);
     w.total = (int)total;
     w.tiles8_x = tiles8_x;
     w.refill_min = kRefillMin;
     if (const char *v = std::getenv("GLRTX_REFILL_MIN")) w.refill_min = std::max(1, std::min(64, std::atoi(v)));
-    w.n_frames = n_frames;
+    w.n_frames = fed ? std::max(fed_cap, 2) : n_frames;  // (fed: the most frames the launch can take -- and > 1, so that path ids are split into frame and pixel)
     w.tiles_per_frame = (int)(total >> 6);
     const size_t plane_f4 = (size_t)a.pitch_f4 * (size_t)c->owned_rows;
     const int n_planes = n_frames * p->n_samples;
-    if (n_frames > 1) {
-        if ((rc = ensure(c, c->wfSeeds, (size_t)n_frames * sizeof(float2)))) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->wfSeeds.p, seeds_xy, (size_t)n_frames * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-        w.seeds = (const float2 *)c->wfSeeds.p;
+    if (fed) {
+        FeedHost *fh = slot->feed_h;
+        for (int i = 0; i < n_frames; i++) fh->seeds[i] = make_float2(seeds_xy[2 * i], seeds_xy[2 * i + 1]);
+        __atomic_store_n(&fh->frames_pub, (unsigned)n_frames, __ATOMIC_RELEASE);
+        w.feed_host = slot->feed_h_dev;
+        w.feed_dev = (FeedDev *)slot->feed_d.p;
+        w.feed_plane_f4 = plane_f4;
+        w.feed_margin = 64 * 4 * grid;  // where guided self-scheduling starts to taper the helpings (gss_div x 64 tiles)
+        if (const char *v = std::getenv("GLRTX_FEED_MARGIN")) w.feed_margin = std::max(0, std::atoi(v));
+    } else {
+        if (n_frames > 1) {
+            if ((rc = ensure(c, c->wfSeeds, (size_t)n_frames * sizeof(float2)))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->wfSeeds.p, seeds_xy, (size_t)n_frames * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+            w.seeds = (const float2 *)c->wfSeeds.p;
+        }
+        if (n_frames > 1 || slot) {
+            if ((rc = ensure(c, planeBuf, (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4)))) return rc;
+            w.planes = (float4 *)planeBuf.p;
+        }
     }
-    if (n_frames > 1 || slot) {
-        if ((rc = ensure(c, planeBuf, (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4)))) return rc;
-        w.planes = (float4 *)planeBuf.p;
-    }
-
-    const int lds_base = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
-                         16 * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block |
-                         kWgPathsMax / 8;  // light-test bits, one per path-queue position
-    // (north_star's "primitives staged into LDS": materials, camera block, root box and the per-lane stacks are; the top tree levels were built, measured worth
-    // nothing -- profiles/r02_lds_top.json -- and removed.)
-    const int lds = lds_base;
-    if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
-    // eight instantiations: ray counting on/off x (list scan of a vine (brute-force) tree | tree traversal with one record per lane | with the pair-cooperative
-    // node fetch | with the two in alternate steps).  The pair fetch trades 25 vector-ALU instructions per step for a third less time in the CU's vector-memory pipe
-    // (trav_asm.hip.h): it pays where a wave's lanes are spread over many records -- large trees, incoherent rays: config 5 (100 k triangles) -9 % per frame --
-    // and costs ~1 % where they share the top of a small tree (headline, 10 k triangles: the step is paced by instruction issue there), profiles/r04_ab_pair_fetch.txt.
-    // Picked by the size of the record array; GLRTX_PAIR_FETCH=0/1 overrides.  Both forms are bit-identical (same IEEE operations on the same record).
-    using Kernel = void (*)(const KernelArgs, const WfArgs, unsigned *, float4 *);
-    const bool vine = c->sc.n_vine > 0;
-    // On small trees the two forms in alternate steps (FETCH 2: the pipe is the busier unit in one step, the SIMDs in the next) beat both by 1.0 .. 1.3 % in round 4.
-    // Since the path state is read and written by queue position (WfArgs::state) the pipe has a fifth less to do and the plain form wins there: headline -0.7 %,
-    // config 2 -0.4 %, config 4 -1.0 % against the alternating one, the pure pair form +1.9 % (profiles/r05_state_by_position.txt).  The alternating form stays
-    // compiled in (GLRTX_PAIR_FETCH=2).  Random triangle soups prefer the pair form from 10 k triangles on (-2 %; 20 k: -4.5 %, 70 k: -7 %): what decides is how
-    // far apart a wave's rays are in the tree, which the record count only approximates.
-    int fetch = vine ? 0 : ((size_t)c->n_fork + (size_t)c->st.n_tri >= (size_t)kPairFetchMinRecords ? 1 : 0);
-    if (const char *v = std::getenv("GLRTX_PAIR_FETCH")) fetch = vine ? 0 : std::max(0, std::min(2, std::atoi(v)));
-    c->st.node_fetch_last = fetch;
-    const bool cr = c->count_rays;
-    const Kernel kernel = vine ? (cr ? (Kernel)pt_render_wgwf<true, true> : (Kernel)pt_render_wgwf<false, true>)
-                        : fetch == 2 ? (cr ? (Kernel)pt_render_wgwf<true, false, 2> : (Kernel)pt_render_wgwf<false, false, 2>)
-                        : fetch == 1 ? (cr ? (Kernel)pt_render_wgwf<true, false, 1> : (Kernel)pt_render_wgwf<false, false, 1>)
-                                     : (cr ? (Kernel)pt_render_wgwf<true, false, 0> : (Kernel)pt_render_wgwf<false, false, 0>);
-    if (lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    int per_cu = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockThreads, lds));
-    if (per_cu < 1) per_cu = 1;
-    if (const char *v = std::getenv("GLRTX_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));  // occupancy experiments
-    // Overlapped single-frame launches hand the CUs' workgroup slots over PROGRESSIVELY: every launch has the full grid and takes its tiles
-    // without guided self-scheduling (gss_div = 0), so its workgroups do not finish together -- one that finds the tile counter exhausted and
-    // its paths dead leaves, and a workgroup of the next launch (queued on another stream) takes the slot.  The device then holds the sparse
-    // late trips of one frame, the dense early trips of the next and the start of a third side by side: one launch per frame 1.49 -> 1.39 ms
-    // against the earlier scheme (GLRTX_PIPE_SHARE=2: a launch that finds another one rendering takes half of the slots, and all its
-    // workgroups finish together), profiles/r03_ab_pipeline.txt.
-    int share = 1;
-    if (slot && c->pipe_share > 1 && pipe_busy > 0) share = c->pipe_share;
-    // paths kept alive per workgroup: 1024, less when the launch cannot give every resident workgroup that many pixels
-    const int resident = std::max(1, per_cu / share) * c->n_cu;
-    const size_t work = total * (size_t)n_frames;
-    int block_paths = kWgPathsMax;
-    while (block_paths > 256 && work < (size_t)resident * block_paths) block_paths /= 2;
-    // ... an overlapped single-frame launch: the frame in ONE helping per workgroup, spread over all the slots (the smallest power of two that
-    // holds work / resident paths: 2048 at 1080p; with 1024 the workgroups come back for a second helping, 1.31 instead of 1.24 ms per frame,
-    // with 4096 half of them get nothing, 1.67)
-    if (slot) { block_paths = 256; while (block_paths < kWgPathsMax && (size_t)resident * block_paths < work) block_paths *= 2; }
-    if (const char *v = std::getenv("GLRTX_BLOCK_PATHS")) { const int x = std::atoi(v); if (x >= 256 && x <= kWgPathsMax && (x & (x - 1)) == 0) block_paths = x; }
     w.block_paths = block_paths;
-    const int grid = std::max(1, (int)std::min<size_t>((size_t)resident, (work + block_paths - 1) / block_paths));
-    w.gss_div = slot ? 0 : 4 * grid;  // (overlapped single-frame launches: no guided self-scheduling, see `share` above)
+    w.gss_div = (slot && !fed) ? 0 : 4 * grid;  // (overlapped single-frame launches: no guided self-scheduling, see `shape` above)
     if (const char *v = std::getenv("GLRTX_GSS_DIV")) w.gss_div = std::max(0, std::atoi(v));
     w.suspend_max = kSuspendMax;
+    if (const char *v = std::getenv("GLRTX_SUSPEND_MAX")) w.suspend_max = std::max(0, std::min(64, std::atoi(v)));
     // trip guards (pt_render_wgwf): a path is alive for at most n_samples x (max_depth + 2) shaded trips; 64 times that (parked trips, the other paths' rounds) and a
     // constant are allowed between two tiles a workgroup is given
     w.trip_limit = (int)std::min<long long>(INT32_MAX, 64ll * std::max(p->n_samples, 1) * (p->max_depth + 2) + 64);
     if (const char *v = std::getenv("GLRTX_TRIP_LIMIT")) w.trip_limit = std::max(1, std::atoi(v));
     w.err = c->guard_dev;
-    if (const char *v = std::getenv("GLRTX_SUSPEND_MAX")) w.suspend_max = std::max(0, std::min(64, std::atoi(v)));
-    if ((rc = ensure(c, queueBuf, (size_t)grid * kWgQueueF4 * sizeof(float4)))) return rc;  // per-workgroup queues
     // Shape invariants of the hand-written kernel, checked on the host before every launch (an access past one of these
     // buffers is a GPU memory fault, not an error code): every path id the launch can form indexes inside the state arrays;
     // every workgroup of the grid has its own queue slice; a slice holds both halves of the double-buffered ray queue
@@ -707,17 +829,25 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
         bool ok = slice_f4 <= kWgSuspendAt && max_id < (size_t)WF_INVALID && 2 * max_sidx + 1 < (size_t)WF_INVALID && (size_t)grid * block_paths <= state_entries &&
                   (size_t)kWfStatePlanes * state_entries * sizeof(float4) < ((size_t)1 << 32) && (block_paths & (block_paths - 1)) == 0 && block_paths >= 256 &&
                   block_paths <= kWgPathsMax && slice_f4 <= kWgQueueF4 && queueBuf.bytes >= (size_t)grid * kWgQueueF4 * sizeof(float4) &&
-                  stateBuf.bytes >= state_bytes && w.ids == state_entries && grid >= 1 && grid <= resident &&
+                  stateBuf.bytes >= state_bytes && w.ids == state_entries && grid >= 1 && (size_t)grid <= wg_slots &&
                   p->max_depth <= kWfDepthMax && p->n_samples <= kWfSampleMax && workPtr != nullptr;
-        if (n_frames > 1) ok = ok && c->wfSeeds.bytes >= (size_t)n_frames * sizeof(float2);
+        if (!fed && n_frames > 1) ok = ok && c->wfSeeds.bytes >= (size_t)n_frames * sizeof(float2);
         if (w.planes) ok = ok && planeBuf.bytes >= (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4);
-        if (!ok) return fail(c, GLRTX_EDEVICE, "internal: wgwf launch shapes inconsistent (ids %zu, max id %zu, grid %d, block_paths %d, frames %d)", ids, max_id, grid, block_paths, n_frames);
+        if (fed) ok = ok && n_frames >= 1 && n_frames <= fed_cap && fed_cap <= kFeedMaxFrames && slot->feed_d.bytes >= sizeof(FeedDev) && w.feed_host != nullptr &&
+                      slot->chunks[(n_frames - 1) / kFeedChunkFrames].p != nullptr && slot->chunk_bytes == frame_bytes;
+        if (!ok) return fail(c, GLRTX_EDEVICE, "internal: wgwf launch shapes inconsistent (ids %zu, max id %zu, grid %d of %zu slots (%d per CU), block_paths %d, frames %d, fed %d)", ids, max_id,
+                             grid, wg_slots, per_cu, block_paths, n_frames, (int)fed);
+        (void)queue_bytes_max;
     }
     glrtx_ctx::LaunchRec *rec = nullptr;
     if ((rc = next_launch_rec(c, rec))) return rc;
     // a slot's render kernel overwrites the planes its previous plane-accumulation pass (two launches ago, on the context's stream) reads
     if (slot && slot->used) HIP_TRY(c, hipStreamWaitEvent(rstream, slot->acc_done, 0));
     HIP_TRY(c, hipMemsetAsync(workPtr, 0, sizeof(unsigned), rstream));
+    if (fed) {  // the device mirror starts with the frames published so far (kernel boundary: visible to every workgroup of the render kernel)
+        hipLaunchKernelGGL(feed_prefill_kernel, dim3(1), dim3(64), 0, rstream, (FeedDev *)slot->feed_d.p, (const FeedHost *)slot->feed_h_dev, n_frames);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipEventRecord(rec->ev0, rstream));
     c->last_kernel = vine ? "pt_render_wgwf (list scan)" : "pt_render_wgwf";
     c->counters_stale = c->counters_stale || c->count_rays;
@@ -733,10 +863,12 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
         HIP_TRY(c, hipEventRecord(rec->eva, c->stream));  // (the interval evm..ev1 would include the wait for the passes queued before this one)
     }
     rec->has_eva = slot != nullptr;
-    if (w.planes && n_planes > 0) {
+    {
         const dim3 g((c->width + 63) / 64, (c->owned_rows + 3) / 4);
-        hipLaunchKernelGGL(accumulate_planes_kernel, g, dim3(256), 0, c->stream, a.accum, a.pitch_f4, c->width, c->owned_rows,
-                           (const float4 *)planeBuf.p, n_planes);
+        if (fed)
+            hipLaunchKernelGGL(accumulate_feed_kernel, g, dim3(256), 0, c->stream, a.accum, a.pitch_f4, c->width, c->owned_rows, (const FeedDev *)slot->feed_d.p, p->n_samples);
+        else if (w.planes && n_planes > 0)
+            hipLaunchKernelGGL(accumulate_planes_kernel, g, dim3(256), 0, c->stream, a.accum, a.pitch_f4, c->width, c->owned_rows, (const float4 *)planeBuf.p, n_planes);
         HIP_TRY(c, hipGetLastError());
     }
     if (slot) { HIP_TRY(c, hipEventRecord(slot->acc_done, c->stream)); slot->used = true; }
@@ -745,6 +877,12 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     c->ring_head++;
     c->st.frames_last = n_frames;
     c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples * (uint64_t)n_frames;
+    // what the next call may build on
+    c->last_render_done = slot ? slot->render_done : nullptr;
+    if (fed) {
+        c->open.slot = slot; c->open.p = *p; c->open.frames = n_frames; c->open.cap = fed_cap; c->open.rec = rec; c->open.frame_bytes = frame_bytes;
+        c->st.feed_launches++;
+    } else c->open.slot = nullptr;
     return GLRTX_OK;
 }
 
@@ -819,6 +957,15 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
             glrtx_destroy(c);
             return GLRTX_EDEVICE;
         }
+    for (auto &sl : c->pipe) {
+        if (hipHostMalloc((void **)&sl.feed_h, sizeof(FeedHost), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&sl.feed_h_dev, sl.feed_h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            c->feed_ok = false;  // no host-coherent memory: launches are never fed (they still overlap as in round 5)
+            break;
+        }
+        std::memset(sl.feed_h, 0, sizeof(FeedHost));
+    }
     c->pipeline = std::getenv("GLRTX_NO_PIPELINE") == nullptr;
     if (const char *v = std::getenv("GLRTX_PIPE_SHARE")) c->pipe_share = std::max(1, std::min(4, std::atoi(v)));
     if (const char *v = std::getenv("GLRTX_PIPE_SLOTS")) c->pipe_slots = (unsigned)std::max(1, std::min((int)kPipeSlots, std::atoi(v)));
@@ -837,7 +984,9 @@ void glrtx_destroy(glrtx_ctx *c) {
         if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
         if (sl.render_done) (void)hipEventDestroy(sl.render_done);
         if (sl.acc_done) (void)hipEventDestroy(sl.acc_done);
-        dev_free(sl.state); dev_free(sl.queues); dev_free(sl.planes); dev_free(sl.work);
+        dev_free(sl.state); dev_free(sl.queues); dev_free(sl.planes); dev_free(sl.work); dev_free(sl.feed_d);
+        for (auto &ch : sl.chunks) dev_free(ch);
+        if (sl.feed_h) (void)hipHostFree(sl.feed_h);
     }
     dev_free(c->spheres); dev_free(c->sphereMat); dev_free(c->forks); dev_free(c->nrms); dev_free(c->mats); dev_free(c->lights); dev_free(c->vine);
     dev_free(c->accum_own); dev_free(c->counter); dev_free(c->rgba8); dev_free(c->work);
@@ -862,6 +1011,7 @@ void glrtx_destroy(glrtx_ctx *c) {
 int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const float *tri, size_t n_tri, const float *mat,
                        size_t n_mat, const float *light, size_t n_light, const float *bvh, size_t n_nodes) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     Packed P;
     if (int prc = pack_scene(c, nullptr, P, vert, n_vert, tri, n_tri, mat, n_mat, light, n_light, bvh, n_nodes)) return prc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -947,6 +1097,7 @@ int glrtx_debug_pack_forks(const float *vert, size_t n_vert, const float *tri, s
 int glrtx_build_lbvh(glrtx_ctx *c, const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out, int *max_depth_out,
                      float *build_ms_out) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (!vert || !tri || !nodes_out || n_tri == 0 || n_vert == 0) return fail(c, GLRTX_EINVAL, "glrtx_build_lbvh: empty input");
     if (2 * n_tri - 1 > ((size_t)1 << 24) || n_vert > (size_t)INT32_MAX / 16)
         return fail(c, GLRTX_EINVAL, "glrtx_build_lbvh: %zu triangles: node indices must fit a float (2^24)", n_tri);
@@ -974,6 +1125,7 @@ int glrtx_build_lbvh(glrtx_ctx *c, const float *vert, size_t n_vert, const float
 int glrtx_build_bvh_sah(glrtx_ctx *c, const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out, int *max_depth_out,
                      float *build_ms_out) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (!vert || !tri || !nodes_out || n_tri == 0 || n_vert == 0) return fail(c, GLRTX_EINVAL, "glrtx_build_bvh_sah: empty input");
     if (2 * n_tri - 1 > ((size_t)1 << 24) || n_vert > (size_t)INT32_MAX / 16)
         return fail(c, GLRTX_EINVAL, "glrtx_build_bvh_sah: %zu triangles: node indices must fit a float (2^24)", n_tri);
@@ -1000,6 +1152,7 @@ int glrtx_build_bvh_sah(glrtx_ctx *c, const float *vert, size_t n_vert, const fl
 
 int glrtx_upload_spheres(glrtx_ctx *c, const float *spheres, size_t n_spheres) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (n_spheres && !spheres) return fail(c, GLRTX_EINVAL, "glrtx_upload_spheres: NULL buffer with non-zero count");
     if (n_spheres > (size_t)kMaxSpheres) return fail(c, GLRTX_EINVAL, "glrtx_upload_spheres: at most %d spheres (they are tested one by one)", kMaxSpheres);
     if (!c->have_scene) return fail(c, GLRTX_EINVAL, "glrtx_upload_spheres: upload the scene (materials) first");
@@ -1023,6 +1176,7 @@ int glrtx_upload_spheres(glrtx_ctx *c, const float *spheres, size_t n_spheres) {
 
 int glrtx_set_extensions(glrtx_ctx *c, int flags) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (flags & ~(GLRTX_EXT_DIELECTRIC | GLRTX_EXT_WHITTED)) return fail(c, GLRTX_EINVAL, "glrtx_set_extensions: unknown flag bits 0x%x", flags);
     static_assert(GLRTX_EXT_DIELECTRIC == EXT_DIELECTRIC && GLRTX_EXT_WHITTED == EXT_WHITTED, "extension flag values");
     c->ext_flags = flags;
@@ -1031,6 +1185,7 @@ int glrtx_set_extensions(glrtx_ctx *c, int flags) {
 
 int glrtx_set_partition(glrtx_ctx *c, int rank, int world, int stripe_rows) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (world < 1 || rank < 0 || rank >= world || stripe_rows < 1)
         return fail(c, GLRTX_EINVAL, "glrtx_set_partition: bad rank/world/stripe %d/%d/%d", rank, world, stripe_rows);
     if (stripe_rows % kStripeQuantum != 0)  // whole 8x8 work tiles per stripe (pixel -> row mapping itself works for any stripe height)
@@ -1049,6 +1204,7 @@ int glrtx_local_row_to_y(const glrtx_ctx *c, int r) {
 
 int glrtx_resize(glrtx_ctx *c, int width, int height) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (width < 1 || height < 1 || width > 65536 || height > 65536) return fail(c, GLRTX_EINVAL, "glrtx_resize: bad size %dx%d", width, height);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1078,6 +1234,7 @@ int glrtx_resize(glrtx_ctx *c, int width, int height) {
 
 int glrtx_clear(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (!c->accum) return fail(c, GLRTX_EINVAL, "glrtx_clear: no accumulator (call glrtx_resize first)");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemsetAsync(c->accum, 0, c->pitch_bytes * (size_t)c->owned_rows, c->stream));
@@ -1086,6 +1243,7 @@ int glrtx_clear(glrtx_ctx *c) {
 
 int glrtx_bind_accum(glrtx_ctx *c, void *device_ptr, size_t pitch_bytes, int capacity_rows) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (c->width < 1) return fail(c, GLRTX_EINVAL, "glrtx_bind_accum: call glrtx_resize first");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1107,6 +1265,7 @@ int glrtx_bind_accum(glrtx_ctx *c, void *device_ptr, size_t pitch_bytes, int cap
 
 int glrtx_set_stream(glrtx_ctx *c, void *hip_stream) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (int rc = fold_launches(c, true)) return rc;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -1115,6 +1274,7 @@ int glrtx_set_stream(glrtx_ctx *c, void *hip_stream) {
 
 int glrtx_set_variant(glrtx_ctx *c, int variant) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (variant < 0 || variant > 2) return fail(c, GLRTX_EINVAL, "glrtx_set_variant: unknown variant %d", variant);
     c->variant = variant;
     return GLRTX_OK;
@@ -1122,12 +1282,14 @@ int glrtx_set_variant(glrtx_ctx *c, int variant) {
 
 int glrtx_set_shadow_range_limit(glrtx_ctx *c, int enable) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     c->sc.shadow_limited = enable != 0 ? 1 : 0;  // read by the next launch (the scene block is copied into every launch's arguments)
     return GLRTX_OK;
 }
 
 int glrtx_count_rays(glrtx_ctx *c, int enable) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     c->count_rays = enable != 0;
     return GLRTX_OK;
 }
@@ -1144,19 +1306,17 @@ int glrtx_render_frames(glrtx_ctx *c, const glrtx_params *p, const float *seeds_
         }
         return GLRTX_OK;
     }
-    // Frames per launch are bounded by a FIXED memory budget for what a launch needs PER FRAME -- one float4 plane per sample and owned pixel -- not by what happens
-    // to be free on the device, so that the launch shapes, and with them the timing, do not depend on what else runs there.  (Path state no longer counts: it is
-    // addressed by workgroup and queue position, 0.8 GB whatever the frames in flight -- WfArgs::state; by pixel it was 96 B per pixel and frame and set the limit.)
-    // A longer request is issued as several launches of equal size, in order.  GLRTX_FRAMES_BUDGET_MB overrides the default (tests).  An allocation that fails is
-    // reported, not worked around.
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t px = (size_t)((c->width + 7) / 8) * (size_t)((c->owned_rows + 7) / 8) * 64;
-    const size_t per_frame = (size_t)std::max(p->n_samples, 1) * c->pitch_bytes * (size_t)std::max(c->owned_rows, 1);
-    size_t budget = (size_t)kFramesBudgetGiB << 30;
-    if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
-    budget /= (size_t)std::max(c->budget_share, 1);
-    const size_t id_cap = (((size_t)1 << 31) - 2) / std::max<size_t>(px, 1);  // path ids (frame * pixels + pixel) stay below 2^31
-    const int most = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, id_cap), budget / std::max<size_t>(per_frame, 1)));
+    // A launch of the same camera that is still open takes the frames itself (feed_append); otherwise they are issued as launches of at most `most` frames -- what the
+    // frames-in-flight memory budget allows (frames_cap) -- of equal size, in order; each of them stays open for the next call.  An allocation that fails is reported,
+    // not worked around.
+    if (p->n_samples >= 0 && p->max_depth >= 0 && c->have_scene && c->accum && c->owned_rows > 0 && feed_append(c, p, seeds_xy, n_frames) == 1) {
+        c->last_was_render = true; c->last_p = *p;
+        return GLRTX_OK;
+    }
+    const bool may_feed = c->feed_ok && std::getenv("GLRTX_NO_FEED") == nullptr && c->pipeline && c->stream == c->own_stream;
+    int most = std::min(n_frames, may_feed ? std::min(frames_cap(c, p, (int)kFedSlots), kFeedMaxFrames) : frames_cap(c, p, 1));
+    if (const char *v = std::getenv("GLRTX_FEED_CAP")) { if (may_feed) most = std::max(1, std::min(most, std::atoi(v))); }
     const int n_launches = (n_frames + most - 1) / most;
     const int chunk = (n_frames + n_launches - 1) / n_launches;  // equal helpings: 16 frames under a limit of 14 are 8 + 8, not 14 + 2
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
@@ -1185,6 +1345,12 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     if (!c->accum || c->width < 1) return fail(c, GLRTX_EINVAL, "glrtx_render: no accumulator (call glrtx_resize)");
     if (p->n_samples < 0 || p->max_depth < 0) return fail(c, GLRTX_EINVAL, "glrtx_render: negative n_samples/max_depth");
     HIP_TRY(c, hipSetDevice(c->device));
+    const bool wavefront = c->variant == 2 && wgwf_can_hold(p) && c->n_spheres == 0 && c->ext_flags == 0;
+    if (c->owned_rows > 0 && wavefront && c->frames_n == 1 && feed_append(c, p, p->seed, 1) == 1) {  // a launch of the same camera that is still open takes the frame itself
+        c->last_was_render = true; c->last_p = *p;
+        return GLRTX_OK;
+    }
+    if (!wavefront) seal_feed(c);
     c->st.launches++;
     if (c->owned_rows == 0) return GLRTX_OK;
 
@@ -1226,7 +1392,11 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
                               (p->n_samples > kWfSampleMax ? GLRTX_FALLBACK_SAMPLES : 0);
         c->st.fallback_launches++;
     }
-    if (variant == 2) return launch_wgwf(c, a, p, c->frames_seeds, c->frames_n);
+    if (variant == 2) {
+        const int rc = launch_wgwf(c, a, p, c->frames_n == 1 ? p->seed : c->frames_seeds, c->frames_n);
+        if (rc == GLRTX_OK) { c->last_was_render = true; c->last_p = *p; } else seal_feed(c);
+        return rc;
+    }
     glrtx_ctx::LaunchRec *rec = nullptr;
     if (int rc = next_launch_rec(c, rec)) return rc;
     if (variant == 1) {
@@ -1278,6 +1448,7 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
 
 int glrtx_sync(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->counters_stale && c->counter.p &&  // the device is idle here: bring the ray counters over now, so that glrtx_get_stats after a sync touches nothing
@@ -1288,6 +1459,7 @@ int glrtx_sync(glrtx_ctx *c) {
 
 int glrtx_read_accum(glrtx_ctx *c, float *dst, size_t dst_pitch_bytes) {
     if (!c || !dst) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (!c->accum) return fail(c, GLRTX_EINVAL, "glrtx_read_accum: no accumulator");
     const size_t row = (size_t)c->width * sizeof(float4);
     if (dst_pitch_bytes < row) return fail(c, GLRTX_EINVAL, "glrtx_read_accum: dst pitch too small");
@@ -1299,6 +1471,7 @@ int glrtx_read_accum(glrtx_ctx *c, float *dst, size_t dst_pitch_bytes) {
 
 int glrtx_accum_device_ptr(const glrtx_ctx *c, void **ptr_out, size_t *pitch_out) {
     if (!c || !ptr_out || !pitch_out) return GLRTX_EINVAL;
+    seal_feed(const_cast<glrtx_ctx *>(c));  // (the caller is about to look at the accumulator: nothing more goes into a launch that is already queued in front of that)
     *ptr_out = c->accum;
     *pitch_out = c->pitch_bytes;
     return GLRTX_OK;
@@ -1306,6 +1479,7 @@ int glrtx_accum_device_ptr(const glrtx_ctx *c, void **ptr_out, size_t *pitch_out
 
 int glrtx_resolve_rgba8(glrtx_ctx *c, uint8_t *dst, size_t dst_pitch_bytes, float gamma, int flip_y) {
     if (!c || !dst) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (!c->accum) return fail(c, GLRTX_EINVAL, "glrtx_resolve_rgba8: no accumulator");
     if (!(gamma > 0.f)) return fail(c, GLRTX_EINVAL, "glrtx_resolve_rgba8: gamma must be positive");
     if (dst_pitch_bytes < (size_t)c->width * 4) return fail(c, GLRTX_EINVAL, "glrtx_resolve_rgba8: dst pitch too small");
@@ -1344,16 +1518,18 @@ int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
         hipMemcpy(c->counters_host, c->counter.p, sizeof c->counters_host, hipMemcpyDeviceToHost) == hipSuccess)
         c->counters_stale = false;
     out->rays = c->counters_host[0]; out->rays_untraced = c->counters_host[1];
+    out->shadow_limited = c->sc.shadow_limited;
     if (have_dev && dev_before != c->device) (void)hipSetDevice(dev_before);
     return GLRTX_OK;
 }
 
 int glrtx_reset_stats(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     if (int rc = glrtx_sync(c)) return rc;
     HIP_TRY(c, hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long)));
     c->counters_host[0] = c->counters_host[1] = 0; c->counters_stale = false;
-    c->st.rays = 0; c->st.rays_untraced = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f; c->st.fallback_launches = 0; c->st.pipe_resident_max = 0;
+    c->st.rays = 0; c->st.rays_untraced = 0; c->st.paths = 0; c->st.launches = 0; c->st.kernel_launches = 0; c->st.kernel_ms_total = 0.0; c->st.accumulate_ms_total = 0.0; c->st.kernel_ms_last = 0.f; c->st.fallback_launches = 0; c->st.pipe_resident_max = 0; c->st.feed_launches = 0; c->st.feed_appended = 0;
     return GLRTX_OK;
 }
 
@@ -1480,6 +1656,7 @@ int glrtx_debug_phase_cycles(unsigned long long out[8]) {
 
 int glrtx_timer_begin(glrtx_ctx *c) {
     if (!c) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipEventRecord(c->tm0, c->stream));
     return GLRTX_OK;
@@ -1487,6 +1664,7 @@ int glrtx_timer_begin(glrtx_ctx *c) {
 
 int glrtx_timer_end(glrtx_ctx *c, float *ms) {
     if (!c || !ms) return GLRTX_EINVAL;
+    seal_feed(c);  // (nothing is appended to an open launch across this call: glrtx_ctx::OpenFeed)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipEventRecord(c->tm1, c->stream));
     HIP_TRY(c, hipEventSynchronize(c->tm1));
@@ -1541,6 +1719,7 @@ int gsub(glrtx_group *g, int i, int rc) {
 // (Round 2 issued every stripe as its own hipMemcpyPeerAsync on the root's stream: 135 serialised copies at 1080p / 8 members.)
 // Members without peer access to the root's memory fall back to hipMemcpyPeerAsync per stripe on the root's stream.
 int group_gather(glrtx_group *g) {
+    for (glrtx_ctx *m : g->ctx) seal_feed(m);  // (the copies read the members' accumulators in stream order: nothing is appended to a launch queued in front of them)
     glrtx_ctx *r = g->ctx[0];
     if (g->width < 1) return gfail(g, GLRTX_EINVAL, "glrtx_group: call glrtx_group_resize first");
     const size_t pitch = r->pitch_bytes;

@@ -1453,6 +1453,33 @@ __global__ __launch_bounds__(kBlockThreads) void pt_render_persistent(const Kern
 // (A device-wide version of this pipeline -- one traverse and one shade kernel per trip over global
 // queues -- was built and measured first: 5.3 ms per headline frame, of which ~3.4 ms was nine
 // device-wide waits for each trip's longest ray.  The workgroup-local form below replaced it.)
+// ---- Fed launches (round 6).  A persistent launch that is still running when the host is asked for more frames of the same camera takes them itself: the host
+// PUBLISHES frames in a block of host-coherent memory (FeedHost) -- seed and sample planes first, then a compare-and-swap on frames_pub -- and a workgroup that finds few
+// tiles left LOOKS there (a system-scope load across PCIe, ~1.3 us: profiles/r06_hostfeed_probe.txt), copies what is new into the launch's device mirror (FeedDev) and
+// raises frames_known; tiles are frame-major, so the tile counter simply runs on into the new frames.  A workgroup with nothing alive and no tile left CLOSES the feed
+// with a compare-and-swap on the same word (bit 31): the host's next compare-and-swap fails and it starts a new launch.  The kernel never waits for the host: what it
+// finds published it renders, and when it runs dry it closes and drains like any other launch.  Back-to-back glrtx_render / glrtx_render_frames calls therefore run as ONE
+// launch -- one ramp and one drain per burst instead of one per call (window.cpp:121-169's cadence without its per-launch cost; glrtx.hip: feed_append).
+constexpr int kFeedMaxFrames = 1024;     // frames one fed launch can take (path ids and sample planes permitting: glrtx.hip)
+constexpr int kFeedChunkFrames = 16;     // sample planes are allocated in chunks of this many frames, as the burst grows
+constexpr int kFeedChunks = kFeedMaxFrames / kFeedChunkFrames;
+constexpr unsigned kFeedClosed = 0x80000000u;
+struct FeedHost {  // host-coherent (hipHostMallocMapped | hipHostMallocCoherent); written by the host, except for the closing bit
+    unsigned frames_pub;  // bits 0-30: frames published; bit 31: closed by the device
+    unsigned pad[31];
+    float2 seeds[kFeedMaxFrames];
+    float4 *chunks[kFeedChunks];  // sample planes of frames [16 k, 16 k + 16): [frame & 15][sample][owned_rows][pitch_f4]
+};
+// The device mirror.  Its entries are written while the kernel runs and read through the CU's vector cache like any launch's seeds: a workgroup that sees the count of
+// known frames grow invalidates that cache ONCE, before it reads any of the new entries (wg_feed_topup) -- a line fetched for a neighbouring entry earlier may still hold
+// what was there before.  (Tried first: every entry in a 128-byte line of its own -- a wave whose paths belong to twenty frames then touched twenty lines for its seeds --
+// and reads past the cache by agent-scope loads; both cost a lone launch ~1 %.)
+struct FeedDev {
+    unsigned frames_known;  // frames copied to this mirror (monotonic; agent-scope atomics); bit 31: the feed is closed and the count final
+    unsigned pad[31];
+    unsigned long long seeds[kFeedMaxFrames];  // {seed.x, seed.y} as one 64-bit word
+    unsigned long long chunks[kFeedChunks];    // device address of the chunk's planes
+};
 constexpr int kWfSetPlanes = 6;  // planes of one set of WfArgs::state (kWfStatePlanes counts both sets)
 struct WfArgs {
     // Path state: six float4-wide planes of `ids` entries each, TWICE (one set read, one written per trip), in ONE allocation (one base pointer and one stride
@@ -1489,6 +1516,11 @@ struct WfArgs {
     // (GLRTX_EDEVICE) -- and leaves the loop, so that a slip in the queue bookkeeping ends as a failed launch, not as a kernel that never ends.
     int trip_limit;
     unsigned *err;
+    // fed launches (FeedHost / FeedDev above; both null otherwise).  n_frames is then the most frames the launch can take; seeds and planes are unused.
+    FeedHost *feed_host;
+    FeedDev *feed_dev;
+    size_t feed_plane_f4;  // float4s per sample plane: owned_rows * pitch_f4
+    int feed_margin;       // a workgroup looks at the host's word when fewer than this many tiles are known ahead of the tile counter
     // Frames in flight (glrtx_render_frames): n_frames consecutive frames that differ only in u_seed run in ONE launch.
     // Path ids are frame * total + tile-order pixel id; every finished sample is stored in its own plane
     // (frame * n_samples + sample) and accumulate_planes_kernel adds the planes to the accumulator in frame order, so
@@ -1543,6 +1575,10 @@ DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, int id) {
     if (w.n_frames > 1) {
         int frame, pid;
         w.split(id, frame, pid);
+        if (w.feed_dev != nullptr) {  // fed launch: the frame's line of the device mirror
+            const nfloat2 v = ((glb_cf2)&w.feed_dev->seeds[0])[frame];
+            return make_float2(v.x, v.y);
+        }
         const nfloat2 v = ((glb_cf2)w.seeds)[frame];
         return make_float2(v.x, v.y);
     }
@@ -1552,7 +1588,15 @@ DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, int id) {
 // A finished sample: radiance() returns min(L, 100) (:558); main() adds it and counts the sample (:608-609).
 // Single frame: read-modify-write of the accumulator.  Frames in flight: the value goes to the sample's plane.
 DEV void wf_add_sample(const KernelArgs &a, const WfArgs &w, int id, int lx, int lrow, unsigned sample, float Lx, float Ly, float Lz) {
-    if (w.planes != nullptr) {  // frames in flight, or a single frame whose launch overlaps its neighbours (glrtx.hip: launch_wgwf)
+    if (w.feed_dev != nullptr) {  // fed launch: the frame's chunk of sample planes
+        int frame, pid;
+        w.split(id, frame, pid);
+        typedef __attribute__((address_space(1))) nfloat4 *glb_f4;
+        const glb_f4 chunk = (glb_f4)w.feed_dev->chunks[frame / kFeedChunkFrames];  // (a global, not a generic, address)
+        const size_t slot = (size_t)(frame % kFeedChunkFrames) * (size_t)a.n_samples + sample;
+        nfloat4 v; v.x = fmin_c(Lx, 100.0f); v.y = fmin_c(Ly, 100.0f); v.z = fmin_c(Lz, 100.0f); v.w = 1.0f;
+        __builtin_nontemporal_store(v, &chunk[slot * w.feed_plane_f4 + (size_t)lrow * (size_t)a.pitch_f4 + lx]);
+    } else if (w.planes != nullptr) {  // frames in flight, or a single frame whose launch overlaps its neighbours (glrtx.hip: launch_wgwf)
         int frame, pid;
         w.split(id, frame, pid);
         const size_t slot = (size_t)frame * (size_t)a.n_samples + sample;
@@ -1702,6 +1746,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
 #ifndef GLRTX_STEPS_PER_TRIP
 #define GLRTX_STEPS_PER_TRIP 6
 #endif
+constexpr int kWgCtlWords = 32;   // control words a workgroup keeps in LDS (pt_render_wgwf: ctl)
 constexpr int kWgPathsMax = 4096;  // most paths a workgroup keeps alive (sizes its queues); the host picks block_paths <= this so
                                    // that the launch has that many pixels for every resident workgroup
 constexpr size_t kWgSuspendAt = 8 * (size_t)kWgPathsMax + (size_t)kWgPathsMax / 2;  // float4 offset of the suspend area in a workgroup's slice
@@ -2059,6 +2104,118 @@ DEV const WgwfKernArgs *wgwf_kernargs() {
 
 DEV int wgwf_suspend_max() { return wgwf_kernargs()->w.suspend_max; }
 
+// Top-up of a FED launch (FeedHost / FeedDev), run by the workgroup's first wave in place of thread 0's part of pt_render_wgwf's top-up: the tiles known so far are
+// frames_known x tiles_per_frame; when few are left the wave looks at the host's word, copies the seeds and plane chunks of newly published frames into the device
+// mirror (a lane each) and raises frames_known.  Tiles are claimed with ONE atomic add, as in the plain top-up (a compare-and-swap loop that never over-runs the known
+// tiles was the first form: a thousand workgroups retrying on one word took a millisecond per top-up).  An add can run past the known tiles; what it claims beyond them
+// is not lost -- the tile counter runs on into frames that may yet be published -- but kept by the workgroup as its PENDING claim (ctl[16..17]) and served, before
+// anything else is claimed, once the frames it falls into are known.  A workgroup with nothing alive and nothing to serve closes the feed -- its pending claim then lies
+// beyond the last frame and is dropped -- or, if the host was quicker, looks again.
+DEV void wg_feed_topup(int kWgPaths, unsigned *ctl, int cur, unsigned *work_counter) {
+    const WgwfKernArgs *k = wgwf_kernargs();
+    FeedHost *fh = k->w.feed_host;
+    FeedDev *fd = k->w.feed_dev;
+    // Every atomic here is RELAXED: an acquire at agent scope invalidates the CU's vector cache -- once per trip and workgroup that would cost the traverse phase its BVH
+    // lines -- and nothing needs one: the counts are read past the caches by the atomics themselves, and what a count announces lies in lines no cache has seen before
+    // (FeedDev) or in host memory (read past the caches as well).  "Closed" travels in bit 31 of the same word as the count, so the two are never seen apart.
+    const int lane = threadIdx.x;
+    const int tpf = k->w.tiles_per_frame, gss_div = k->w.gss_div;
+    const int np = (int)ctl[4 + cur];
+    const bool may_take = ctl[7] == 0u && ctl[13] == 0u;
+    int want = (kWgPaths - np) >> 6;
+    unsigned kw = __hip_atomic_load(&fd->frames_known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int known = (int)(kw & ~kFeedClosed);
+    bool closed = (kw & kFeedClosed) != 0u;
+    const int done = (int)__hip_atomic_load(work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // look at the host's word when guided self-scheduling would start to taper the helpings (fewer than feed_margin = gss_div x 64 tiles known ahead): a host that keeps
+    // publishing is then always seen in time, and one that has stopped costs a load per trip for the last few trips only
+    // Only every 32nd workgroup looks -- and any workgroup that has nothing alive (it is about to close the feed): the others learn of new frames from the device mirror.
+    // A load across PCIe is cheap alone (1.3 us) but not from a thousand workgroups at once: with all of them looking every trip a lone launch ran 4 % slower.
+    unsigned wg_id = blockIdx.x;  // (opaque: the test is formed here, not kept in a scalar register across the persistent loop)
+    asm volatile("" : "+s"(wg_id));
+    const bool looker = (wg_id & 31u) == 0u || np == 0;
+    if (looker && may_take && want > 0 && !closed && known * tpf - done < k->w.feed_margin) {
+        unsigned v = 0u;
+        if (lane == 0) v = __hip_atomic_load(&fh->frames_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+        int pub = (int)(v & ~kFeedClosed);
+        pub = pub > kFeedMaxFrames ? kFeedMaxFrames : pub;
+        if (pub > known) {
+            for (int f = known + lane; f < pub; f += 64) {
+                const float sx = __hip_atomic_load(&fh->seeds[f].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), sy = __hip_atomic_load(&fh->seeds[f].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&fd->seeds[f], (unsigned long long)__float_as_uint(sx) | ((unsigned long long)__float_as_uint(sy) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int c = known / kFeedChunkFrames + lane; c <= (pub - 1) / kFeedChunkFrames; c += 64) {
+                unsigned long long ptr = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&fh->chunks[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&fd->chunks[c], ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every lane's copies have reached the L2 before the count that announces them (rare: once per new frame)
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_fetch_max(&fd->frames_known, (unsigned)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            known = pub;
+        }
+        if ((v & kFeedClosed) != 0u && pub == known) {  // closed by another workgroup, at this count
+            if (lane == 0) __hip_atomic_fetch_max(&fd->frames_known, (unsigned)known | kFeedClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            closed = true;
+        }
+    }
+    if (known != (int)ctl[18]) {  // (wave-uniform) more frames than this workgroup knew of: their seeds and chunk addresses must not come out of a stale cache line (FeedDev)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) ctl[18] = (unsigned)known;
+    }
+    if (lane != 0) return;
+    const int n_tiles = known * tpf;
+    if (want > 0 && gss_div > 0) {  // guided self-scheduling, as in the plain top-up
+        const int left = n_tiles - done;
+        const int share = left > 0 ? (left + gss_div - 1) / gss_div : 1;
+        want = want < share ? want : share;
+    }
+    int base = 0, got = 0;
+    unsigned p_lo = ctl[16], p_hi = ctl[17];  // the pending claim: tiles [p_lo, p_hi) of frames that were not known when they were claimed
+    if (may_take) {
+        if (p_lo < p_hi) {
+            const int v_hi = (int)p_hi < n_tiles ? (int)p_hi : n_tiles;
+            if ((int)p_lo < v_hi) { base = (int)p_lo; got = v_hi - (int)p_lo; p_lo += (unsigned)got; }  // (they were claimed when there was room for them, and nothing has come in since)
+        } else if (want > 0 && !closed) {
+            base = (int)atomicAdd(work_counter, (unsigned)want);
+            const int hi = base + want;
+            const int v_hi = hi < n_tiles ? hi : (base < n_tiles ? n_tiles : base);
+            got = v_hi - base;
+            if (hi > v_hi) { p_lo = (unsigned)v_hi; p_hi = (unsigned)hi; }
+        }
+    }
+    unsigned again = 0u;
+    if (may_take && got == 0 && np == 0) {
+        // nothing alive and nothing to serve: this workgroup would leave.  Close the feed first -- unless it is closed already, or the host has published more in the
+        // meantime (the compare-and-swap fails: look again; the loop in pt_render_wgwf comes straight back here)
+        if (!closed) {
+            unsigned expect = (unsigned)known;
+            if (__hip_atomic_compare_exchange_strong(&fh->frames_pub, &expect, (unsigned)known | kFeedClosed, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ||
+                expect == ((unsigned)known | kFeedClosed)) {
+                __hip_atomic_fetch_max(&fd->frames_known, (unsigned)known | kFeedClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                closed = true;
+            } else again = 1u;
+        }
+    }
+    // (bound of the look-again loop, like the trip guards of pt_render_wgwf: a host that publishes a frame every time this workgroup is about to close keeps it here, and
+    //  each such turn hands it tiles -- thousands of turns in a row without one mean the bookkeeping has slipped: report and leave)
+    const unsigned turns = again ? ctl[15] + 1u : 0u;
+    ctl[15] = turns;
+    if (turns > 4096u) {
+        unsigned *e = k->w.err;
+        __hip_atomic_store(e + 1, (unsigned)known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(e + 2, turns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(e + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(e, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ctl[13] = 1u;
+        again = 0u;
+    }
+    if (closed && (int)p_lo >= n_tiles) { ctl[7] = 1u; p_lo = p_hi = 0u; }  // closed: `known` is final, every tile below it has been claimed by someone, and what this workgroup still holds lies beyond
+    ctl[16] = p_lo; ctl[17] = p_hi;
+    ctl[0] = (unsigned)base; ctl[6] = (unsigned)got; ctl[14] = again;
+    if (np > 0) ctl[12] = got > 0 ? 0u : ctl[12] + 1u;  // (the trip guard counts trips, not looks)
+}
+
 template <bool COUNT_RAYS, bool VINE, int FETCH = 0>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgwf(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -2071,11 +2228,12 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
     unsigned *ctl = reinterpret_cast<unsigned *>(pl);            // 0: first new tile, 1: ray head, 2..3: nRays[2], 4..5: nPaths[2], 6: new tiles, 7: frame exhausted
                                                                  // trip guards -- 10: a path moved this trip, 11: trips in a row in which nothing did, 12: trips since the last tile, 13: abort
+                                                                 // fed launches -- 14: nothing to do but the feed is still open: look again, 15: such turns in a row
     // launch constants that only the refill / camera code reads: kept in LDS, not in scalar registers (the kernel arguments alone
     // would occupy ~100 of the 102 SGPRs and spill into VGPR lanes inside the traversal loop)
-    float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));      // {root_lo, root_hi}
-    float *lds_cam = reinterpret_cast<float *>(pl + 16 * sizeof(unsigned) + 32);     // {c2w, s2c, aperture, focal}
-    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);  // kWgPathsMax bits
+    float4 *lds_root = reinterpret_cast<float4 *>(pl + kWgCtlWords * sizeof(unsigned));      // {root_lo, root_hi}
+    float *lds_cam = reinterpret_cast<float *>(pl + kWgCtlWords * sizeof(unsigned) + 32);     // {c2w, s2c, aperture, focal}
+    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + kWgCtlWords * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);  // kWgPathsMax bits
     if (threadIdx.x < kCamFloats) lds_cam[threadIdx.x] = a.cam[threadIdx.x];
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
     if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
@@ -2090,7 +2248,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.x / 64 < 16)
         g_trip_log[blockIdx.x / 64][0].y = (unsigned)(__builtin_amdgcn_s_memtime() >> 4);
 #endif
-    if (threadIdx.x == 0) { ctl[2] = 0u; ctl[3] = 0u; ctl[4] = 0u; ctl[5] = 0u; ctl[7] = 0u; ctl[10] = 0u; ctl[11] = 0u; ctl[12] = 0u; ctl[13] = 0u; }
+    if (threadIdx.x == 0) { ctl[2] = 0u; ctl[3] = 0u; ctl[4] = 0u; ctl[5] = 0u; ctl[7] = 0u; ctl[10] = 0u; ctl[11] = 0u; ctl[12] = 0u; ctl[13] = 0u; ctl[14] = 0u; ctl[15] = 0u; ctl[16] = 0u; ctl[17] = 0u; ctl[18] = 0u; }
     if (!VINE) rayQ[kWgSuspendAt + (size_t)kSuspendF4 * threadIdx.x + 3] = make_float4(0.f, 0.f, 0.f, 0.f);  // no lane holds a parked ray yet (wg_traverse_phase)
     int cur = 0;
     __syncthreads();  // materials staged, ctl initialised
@@ -2099,7 +2257,11 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
         // at a time, from the frame's tile counter (one atomic per workgroup and trip).  Every trip therefore runs on a
         // (nearly) full set of rays, and workgroups finish together when the counter runs out.
         PH_STAMP(pg0);
-        if (threadIdx.x == 0) {
+        unsigned tid_topup = threadIdx.x;  // (an opaque copy, as below: the lane masks of these tests are then formed here, not held in scalar registers across the whole loop)
+        asm volatile("" : "+v"(tid_topup));
+        if (wgwf_kernargs()->w.feed_dev != nullptr) {
+            if (tid_topup < 64u) wg_feed_topup(kWgPaths, ctl, cur, work_counter);  // fed launch: the first wave (it copies what the host has published side by side)
+        } else if (tid_topup == 0u) {
             // 8x8-pixel tiles (64 consecutive tile-order ids each), frame-major; formed here from the kernarg segment, not once in front of the persistent
             // loop, for the same reason as gss_div below
             const int n_tiles = wgwf_kernargs()->w.tiles_per_frame * wgwf_kernargs()->w.n_frames;
@@ -2120,11 +2282,12 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
                 got = base < n_tiles ? (want < n_tiles - base ? want : n_tiles - base) : 0;
                 if (base + want >= n_tiles) ctl[7] = 1u;  // the frame has no more tiles
             }
-            ctl[0] = (unsigned)base; ctl[6] = (unsigned)got;
+            ctl[0] = (unsigned)base; ctl[6] = (unsigned)got; ctl[14] = 0u;
             ctl[12] = got > 0 ? 0u : ctl[12] + 1u;
         }
         __syncthreads();
         if (ctl[13] != 0u) break;  // a trip guard fired at the end of the previous trip (below): the launch is reported as failed, whatever is still alive is dropped
+        const bool look_again = ctl[14] != 0u;  // (fed launches) nothing alive, no tile, and the feed could not be closed: the host has just published more
         {
             const int got = (int)ctl[6] * 64, tile0 = (int)ctl[0];
             {   // (an opaque copy of the thread index: the compare is then formed here, not kept as a lane mask in two scalar registers across the whole loop)
@@ -2146,13 +2309,16 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
                 pq_w[k] = go ? (unsigned)id : WF_INVALID;
             }
             __syncthreads();  // everyone has read the counts
-            if (threadIdx.x == 0) { ctl[2 + cur] = (unsigned)(nr + got); ctl[4 + cur] = (unsigned)(np + got); ctl[1] = 0u; }
+            if (tid_topup == 0u) { ctl[2 + cur] = (unsigned)(nr + got); ctl[4 + cur] = (unsigned)(np + got); ctl[1] = 0u; }
         }
         __syncthreads();  // queues of `cur` complete, state stores visible in the workgroup
         PH_STAMP(pg1);
         PH_ADD(0, pg0, pg1);
         const int n_rays = (int)ctl[2 + cur], n_paths = (int)ctl[4 + cur];
-        if (n_paths == 0) break;  // nothing alive and nothing left to take
+        if (n_paths == 0) {
+            if (look_again) continue;  // (every thread read the same word behind the same barrier)
+            break;  // nothing alive and nothing left to take
+        }
         const float4 *rq = rayQ + 2 * ((size_t)cur * 2 * kWgPaths);
         const unsigned *pq = pathQ + cur * kWgPaths;
 
@@ -2203,7 +2369,9 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
             if (n < 64u) { lg[n] = make_uint4((unsigned)n_rays, (unsigned)n_paths, (unsigned)(pt2 - pt0), (unsigned)(ps2 - pt2)); lg[0].x = n; }
         }
 #endif
-        if (threadIdx.x == 0) {
+        unsigned tid_end = threadIdx.x;  // (opaque, like tid_topup)
+        asm volatile("" : "+v"(tid_end));
+        if (tid_end == 0u) {
             ctl[2 + cur] = 0u; ctl[4 + cur] = 0u;
             // Trip guards: every trip of a sound launch consumes queued rays or shades / closes a path (a path that waits for a parked ray is the only thing that is
             // carried over untouched, and its ray is finished in the first trip that deals no new rays), and a path is alive for at most
@@ -2247,8 +2415,8 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_tra
     int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
     unsigned *ctl = reinterpret_cast<unsigned *>(pl);
-    float4 *lds_root = reinterpret_cast<float4 *>(pl + 16 * sizeof(unsigned));
-    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + 16 * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
+    float4 *lds_root = reinterpret_cast<float4 *>(pl + kWgCtlWords * sizeof(unsigned));
+    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + kWgCtlWords * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
     if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
@@ -2286,6 +2454,35 @@ __global__ __launch_bounds__(256) void accumulate_planes_kernel(float4 *accum, i
         const float4 v = planes[(size_t)k * plane + at];
         acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z;
         acc.w = acc.w + 1.0f;
+    }
+    accum[at] = acc;
+}
+
+// In front of a fed launch's render kernel, on its stream: the frames the launch starts with go into the device mirror by ONE wave (left to the render kernel, every
+// workgroup would fetch them across PCIe in its first top-up: a thousand times the same reads).
+__global__ __launch_bounds__(64) void feed_prefill_kernel(FeedDev *fd, const FeedHost *fh, int n_frames) {
+    const int lane = threadIdx.x;
+    for (int f = lane; f < n_frames; f += 64) fd->seeds[f] = (unsigned long long)__float_as_uint(fh->seeds[f].x) | ((unsigned long long)__float_as_uint(fh->seeds[f].y) << 32);
+    for (int c = lane; c <= (n_frames - 1) / kFeedChunkFrames; c += 64) fd->chunks[c] = (unsigned long long)fh->chunks[c];
+    if (lane == 0) fd->frames_known = (unsigned)n_frames;
+}
+
+// The same pass behind a FED launch: the frames are however many the launch ended up taking (FeedDev::frames_known, final once the render kernel has ended) and their
+// planes lie in chunks of kFeedChunkFrames frames.  Same order of additions: frame by frame, sample by sample.
+__global__ __launch_bounds__(256) void accumulate_feed_kernel(float4 *accum, int pitch_f4, int width, int rows, const FeedDev *fd, int n_samples) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= rows) return;
+    const size_t at = (size_t)y * pitch_f4 + x, plane = (size_t)rows * pitch_f4;
+    const int n_frames = (int)(fd->frames_known & ~kFeedClosed);
+    float4 acc = accum[at];
+    for (int f = 0; f < n_frames; f++) {
+        const float4 *chunk = reinterpret_cast<const float4 *>(fd->chunks[f / kFeedChunkFrames]) + (size_t)(f % kFeedChunkFrames) * (size_t)n_samples * plane;
+        for (int k = 0; k < n_samples; k++) {
+            const float4 v = chunk[(size_t)k * plane + at];
+            acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z;
+            acc.w = acc.w + 1.0f;
+        }
     }
     accum[at] = acc;
 }

@@ -30,7 +30,8 @@ class Stats(C.Structure):
                 ("stack_entries", C.c_int32), ("lds_bytes", C.c_int32), ("n_tri", C.c_int32), ("n_fork", C.c_int32),
                 ("n_mat", C.c_int32), ("n_light", C.c_int32), ("variant_last", C.c_int32), ("fallback_last", C.c_int32),
                 ("resolve_ms_last", C.c_float), ("node_fetch_last", C.c_int32), ("fallback_launches", C.c_uint64),
-                ("pipe_slots", C.c_int32), ("pipe_resident_max", C.c_int32), ("device_error_pending", C.c_int32), ("wf_state_mib", C.c_int32)]
+                ("pipe_slots", C.c_int32), ("pipe_resident_max", C.c_int32), ("device_error_pending", C.c_int32), ("wf_state_mib", C.c_int32),
+                ("shadow_limited", C.c_int32), ("reserved2", C.c_int32), ("feed_launches", C.c_uint64), ("feed_appended", C.c_uint64)]
 
 
 EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_error", "glrtx_upload_scene", "glrtx_build_lbvh", "glrtx_build_bvh_sah",

@@ -768,8 +768,9 @@ def test_frames_in_flight_are_chunked_by_the_memory_budget(gpu_device, monkeypat
     want, _ = gpu_render(d, scene, params, frames=seeds)
     per_frame_mb = 256 * 144 * 16 / 2**20   # one float4 sample plane per frame (path state is addressed by workgroup and queue position: constant, not charged)
     assert per_frame_mb == 0.5625
-    # 1 MB: one frame per launch; 2 MB: three fit, so 7 frames go as 3 + 3 + 1; 3 MB: five fit -> equal helpings of 4 + 3; 16 GB: one launch
-    for budget_mb, launches in ((1, 7), (2, 3), (3, 2), (1 << 14, 1)):
+    # (round 6: launches on the context's own stream are fed launches, and up to three of them share the budget -- one renders, one drains, one is being fed: a third each)
+    # 3 MB: one frame per launch; 6 MB: three fit, so 7 frames go as 3 + 3 + 1; 9 MB: five fit -> equal helpings of 4 + 3; 16 GB: one launch
+    for budget_mb, launches in ((3, 7), (6, 3), (9, 2), (1 << 14, 1)):
         monkeypatch.setenv("GLRTX_FRAMES_BUDGET_MB", str(budget_mb))
         d.clear(); d.reset_stats()
         d.render_frames(params, seeds); d.sync()
@@ -783,7 +784,7 @@ def test_path_state_does_not_grow_with_the_frames_in_flight(gpu_device):
     2 and for 24 frames in flight (two sets of six float4 planes for every workgroup slot of the device x 4096 paths: 3 MiB per CU), and both launches render what
     consecutive single-frame launches render."""
     d = gpu_device
-    scene, params = scenes.config_c2(width=320, height=180, max_depth=5, subdiv=1)
+    scene, params = scenes.config_c2(width=1280, height=720, max_depth=5, subdiv=1)  # (large enough for a full grid: the state is sized by the launch's workgroups, ABI 10)
     sizes = []
     for n in (2, 24):
         seeds = _seeds(n)
@@ -811,6 +812,8 @@ def test_tiny_images_single_and_in_flight(gpu_device, w, h):
     assert_bit_equal(seq, ref, f"{w}x{h} consecutive launches")
     d.clear(); d.render_frames(params, seeds); d.sync()
     assert_bit_equal(d.read_accum(), ref, f"{w}x{h} frames in flight")
+    # the path state is sized by the workgroups this launch has, not by the device (it was 768 MiB for a 1x1 image)
+    assert 0 < d.stats().wf_state_mib <= 1, d.stats().wf_state_mib
 
 
 def test_untraced_rays_are_a_subset_and_disappear_without_lights(gpu_device):
@@ -964,11 +967,13 @@ def test_leaving_the_wavefront_kernel_is_visible_in_the_stats(gpu_device):
         d.set_variant(2)
 
 
-def test_render_calls_return_before_the_device_is_done(gpu_device):
+def test_render_calls_return_before_the_device_is_done(gpu_device, monkeypatch):
     """glrtx_render is asynchronous (include/glrtx.h): consecutive calls are enqueued without waiting for the previous launch -- the host
     returns from several 1080p launches in a fraction of the time the device needs for them -- and the per-launch kernel times are
-    folded into the stats afterwards (ring of event triples, also beyond its 16 entries)."""
+    folded into the stats afterwards (ring of event triples, also beyond its 16 entries).  (One launch per call: GLRTX_NO_FEED=1; with fed launches -- the
+    default on the context's own stream, tests/test_gpu_feed.py -- the calls of such a burst are not even launches.)"""
     import time
+    monkeypatch.setenv("GLRTX_NO_FEED", "1")
     d = gpu_device
     scene, params = scenes.config_headline()
     d.upload_scene(scene); d.set_partition(0, 1, 16); d.resize(params["width"], params["height"]); d.count_rays(False)
@@ -1000,6 +1005,7 @@ def test_overlapped_launches_next_to_a_callers_own_streams(gpu_device, monkeypat
     none at all (un-piped launches on the context's stream) -- the same image every time, never a failed render."""
     import time
     import torch
+    monkeypatch.setenv("GLRTX_NO_FEED", "1")  # (the overlapped single-frame launches themselves: what a render-resolve-save loop and a caller's stream get)
     d = gpu_device
     scene, params = scenes.config_headline()
     d.upload_scene(scene); d.set_partition(0, 1, 16); d.resize(params["width"], params["height"]); d.count_rays(False)
@@ -1046,15 +1052,19 @@ def test_overlapped_launches_next_to_a_callers_own_streams(gpu_device, monkeypat
 @BOTH_INSTANTIATIONS
 @pytest.mark.parametrize("cfg,kw", [("c2", dict(width=320, height=200, max_depth=8, n_samples=1)), ("c2", dict(width=97, height=61, max_depth=5, n_samples=3)),
                                     ("c5", dict(width=256, height=144, max_depth=4, n_samples=1, n=4000))])
-def test_many_overlapped_single_frame_launches_equal_one_launch_of_all_frames(gpu_device, cfg, kw, count_rays):
+@pytest.mark.parametrize("fed", [False, True], ids=["overlapped", "fed"])
+def test_many_overlapped_single_frame_launches_equal_one_launch_of_all_frames(gpu_device, monkeypatch, cfg, kw, count_rays, fed):
     """26 back-to-back glrtx_render calls -- the internal slots (stream, path state, queues, planes, tile counter each) come round four times,
     every launch with the full grid and without guided self-scheduling, workgroups of up to six frames resident side by side -- against the
-    same 26 frames as one glrtx_render_frames launch (itself pinned to the oracle above): accumulator and ray count, bitwise."""
+    same 26 frames as one glrtx_render_frames launch (itself pinned to the oracle above): accumulator and ray count, bitwise.  Both as 26 overlapped
+    launches (GLRTX_NO_FEED=1: round 3's form, what a caller's stream still gets) and as the default of round 6, where the calls behind the first feed a running launch."""
+    if not fed:
+        monkeypatch.setenv("GLRTX_NO_FEED", "1")
     d = gpu_device
     scene, params = scenes.CONFIGS[cfg](**kw)
     seeds = _seeds(26, start=3)
     seq, st_seq = gpu_render(d, scene, params, frames=seeds, count_rays=count_rays)
-    assert st_seq.launches == 26 and st_seq.kernel_launches == 26
+    assert st_seq.launches == 26 and (st_seq.kernel_launches == 26 if not fed else 1 <= st_seq.kernel_launches <= 26)
     d.clear(); d.reset_stats()
     d.render_frames(params, seeds); d.sync()
     assert_bit_equal(seq, d.read_accum(), f"{cfg} {kw}: 26 overlapped launches vs one launch of 26 frames")
