@@ -161,10 +161,18 @@ class GpuRenderer:
             nodes, depth, build_ms = self.dev.build_bvh_sah(scene["vert"], scene["tri"])
             nodes, lf = host.lights_first(nodes, scene["tri"], scene["mat"])
             self.scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"SAH by levels, built on the GPU in {build_ms:.2f} ms", bvh_lights_first=lf)
-        elif bvh == "sah-reinsert":  # the CPU SAH tree + insertion-based optimisation (glrt_bvh_reinsert)
+        elif bvh in ("sah-reinsert", "sah-hits", "sah-reinsert-hits"):
+            # the CPU SAH tree, optionally + insertion-based optimisation (glrt_bvh_reinsert), optionally + the children of every fork ordered by the closest hits of a
+            # calibration frame (glrtx_hit_histogram: one 480x270 frame of this camera counted by the render kernel; glrt_bvh_order_by_hits)
             from glrt_amd import scenes as _scenes
-            self.scene = _scenes.rebuild_bvh(scene, "sah-reinsert")
-            self.scene["bvh_kind"] = "sah + reinsertion (CPU)"
+            self.scene = _scenes.rebuild_bvh(scene, "sah-reinsert" if "reinsert" in bvh else "sah")
+            self.scene["bvh_kind"] = "sah + reinsertion (CPU)" if "reinsert" in bvh else "sah"
+            if bvh.endswith("-hits"):
+                self.dev.upload_scene(self.scene)
+                self.dev.resize(480, 270)
+                hist = self.dev.hit_histogram(dict(params, width=480, height=270, seed=host.frame_seed(12345)), self.scene["tri"].shape[0])
+                self.scene["bvh"], n_ex = host.order_by_hits(self.scene["bvh"], hist, self.scene["tri"], self.scene["mat"])
+                self.scene["bvh_kind"] += f" + children ordered by the hits of a calibration frame ({n_ex} forks exchanged)"
         W, H = params["width"], params["height"]
         self.params = params
         self.dev.upload_scene(self.scene)
@@ -334,7 +342,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="headline", help="headline | c2 | c3 | c4 | c5 (parity-test configs)")
-    ap.add_argument("--bvh", default="default", help="default (the config's CPU SAH tree) | lbvh (linear BVH built on the GPU, glrtx_build_lbvh) | sah-gpu (binned SAH built on the GPU, glrtx_build_bvh_sah) | sah-reinsert (the CPU SAH tree + glrt_bvh_reinsert)")
+    ap.add_argument("--bvh", default="default", help="default (the config's CPU SAH tree) | lbvh (linear BVH built on the GPU, glrtx_build_lbvh) | sah-gpu (binned SAH built on the GPU, glrtx_build_bvh_sah) | sah-reinsert (the CPU SAH tree + glrt_bvh_reinsert) | sah-hits, sah-reinsert-hits (+ every fork's children ordered by the hits of a calibration frame: glrtx_hit_histogram, glrt_bvh_order_by_hits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-llvmpipe", action="store_true", help="skip the llvmpipe leg of cpu_baseline (the repository's own GLSL port through oracle/glref)")

@@ -70,6 +70,14 @@ int glrt_bvh_build_sah_levels(const float *vert, size_t n_vert, const float *tri
  * exchanged fork change, nothing else.  mat: n_mat records of 18 floats (scene.h:28-35).  Returns the number of forks exchanged (>= 0) or GLRT_HOST_E*.
  * glrt::Scene::parse and the Python scene builder apply it after their builder (GLRT_BVH_LIGHTS_FIRST=0 leaves the builder's order). */
 int glrt_bvh_lights_first(float *nodes, size_t n_nodes, const float *tri, size_t n_tri, const float *mat, size_t n_mat);
+/* The order of a fork's children from measured hits: tri_hits[t] = closest hits triangle t collected in a calibration frame (glrtx_hit_histogram, glrtx.h); at every
+ * fork the child whose subtree collected more goes into the slot the traversal visits first (raytrace.frag:299-307).  No box and no closest hit changes; exact ties between
+ * two triangles may resolve to the other one.  Apply it last.  Returns the forks exchanged, or GLRT_HOST_E*. */
+int glrt_bvh_order_by_hits(float *nodes, size_t n_nodes, const uint32_t *tri_hits, size_t n_tri);
+/* The shadow rays' share of a calibration frame's hits, by the reference's sampling rule (raytrace.frag:341-343: a light triangle is drawn uniformly for every shaded
+ * hit): (sum of tri_hits) / (number of emitting triangles) is added to every emitting triangle.  Call it on glrtx_hit_histogram's output before glrt_bvh_order_by_hits.
+ * Returns the number of emitting triangles, or GLRT_HOST_E*. */
+int glrt_bvh_add_shadow_hits(uint32_t *tri_hits, size_t n_tri, const float *tri, const float *mat, size_t n_mat);
 /* Optimisation pass over a finished tree of any builder: every subtree is taken out and put back where the summed area of the forks' boxes grows least (insertion-based
  * optimisation, Bittner et al. 2013; host/bvh.cpp).  At most max_passes passes, stopping when one gains < 0.1 %.  The tree is renumbered in DFS pre-order.
  * cost_out (may be NULL): summed fork area / root area before [0] and after [1].  Returns the number of subtrees moved (>= 0; 0 and max_depth -1 for trees it leaves

@@ -229,6 +229,16 @@ int glrtx_accum_device_ptr(const glrtx_ctx *ctx, void **ptr_out, size_t *pitch_b
  * dst is the top image row (as written by the reference's saveCurrentFrame).  Implies a sync. */
 int glrtx_resolve_rgba8(glrtx_ctx *ctx, uint8_t *dst, size_t dst_pitch_bytes, float gamma, int flip_y);
 
+/* Profile of a calibration frame (ABI 10): hist_out[t] = how often triangle t of the uploaded scene was the closest hit of a path ray -- camera rays and bounces -- in
+ * ONE frame of `p`, rendered by the wavefront kernel into a scratch accumulator (the context's accumulator and statistics are left as they were; the call waits for the
+ * device).  n_tri must be the uploaded scene's triangle count.  Input of glrt_bvh_order_by_hits (glrt_host.h): the child that is hit more often goes into the slot the
+ * reference's traversal visits first (raytrace.frag:299-307; which child is which is the builder's choice, bvh.cpp:72-160). */
+int glrtx_hit_histogram(glrtx_ctx *ctx, const glrtx_params *p, uint32_t *hist_out, size_t n_tri);
+
+/* Measurement aid (bench.py's roofline_aux): device time of ONE launch of the resolve kernel -- screen.frag:15-25 over the owned rows -- from `reps` launches back to
+ * back between one pair of events (a single launch between two events also measures the command processor's latency on both sides). */
+int glrtx_debug_resolve_burst(glrtx_ctx *ctx, float gamma, int reps, float *ms_per_launch);
+
 int glrtx_get_stats(const glrtx_ctx *ctx, glrtx_stats *out);
 int glrtx_reset_stats(glrtx_ctx *ctx);
 

@@ -124,6 +124,9 @@ struct glrtx_ctx {
     // read -- and cleared -- when a launch is folded.
     unsigned *guard_host = nullptr, *guard_dev = nullptr;
 
+    std::vector<int> leaf_tri;  // leaf record k of the uploaded scene -> wire triangle (glrtx_hit_histogram)
+    unsigned *hit_hist_dev = nullptr;  // set only inside glrtx_hit_histogram
+
     bool count_rays = false;
     const char *last_kernel = "";  // name of the last render kernel launched (error reports)
     mutable bool counters_stale = false;          // a counting launch was issued since the device counters were last read
@@ -244,6 +247,7 @@ struct Packed {
     int root_ref = REF_ABSENT;
     int root_boxed = 0;   // the wire root is a fork: its own box (root_lo / root_hi) is tested before anything else
     int stack_need = 0;
+    std::vector<int> leaf_tri;  // leaf record k (id k + 1) -> wire triangle
 };
 
 int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert, size_t n_vert, const float *tri, size_t n_tri,
@@ -528,6 +532,7 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
 
     P.root_ref = root_ref;
     P.stack_need = stack_need;
+    P.leaf_tri.swap(leaf_tri);
     return GLRTX_OK;
 }
 
@@ -1055,6 +1060,7 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     if (std::getenv("GLRTX_NO_VINE_SCAN")) sc.n_vine = 0;  // A/B: force the generic tree traversal
     c->n_tri = (int)n_tri; c->n_fork = (int)(forks.size() / 4); c->n_mat = (int)n_mat; c->n_light = (int)n_light;
     c->have_scene = true;
+    c->leaf_tri.swap(P.leaf_tri);
     c->n_spheres = 0;  // spheres reference this scene's materials: upload them again after a new scene
     c->st.stack_entries = stack_need;
     c->st.lds_bytes = lds_bytes_for(sc);
@@ -1368,6 +1374,7 @@ int glrtx_render(glrtx_ctx *c, const glrtx_params *p) {
     a.accum = c->accum;
     a.pitch_f4 = (int)(c->pitch_bytes / sizeof(float4));
     a.ray_counter = (unsigned long long *)c->counter.p;
+    a.hit_hist = c->hit_hist_dev;  // (null outside glrtx_hit_histogram)
     a.tiles_x = (c->width + kTile - 1) / kTile;
     const int tiles_y = (c->owned_rows + kTile - 1) / kTile;
     a.n_tiles = a.tiles_x * tiles_y;
@@ -1491,9 +1498,13 @@ int glrtx_resolve_rgba8(glrtx_ctx *c, uint8_t *dst, size_t dst_pitch_bytes, floa
         HIP_TRY(c, hipMalloc(&c->rgba8.p, bytes));
         c->rgba8.bytes = bytes;
     }
-    dim3 grid((c->width + 63) / 64, (c->owned_rows + 3) / 4);
+    int per = kResolvePer;
+    if (const char *v = std::getenv("GLRTX_RESOLVE_PER")) per = std::atoi(v);  // (A/B: pixels per lane)
+    per = per == 1 || per == 4 ? per : 2;
+    const dim3 grid = resolve_grid(c->width, c->owned_rows, per);
     HIP_TRY(c, hipEventRecord(c->rs0, c->stream));
-    hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, c->stream, (const float4 *)c->accum, (int)(c->pitch_bytes / sizeof(float4)),
+    const auto rk = per == 1 ? resolve_kernel<1> : (per == 4 ? resolve_kernel<4> : resolve_kernel<2>);
+    hipLaunchKernelGGL(rk, grid, dim3(256), 0, c->stream, (const float4 *)c->accum, (int)(c->pitch_bytes / sizeof(float4)),
                        c->width, c->owned_rows, (uchar4 *)c->rgba8.p, c->width, 1.0f / gamma, flip_y ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->rs1, c->stream));
@@ -1502,6 +1513,80 @@ int glrtx_resolve_rgba8(glrtx_ctx *c, uint8_t *dst, size_t dst_pitch_bytes, floa
     HIP_TRY(c, hipMemcpy2D(dst, dst_pitch_bytes, c->rgba8.p, (size_t)c->width * 4, (size_t)c->width * 4, (size_t)c->owned_rows,
                            hipMemcpyDeviceToHost));
     return GLRTX_OK;
+}
+
+// Device time of the resolve kernel by itself: `reps` launches back to back between one pair of events, per launch.  A single launch between two events (what
+// glrtx_stats.resolve_ms_last reports) carries the command processor's latency on both sides -- ~6 us of a 15-us measurement at 1080p -- which says nothing about the kernel.
+int glrtx_debug_resolve_burst(glrtx_ctx *c, float gamma, int reps, float *ms_per_launch) {
+    if (!c || !ms_per_launch || reps < 1 || !(gamma > 0.f)) return GLRTX_EINVAL;
+    seal_feed(c);
+    if (!c->accum || c->owned_rows == 0) return fail(c, GLRTX_EINVAL, "glrtx_debug_resolve_burst: no accumulator");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = ensure(c, c->rgba8, (size_t)c->width * 4 * (size_t)c->owned_rows)) return rc;
+    int per = kResolvePer;
+    if (const char *v = std::getenv("GLRTX_RESOLVE_PER")) per = std::atoi(v);
+    per = per == 1 || per == 4 ? per : 2;
+    const dim3 grid = resolve_grid(c->width, c->owned_rows, per);
+    const auto rk = per == 1 ? resolve_kernel<1> : (per == 4 ? resolve_kernel<4> : resolve_kernel<2>);
+    for (int pass = 0; pass < 2; pass++) {  // (the first pass warms the device up)
+        HIP_TRY(c, hipEventRecord(c->rs0, c->stream));
+        for (int i = 0; i < reps; i++)
+            hipLaunchKernelGGL(rk, grid, dim3(256), 0, c->stream, (const float4 *)c->accum, (int)(c->pitch_bytes / sizeof(float4)), c->width, c->owned_rows,
+                               (uchar4 *)c->rgba8.p, c->width, 1.0f / gamma, 1);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->rs1, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->rs0, c->rs1));
+    *ms_per_launch = ms / (float)reps;
+    return GLRTX_OK;
+}
+
+// Profile of a calibration frame: how often every triangle of the uploaded scene is the CLOSEST hit of a path ray (camera rays and bounces), counted by the render
+// kernel itself while it shades one frame of `p` into a scratch accumulator -- the context's own accumulator, its statistics and its open launches are left alone.
+// What it is for: glrt_bvh_order_by_hits (glrt_host.h) puts, at every fork, the child whose subtree is hit more often into the slot the reference's traversal visits
+// first (raytrace.frag:299-307) -- a hit found early culls the sibling.  The order of a fork's children is the builder's choice (bvh.cpp:72-160); images stay the
+// reference's for the re-ordered tree (exact ties between two triangles may resolve to the other one: INTEGRATION.md).
+int glrtx_hit_histogram(glrtx_ctx *c, const glrtx_params *p, uint32_t *hist_out, size_t n_tri) {
+    if (!c || !p || !hist_out) return GLRTX_EINVAL;
+    seal_feed(c);
+    if (!c->have_scene) return fail(c, GLRTX_EINVAL, "glrtx_hit_histogram: no scene uploaded");
+    if (!c->accum || c->width < 1 || c->owned_rows < 1) return fail(c, GLRTX_EINVAL, "glrtx_hit_histogram: no image size (call glrtx_resize)");
+    if (n_tri != (size_t)c->n_tri) return fail(c, GLRTX_EINVAL, "glrtx_hit_histogram: the scene has %d triangles, room for %zu", c->n_tri, n_tri);
+    if (c->variant != 2 || !wgwf_can_hold(p) || c->n_spheres > 0 || c->ext_flags != 0) return fail(c, GLRTX_EINVAL, "glrtx_hit_histogram: wavefront kernel only");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = glrtx_sync(c)) return rc;
+    const size_t n_rec = c->leaf_tri.size() + 1;
+    DevBuf hist, scratch;
+    int rc = GLRTX_OK;
+    float4 *const accum_was = c->accum;
+    const bool pipeline_was = c->pipeline, count_was = c->count_rays;
+    const glrtx_stats st_was = c->st;
+    if ((rc = ensure(c, hist, n_rec * sizeof(unsigned))) == GLRTX_OK && (rc = ensure(c, scratch, c->pitch_bytes * (size_t)c->owned_rows)) == GLRTX_OK) {
+        hipError_t e = hipMemsetAsync(hist.p, 0, n_rec * sizeof(unsigned), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(scratch.p, 0, c->pitch_bytes * (size_t)c->owned_rows, c->stream);
+        if (e != hipSuccess) rc = fail(c, GLRTX_EDEVICE, "glrtx_hit_histogram: %s", hipGetErrorString(e));
+        if (rc == GLRTX_OK) {
+            c->accum = (float4 *)scratch.p; c->pipeline = false; c->count_rays = false; c->hit_hist_dev = (unsigned *)hist.p;  // one plain launch on the context's stream
+            rc = glrtx_render(c, p);
+            c->hit_hist_dev = nullptr; c->accum = accum_was; c->pipeline = pipeline_was; c->count_rays = count_was;
+            seal_feed(c);
+            if (rc == GLRTX_OK) rc = glrtx_sync(c);
+        }
+        if (rc == GLRTX_OK) {
+            std::vector<unsigned> h(n_rec);
+            if (hipMemcpy(h.data(), hist.p, n_rec * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, GLRTX_EDEVICE, "glrtx_hit_histogram: read-back failed");
+            else {
+                std::fill(hist_out, hist_out + n_tri, 0u);
+                for (size_t k = 0; k + 1 < n_rec; k++) hist_out[c->leaf_tri[k]] += h[k + 1];
+            }
+        }
+    }
+    dev_free(hist); dev_free(scratch);
+    const double kms = c->st.kernel_ms_total; (void)kms;
+    c->st = st_was;  // (the calibration frame is not part of the caller's statistics)
+    return rc;
 }
 
 int glrtx_get_stats(const glrtx_ctx *c, glrtx_stats *out) {
@@ -1897,8 +1982,8 @@ int glrtx_group_resolve_rgba8(glrtx_group *g, uint8_t *dst, size_t dst_pitch_byt
         GHIP_TRY(g, hipMalloc(&g->full8.p, bytes));
         g->full8.bytes = bytes;
     }
-    dim3 grid((g->width + 63) / 64, (g->height + 3) / 4);
-    hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, r->stream, (const float4 *)g->full.p, (int)(r->pitch_bytes / sizeof(float4)), g->width, g->height,
+    const dim3 grid = resolve_grid(g->width, g->height);
+    hipLaunchKernelGGL(resolve_kernel<kResolvePer>, grid, dim3(256), 0, r->stream, (const float4 *)g->full.p, (int)(r->pitch_bytes / sizeof(float4)), g->width, g->height,
                        (uchar4 *)g->full8.p, g->width, 1.0f / gamma, flip_y ? 1 : 0);
     GHIP_TRY(g, hipGetLastError());
     GHIP_TRY(g, hipStreamSynchronize(r->stream));

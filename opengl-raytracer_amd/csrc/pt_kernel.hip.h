@@ -92,6 +92,7 @@ struct KernelArgs {
     int pitch_f4;            // accumulator pitch in float4 units
     unsigned long long *ray_counter;
     int tiles_x, n_tiles;
+    unsigned *hit_hist;      // null, or (glrtx_hit_histogram: a calibration frame) a counter per leaf record: closest hits of the path rays shaded in this launch
 };
 
 #define DEV __device__ __forceinline__
@@ -1700,6 +1701,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         }
         Hit h;
         h.t = hh.x; h.tri = __float_as_int(hh.y); h.u = hh.z; h.v = hh.w;
+        if (a.hit_hist != nullptr && h.tri >= 0) atomicAdd(&a.hit_hist[h.tri], 1u);  // (a calibration frame only: glrtx_hit_histogram)
         shade_hit(a, lds_mats, rng, P, h, sh);
         if (sh.untraced) rays += (1ull << 32) + 1ull;  // counted as the reference's intersect() call, not traced (Shade::untraced)
         if (sh.ended && !sh.has_shadow) { P.Lx = sh.Lpx; P.Ly = sh.Lpy; P.Lz = sh.Lpz; }
@@ -2520,23 +2522,84 @@ DEV float rs_exp2(float t) {
     const float d = __builtin_fmaf(z, b, 1.0f);
     return scale * __builtin_fmaf(c, f, d);
 }
-DEV unsigned char rs_channel(float v, float count, float inv_gamma) {
-    float L = v / count;
-    L = (L > 0.0f) ? L : 0.0f;  // maxps(L, 0): 0 when L is NaN
-    L = (L < 1.0f) ? L : 1.0f;  // minps(L, 1)
-    float r = (L == 0.0f) ? 0.0f : rs_exp2(rs_log2(L) * inv_gamma);
+DEV unsigned char rs_finish(float L, float inv_gamma, float t) {  // t = (m - 1) / (m + 1) of rs_log2, formed by the caller
+    float r = 0.0f;
+    if (L != 0.0f) {
+        const uint32_t i = __float_as_uint(L);
+        const float ef = (float)((int)((i & 0x7f800000u) >> 23) - 127);
+        const float z = t * t, z2 = z * z;
+        const float a = __builtin_fmaf(z2, 0x1.a07ab2p-2f, 0x1.27a642p-1f);
+        const float b = __builtin_fmaf(z2, 0x1.9d062cp-2f, 0x1.ec6ff2p-1f);
+        const float c = __builtin_fmaf(z2, a, 0x1.715476p+1f);
+        const float d = __builtin_fmaf(b, z, c);
+        r = rs_exp2(__builtin_fmaf(t, d, ef) * inv_gamma);
+    }
     r = (1.0f < r) ? 1.0f : r;
     const int q = (int)__builtin_rintf(r * 255.0f);  // cvtps2dq: round to nearest even
     return (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
 }
+DEV float rs_clamp01(float L) {
+    L = (L > 0.0f) ? L : 0.0f;  // maxps(L, 0): 0 when L is NaN
+    return (L < 1.0f) ? L : 1.0f;  // minps(L, 1)
+}
+DEV unsigned char rs_channel(float v, float count, float inv_gamma) {  // the plain statement: IEEE quotients as the compiler expands them
+    const float L = rs_clamp01(v / count);
+    const float m = __uint_as_float((__float_as_uint(L) & 0x007fffffu) | 0x3f800000u);
+    return rs_finish(L, inv_gamma, (m - 1.0f) / (m + 1.0f));
+}
+// The two quotients of a channel -- v / count and (m - 1) / (m + 1) -- in the short form that is PROVED equal to the IEEE quotient (tools/ubench/quotient.hip.h,
+// tools/ubench/div_exact.hip: all 2^46 pairs of significands on the device; rcp_newton = RN(1 / b) for every normal b): q = a * r, e = fma(-b, q, a), s = fma(e, r, q),
+// valid when s is a normal number, |a| >= 2^-79 and |b| <= 2^40 -- and a numerator that is +-0 over a positive normal divisor is that zero.  The compiler's expansion
+// costs 14 vector instructions and two mode switches per quotient, six quotients a pixel: the resolve pass was paced by them, not by memory (round 6).  A wave in which any
+// lane falls outside (count = 0: a texel never rendered; a huge or non-finite sum) takes the plain statement for all its lanes.
+DEV float rs_quot(float a, float b, float r, bool &outside) {
+    const float q = a * r;
+    const float s = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    const bool zero = a == 0.0f;  // (+-0)
+    outside = outside || !(zero || (__builtin_amdgcn_class(s, 0x108) && __builtin_fabsf(a) >= 0x1p-79f));
+    return zero ? a : s;
+}
+DEV uchar4 rs_pixel(float4 v, float inv_gamma) {
+    bool outside = !(v.w >= 0x1p-126f && v.w <= 0x1p40f);  // count: a positive normal number up to 2^40 (NaN fails)
+    const float rc = rcp_newton(v.w);
+    const float Lx = rs_clamp01(rs_quot(v.x, v.w, rc, outside)), Ly = rs_clamp01(rs_quot(v.y, v.w, rc, outside)), Lz = rs_clamp01(rs_quot(v.z, v.w, rc, outside));
+    const float mx = __uint_as_float((__float_as_uint(Lx) & 0x007fffffu) | 0x3f800000u), my = __uint_as_float((__float_as_uint(Ly) & 0x007fffffu) | 0x3f800000u),
+                mz = __uint_as_float((__float_as_uint(Lz) & 0x007fffffu) | 0x3f800000u);
+    // (m - 1) / (m + 1): m in [1, 2), the divisor in [2, 3], the numerator 0 or >= 2^-23
+    const float tx = rs_quot(mx - 1.0f, mx + 1.0f, rcp_newton(mx + 1.0f), outside), ty = rs_quot(my - 1.0f, my + 1.0f, rcp_newton(my + 1.0f), outside),
+                tz = rs_quot(mz - 1.0f, mz + 1.0f, rcp_newton(mz + 1.0f), outside);
+    if (__any(outside)) return make_uchar4(rs_channel(v.x, v.w, inv_gamma), rs_channel(v.y, v.w, inv_gamma), rs_channel(v.z, v.w, inv_gamma), 255);
+    return make_uchar4(rs_finish(Lx, inv_gamma, tx), rs_finish(Ly, inv_gamma, ty), rs_finish(Lz, inv_gamma, tz), 255);
+}
+// A wave takes SEG = 64 * PER consecutive pixels of a row -- PER fully coalesced 1-KiB loads issued back to back, then the arithmetic, then PER coalesced 256-byte
+// stores.  The pass is paced by its ~250 vector instructions a pixel as much as by memory (round 6, tools/gpu_aux_roofline.py: 12.1 us at 1080p, 39.6 us at 4K per launch
+// in a train of launches; a persistent grid that fetches the next segment ahead was slower: 13.8 / 47 us; one and four pixels per lane: 12.8 / 45 and 13.6 / 41).
+template <int PER>
 __global__ __launch_bounds__(256) void resolve_kernel(const float4 *accum, int pitch_f4, int width, int rows,
                                                       uchar4 *out, int out_pitch_px, float inv_gamma, int flip) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= width || y >= rows) return;
-    const float4 v = accum[(size_t)y * pitch_f4 + x];
+    constexpr int SEG = 64 * PER;
+    const int lane = threadIdx.x & 63;
+    const int segs = (width + SEG - 1) / SEG;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int y = task / segs, x0 = (task - y * segs) * SEG + lane;
+    if (y >= rows) return;
+    const float4 *row = accum + (size_t)y * pitch_f4;
+    float4 v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const int x = x0 + 64 * j;
+        v[j] = x < width ? row[x] : make_float4(0.f, 0.f, 0.f, 1.f);  // (a plain load: the accumulator has just been written and sits in the last-level cache; read non-temporally the pass took 15 instead of 12 us)
+    }
     const int oy = flip ? rows - 1 - y : y;
-    out[(size_t)oy * out_pitch_px + x] = make_uchar4(rs_channel(v.x, v.w, inv_gamma), rs_channel(v.y, v.w, inv_gamma), rs_channel(v.z, v.w, inv_gamma), 255);
+    uchar4 *orow = out + (size_t)oy * out_pitch_px;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const int x = x0 + 64 * j;
+        const uchar4 px = rs_pixel(v[j], inv_gamma);  // (every lane of the wave: rs_pixel votes)
+        if (x < width) orow[x] = px;
+    }
 }
+constexpr int kResolvePer = 2;
+inline dim3 resolve_grid(int width, int rows, int per = kResolvePer) { return dim3((unsigned)(((size_t)((width + 64 * per - 1) / (64 * per)) * (size_t)rows + 3) / 4)); }
 
 }  // namespace glrtx

@@ -870,6 +870,75 @@ int glrt_bvh_lights_first(float *nodes, size_t n_nodes, const float *tri, size_t
     return swapped;
 }
 
+// The order of a fork's children from MEASURED hits (round 6): tri_hits[t] = how often triangle t was a path ray's closest hit in a calibration frame
+// (glrtx_hit_histogram: the render kernel counts them while it shades).  At every fork with two children the one whose subtree collected more hits goes into the y slot --
+// the one the reference's traversal visits first (raytrace.frag:299-307): a ray that finds its hit there culls the sibling's box, or most of what is inside it.  Forks whose
+// subtrees were hit equally often (no ray came there at all, usually) keep the builder's order.  Like glrt_bvh_lights_first this changes no box and no closest hit; which
+// of two EXACTLY tied triangles a ray reports can change.  Apply it after every other pass (glrt_bvh_lights_first included: where one child holds the
+// only lights it usually also collects the hits -- and if it does not, the measured order is the better one for the rays that were counted).
+// Returns the number of forks whose children were exchanged, or a negative GLRT_HOST_E* code for a malformed tree.
+int glrt_bvh_order_by_hits(float *nodes, size_t n_nodes, const uint32_t *tri_hits, size_t n_tri) {
+    if (!nodes || n_nodes == 0) return 0;
+    if (!tri_hits) return GLRT_HOST_EINVAL;
+    std::vector<char> seen(n_nodes, 0);
+    std::vector<size_t> order, st{0};
+    order.reserve(n_nodes);
+    while (!st.empty()) {
+        const size_t i = st.back();
+        st.pop_back();
+        if (i >= n_nodes || seen[i]) return GLRT_HOST_EINVAL;
+        seen[i] = 1;
+        order.push_back(i);
+        const float *N = nodes + 9 * i;
+        if (N[8] < 0.0f)
+            for (int k = 6; k <= 7; k++)
+                if (N[k] >= 0.0f) st.push_back((size_t)N[k]);
+    }
+    std::vector<uint64_t> hits(n_nodes, 0);
+    int swapped = 0;
+    for (size_t q = order.size(); q-- > 0;) {  // children before parents
+        const size_t i = order[q];
+        float *N = nodes + 9 * i;
+        if (N[8] >= 0.0f) {
+            const size_t t = (size_t)N[8];
+            hits[i] = t < n_tri ? tri_hits[t] : 0;
+            continue;
+        }
+        const bool hx = N[6] >= 0.0f, hy = N[7] >= 0.0f;
+        const uint64_t ax = hx ? hits[(size_t)N[6]] : 0, ay = hy ? hits[(size_t)N[7]] : 0;
+        hits[i] = ax + ay;
+        if (hx && hy && ax > ay) { std::swap(N[6], N[7]); swapped++; }
+    }
+    return swapped;
+}
+
+// glrtx_hit_histogram counts the closest hits of PATH rays.  Every hit that is shaded also sends a shadow ray to a light triangle drawn uniformly (raytrace.frag:341-343),
+// and half of all rays are such rays: their share is added here by that rule -- (all counted hits) / (number of light triangles) to every emitting triangle -- so that
+// glrt_bvh_order_by_hits weighs the side of a fork the shadow rays end in as well (on a Cornell-box scene they are what decides: without them the measured order undid
+// glrt_bvh_lights_first and the frame took 2-4 % longer).  Returns the number of emitting triangles.
+int glrt_bvh_add_shadow_hits(uint32_t *tri_hits, size_t n_tri, const float *tri, const float *mat, size_t n_mat) {
+    if (!tri_hits || !tri || !mat) return GLRT_HOST_EINVAL;
+    std::vector<char> emits(n_mat, 0);
+    for (size_t m = 0; m < n_mat; m++) {
+        const float *e = mat + 18 * m + 3;
+        emits[m] = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) != 0.0f;
+    }
+    uint64_t total = 0;
+    size_t n_light = 0;
+    for (size_t t = 0; t < n_tri; t++) {
+        total += tri_hits[t];
+        const float fm = tri[4 * t + 3];
+        if (fm >= 0.0f && (size_t)fm < n_mat && emits[(size_t)fm]) n_light++;
+    }
+    if (n_light == 0) return 0;
+    const uint64_t share = total / n_light;
+    for (size_t t = 0; t < n_tri; t++) {
+        const float fm = tri[4 * t + 3];
+        if (fm >= 0.0f && (size_t)fm < n_mat && emits[(size_t)fm]) tri_hits[t] = (uint32_t)std::min<uint64_t>(UINT32_MAX, (uint64_t)tri_hits[t] + share);
+    }
+    return (int)n_light;
+}
+
 // ---- Reinsertion, an optimisation pass over a finished tree (after Bittner, Hapala, Havran, "Fast insertion-based optimization of bounding volume hierarchies", CGF 2013,
 // in the per-node form of Meister & Bittner 2018).  A top-down SAH build decides every split once, greedily; afterwards each subtree N is taken out (its parent's slot P is
 // freed, the sibling moves up) and put back where the tree's summed box area grows least: a branch-and-bound search over all positions X, cost(X) = area(X u N) + the

@@ -14,7 +14,7 @@
 using namespace glrt;
 
 static void usage(const char *exe) {
-    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--bvh sah|sah-reinsert|sah-gpu|lbvh|sah-levels-cpu|lbvh-cpu] [--out file.png] [--save-every-frame] [--device G | --gpus N | --devices a,b,..] [--extensions] [--whitted]\n"
+    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--bvh sah|sah-reinsert|sah-gpu|lbvh|sah-levels-cpu|lbvh-cpu] [--order-by-hits] [--out file.png] [--save-every-frame] [--device G | --gpus N | --devices a,b,..] [--extensions] [--whitted]\n"
                 "  -i, --input             scene description (JSON; schema: SURVEY.md Appendix C)            [required]\n"
                 "  -s, --sample-per-cycle  accepted for compatibility; like the reference (main.cpp:13) it is not read\n"
                 "      --max-depth D       u_maxDepth (default 16, the reference shader's default)\n"
@@ -22,6 +22,7 @@ static void usage(const char *exe) {
                 "      --frames F          frames to accumulate before exiting (default 16)\n"
                 "      --frames-in-flight B frames per launch of the render kernel (default 16; same pixels as 1)\n"
                 "      --bvh KIND          sah (CPU, default) | sah-reinsert (sah + insertion-based optimisation: seconds to build, config 5 renders 3 percent faster) | sah-gpu (binned SAH built on the GPU) | lbvh (linear BVH built on the GPU) | sah-levels-cpu | lbvh-cpu\n"
+                "      --order-by-hits     before the first frame, order every fork's children by the closest hits of one calibration frame (config 5: -1 percent per frame)\n"
                 "      --out file.png      tonemapped output (default output.png, written after the last frame)\n"
                 "      --save-every-frame  write the image after every frame, one frame per launch (the reference's cadence, window.cpp:164)\n"
                 "      --device G          HIP device ordinal (default: current)\n"
@@ -35,7 +36,7 @@ static void usage(const char *exe) {
 int main(int argc, char **argv) {
     std::string input, out = "output.png";
     int depth = 16, spp = 1, frames = 16, device = -1, in_flight = 0;
-    bool every_frame = false, extensions = false, whitted = false;
+    bool every_frame = false, extensions = false, whitted = false, order_by_hits = false;
     std::vector<int> devices;
     std::string bvh;
     for (int i = 1; i < argc; i++) {
@@ -54,6 +55,7 @@ int main(int argc, char **argv) {
         else if (a == "--bvh") bvh = next("--bvh");
         else if (a == "--device") device = std::atoi(next("--device"));
         else if (a == "--save-every-frame") every_frame = true;
+        else if (a == "--order-by-hits") order_by_hits = true;
         else if (a == "--extensions") extensions = true;
         else if (a == "--whitted") { extensions = true; whitted = true; }
         else if (a == "--gpus") { const int n = std::atoi(next("--gpus")); devices.clear(); for (int k = 0; k < n; k++) devices.push_back(k); }
@@ -73,6 +75,7 @@ int main(int argc, char **argv) {
     window->setFrameLimit(frames);
     if (in_flight > 0) window->setFramesInFlight(in_flight);
     window->setOutput(out, every_frame);
+    window->setOrderChildrenByHits(order_by_hits);
 
     auto scene = std::make_shared<Scene>();
     if (!bvh.empty()) scene->setBvhBuilder(bvh);

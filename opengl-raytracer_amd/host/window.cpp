@@ -65,6 +65,25 @@ void Window::mainloop(const std::shared_ptr<Scene> &scene_, double fps) {
                   scene->hasDielectric_ ? ", dielectric" : "", scene->whitted_ ? ", Whitted termination" : "");
     }
     resize(scene->width, scene->height);
+    if (const char *e = std::getenv("GLRT_BVH_ORDER")) orderByHits_ = std::string(e) == "hits";
+    if (orderByHits_ && !scene->nodes.empty() && scene->spheres.empty() && !scene->hasDielectric_ && !scene->whitted_) {
+        // one calibration frame on the first member's share of the rows (interleaved stripes: a fair sample of the image), counted by the render kernel itself
+        glrtx_params p;
+        frameParams(p);
+        glrt_frame_seed(0x9e3779b9u, p.seed);
+        std::vector<uint32_t> hist(scene->triangles.size(), 0u);
+        glrtx_ctx *c0 = glrtx_group_ctx(grp_, 0);
+        if (glrtx_hit_histogram(c0, &p, hist.data(), hist.size()) != GLRTX_OK) GLRT_FatalError("glrtx_hit_histogram: %s", glrtx_last_error(c0));
+        if (glrt_bvh_add_shadow_hits(hist.data(), hist.size(), &scene->triangles[0].indices[0], &scene->materials[0].type[0], scene->materials.size()) < 0)
+            GLRT_FatalError("glrt_bvh_add_shadow_hits failed");
+        const int exchanged = glrt_bvh_order_by_hits(&scene->nodes[0].bboxMin[0], scene->nodes.size(), hist.data(), hist.size());
+        if (exchanged < 0) GLRT_FatalError("glrt_bvh_order_by_hits failed (%d)", exchanged);
+        GLRT_Info("BVH: children ordered by the hits of a calibration frame, %d forks exchanged", exchanged);
+        GLRTX_CHECK(glrtx_group_upload_scene(
+            grp_, &scene->vertices[0].pos[0], scene->vertices.size(), &scene->triangles[0].indices[0], scene->triangles.size(),
+            &scene->materials[0].type[0], scene->materials.size(), scene->lights.empty() ? nullptr : &scene->lights[0].indices[0], scene->lights.size(),
+            &scene->nodes[0].bboxMin[0], scene->nodes.size()));
+    }
     initialize();
     // The reference presents (and saves) every frame; when only the final image is wanted the frames of a static
     // camera go to the device several at a time -- same pixels, bit for bit, fewer and fuller launches.

@@ -41,7 +41,7 @@ EXPORTS = ["glrtx_abi_version", "glrtx_create", "glrtx_destroy", "glrtx_last_err
            "glrtx_timer_begin", "glrtx_timer_end", "glrtx_upload_spheres", "glrtx_set_extensions",
            "glrtx_group_create", "glrtx_group_destroy", "glrtx_group_last_error", "glrtx_group_size", "glrtx_group_ctx",
            "glrtx_group_upload_scene", "glrtx_group_resize", "glrtx_group_clear", "glrtx_group_render", "glrtx_group_render_frames",
-           "glrtx_group_sync", "glrtx_group_read_accum", "glrtx_group_resolve_rgba8", "glrtx_group_get_stats", "glrtx_group_gather_copies"]
+           "glrtx_debug_resolve_burst", "glrtx_hit_histogram", "glrtx_group_sync", "glrtx_group_read_accum", "glrtx_group_resolve_rgba8", "glrtx_group_get_stats", "glrtx_group_gather_copies"]
 
 _lib = None
 
@@ -85,6 +85,11 @@ def lib():
         L.glrtx_accum_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.glrtx_resolve_rgba8.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_int]
         L.glrtx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        try:  # (ABI 10; tools/gpu_abx.py also loads libraries of earlier rounds for A/B runs)
+            L.glrtx_debug_resolve_burst.argtypes = [vp, C.c_float, C.c_int, C.POINTER(C.c_float)]
+            L.glrtx_hit_histogram.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_uint32), C.c_size_t]
+        except AttributeError:
+            pass
         L.glrtx_reset_stats.argtypes = [vp]
         L.glrtx_timer_begin.argtypes = [vp]
         L.glrtx_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
@@ -254,6 +259,19 @@ class Device:
         out = np.zeros((s.owned_rows, s.width, 4), np.uint8)
         self._ck(self.L.glrtx_resolve_rgba8(self.h, out.ctypes.data, s.width * 4, gamma, int(flip_y)))
         return out
+
+    def hit_histogram(self, params, n_tri) -> np.ndarray:
+        """Closest hits per triangle of the uploaded scene in ONE calibration frame of `params` (glrtx_hit_histogram): input of host.order_by_hits."""
+        p = params if isinstance(params, Params) else make_params(params)
+        out = np.zeros(int(n_tri), np.uint32)
+        self._ck(self.L.glrtx_hit_histogram(self.h, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_uint32)), int(n_tri)))
+        return out
+
+    def resolve_burst_ms(self, gamma=2.2, reps=32) -> float:
+        """Device time of one launch of the resolve kernel, from `reps` launches back to back (glrtx_debug_resolve_burst)."""
+        ms = C.c_float(0)
+        self._ck(self.L.glrtx_debug_resolve_burst(self.h, gamma, int(reps), C.byref(ms)))
+        return float(ms.value)
 
     def timer_begin(self):
         self._ck(self.L.glrtx_timer_begin(self.h))

@@ -31,6 +31,8 @@ def lib():
         L.glrt_bvh_build_sah_levels.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_build_chain.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp]
         L.glrt_bvh_lights_first.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t]
+        L.glrt_bvh_order_by_hits.argtypes = [fp, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t]
+        L.glrt_bvh_add_shadow_hits.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, fp, fp, C.c_size_t]
         L.glrt_bvh_reinsert.argtypes = [fp, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.glrt_look_at.argtypes = [fp, fp, fp, fp]
         L.glrt_perspective.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, fp]
@@ -88,6 +90,22 @@ def lights_first(nodes, tri, mat):
     rc = lib().glrt_bvh_lights_first(_fp(out), out.shape[0] // 3, _fp(tri), tri.shape[0], _fp(mat), mat.shape[0])
     if rc < 0:
         raise RuntimeError(f"glrt_bvh_lights_first failed: {rc}")
+    return out, int(rc)
+
+
+def order_by_hits(nodes, tri_hits, tri=None, mat=None):
+    """glrt_bvh_order_by_hits on a copy of `nodes`: at every fork the child whose subtree collected more closest hits in a calibration frame (device.Device.hit_histogram)
+    into the slot the traversal visits first.  With `tri` and `mat` the shadow rays' share is added first (glrt_bvh_add_shadow_hits).  Returns (nodes, forks exchanged)."""
+    out = _f32(nodes).reshape(-1, 3).copy()
+    h = np.ascontiguousarray(tri_hits, dtype=np.uint32).copy()
+    if tri is not None and mat is not None:
+        t, m = _f32(tri).reshape(-1, 4), _f32(mat).reshape(-1, 18)
+        rc = lib().glrt_bvh_add_shadow_hits(h.ctypes.data_as(C.POINTER(C.c_uint32)), h.shape[0], _fp(t), _fp(m), m.shape[0])
+        if rc < 0:
+            raise RuntimeError(f"glrt_bvh_add_shadow_hits failed: {rc}")
+    rc = lib().glrt_bvh_order_by_hits(_fp(out), out.shape[0] // 3, h.ctypes.data_as(C.POINTER(C.c_uint32)), h.shape[0])
+    if rc < 0:
+        raise RuntimeError(f"glrt_bvh_order_by_hits failed: {rc}")
     return out, int(rc)
 
 

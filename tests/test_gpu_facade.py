@@ -157,3 +157,20 @@ def test_glrt_main_extension_scene_matches_the_c_abi(tmp_path, gpu_device):
 def test_glrt_main_requires_input():
     r = subprocess.run([str(PKG / "lib" / "glrt_main")], capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stdout
+
+
+def test_glrt_main_order_by_hits_gives_the_same_image(tmp_path, gpu_device):
+    """--order-by-hits: one calibration frame, every fork's children ordered by the hits it counted (glrtx_hit_histogram, glrt_bvh_order_by_hits), the scene uploaded
+    again -- the image is the plain run's (this scene has no exactly tied triangles) and the run says how many forks it exchanged."""
+    from PIL import Image
+    b = _c1_builder()
+    js = scenes.export_json_obj(b, tmp_path, 96, 64, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0)
+    imgs = {}
+    for tag, extra in (("plain", []), ("hits", ["--order-by-hits"])):
+        out = tmp_path / f"{tag}.png"
+        r = subprocess.run([str(PKG / "lib" / "glrt_main"), "-i", str(js), "--max-depth", "4", "--frames", "3", "--out", str(out)] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ("children ordered by the hits of a calibration frame" in r.stdout) == (tag == "hits")
+        imgs[tag] = np.asarray(Image.open(out)).astype(np.int32)
+    assert (np.abs(imgs["hits"] - imgs["plain"]).max(-1) > 0).mean() < 0.01

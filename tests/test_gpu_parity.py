@@ -1186,3 +1186,27 @@ def test_contexts_driven_from_concurrent_host_threads(gpu_device):
     assert not errors, errors
     for (name, _, _), got, ref in zip(jobs, results, refs):
         assert_bit_equal(got, ref, f"{name}, rendered next to two other contexts")
+
+
+def test_hit_histogram_and_the_measured_child_order(gpu_device):
+    """glrtx_hit_histogram counts, per triangle, the closest hits of the path rays of one frame -- their sum is the oracle's count of path rays that hit something, the
+    context's accumulator and statistics are untouched -- and a tree whose forks are re-ordered by those counts (glrt_bvh_order_by_hits, with the shadow rays' share)
+    renders what the oracle renders for that same tree, bit for bit."""
+    from oracle import pt_oracle
+    d = gpu_device
+    scene, params = scenes.CONFIGS["c5"](width=192, height=108, n=3000)
+    acc0, st0 = gpu_render(d, scene, params)
+    hist = d.hit_histogram(params, scene["tri"].shape[0])
+    st1 = d.stats()
+    assert st1.launches == st0.launches and st1.kernel_launches == st0.kernel_launches and st1.rays == st0.rays
+    assert_bit_equal(d.read_accum(), acc0, "the accumulator after a calibration frame")
+    # every shaded hit of the frame is counted once: rays of the oracle = path rays + shadow rays; hits <= path rays
+    _, ref_rays = pt_oracle.render(scene, params)
+    assert 100 < int(hist.sum()) <= ref_rays  # (a sparse soup of 3000 triangles: most rays of this frame miss)
+    nodes, exchanged = host.order_by_hits(scene["bvh"], hist, scene["tri"], scene["mat"])
+    assert exchanged > 0
+    sc2 = dict(scene, bvh=nodes)
+    ref, ref_rays2 = pt_oracle.render(sc2, params)
+    acc, st = gpu_render(d, sc2, params)
+    assert st.rays == ref_rays2 == ref_rays
+    assert_bit_equal(acc, ref, "tree re-ordered by measured hits")

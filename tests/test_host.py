@@ -570,3 +570,37 @@ def test_lights_first_can_be_switched_off(monkeypatch):
     monkeypatch.setenv("GLRT_BVH_LIGHTS_FIRST", "0")
     sc, _ = scenes.config_c2(16, 16, subdiv=1)
     assert sc["bvh_lights_first"] == 0 and np.array_equal(np.asarray(sc["bvh"]), np.asarray(sc["bvh_builder"]))
+
+
+def test_order_by_hits_puts_the_busier_child_first():
+    """glrt_bvh_order_by_hits: at every fork the child whose subtree collected more hits goes into children.y (the slot raytrace.frag:299-307 pops first); equal counts
+    keep the builder's order; boxes, leaves and the set of triangles are untouched.  glrt_bvh_add_shadow_hits adds (all hits) / (light triangles) to every emitter."""
+    sc, _ = scenes.config_c1(32, 32, subdiv=1)
+    nodes = np.asarray(sc["bvh"], np.float32).reshape(-1, 9)
+    n_tri = sc["tri"].shape[0]
+    rng = np.random.default_rng(3)
+    hits = rng.integers(0, 50, n_tri).astype(np.uint32)
+    out, exchanged = host.order_by_hits(sc["bvh"], hits)
+    out = out.reshape(-1, 9)
+    assert exchanged > 0 and np.array_equal(out[:, :6], nodes[:, :6]) and np.array_equal(out[:, 8], nodes[:, 8])
+
+    def subtree_hits(n, i):
+        return int(hits[int(n[i, 8])]) if n[i, 8] >= 0 else sum(subtree_hits(n, int(c)) for c in n[i, 6:8] if c >= 0)
+    for i in range(out.shape[0]):
+        if out[i, 8] < 0 and out[i, 6] >= 0 and out[i, 7] >= 0:
+            hx, hy = subtree_hits(out, int(out[i, 6])), subtree_hits(out, int(out[i, 7]))
+            assert hy >= hx
+            assert {out[i, 6], out[i, 7]} == {nodes[i, 6], nodes[i, 7]}
+            if hx == hy:
+                assert out[i, 6] == nodes[i, 6]
+    same, n0 = host.order_by_hits(sc["bvh"], np.zeros(n_tri, np.uint32))
+    assert n0 == 0 and np.array_equal(same.reshape(-1, 9), nodes)
+    # the shadow rays' share
+    h2 = hits.copy()
+    L = host.lib()
+    import ctypes as C
+    tri, mat = np.ascontiguousarray(sc["tri"], np.float32).reshape(-1, 4), np.ascontiguousarray(sc["mat"], np.float32).reshape(-1, 18)
+    n_light = L.glrt_bvh_add_shadow_hits(h2.ctypes.data_as(C.POINTER(C.c_uint32)), n_tri, tri.ctypes.data_as(C.POINTER(C.c_float)), mat.ctypes.data_as(C.POINTER(C.c_float)), mat.shape[0])
+    assert n_light == sc["light"].shape[0] > 0
+    emit = np.array([np.linalg.norm(mat[int(t[3]), 3:6]) != 0 for t in tri])
+    assert np.array_equal(h2[~emit], hits[~emit]) and np.all(h2[emit] == hits[emit] + int(hits.sum()) // n_light)

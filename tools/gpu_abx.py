@@ -26,6 +26,12 @@ def child(lib, config, frames, rounds):
         sc, pr = scenes._random_tri_scene(n, 20260102, ext, 3.4 * ext, 1920, 1080, 4, 1, "sah")
     else:
         sc, pr = scenes.CONFIGS[config]()
+    if os.environ.get("ABX_PREALLOC_MB"):  # (placement experiments: device memory taken before the library allocates anything)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        for mb in os.environ["ABX_PREALLOC_MB"].split("+"):
+            ptr = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(int(float(mb) * (1 << 20)))) == 0
     d = device.Device(); d.upload_scene(sc); d.resize(pr["width"], pr["height"])
     seeds = lambda f0: [host.frame_seed(f0 + i) for i in range(frames)]
     d.count_rays(True); d.reset_stats()

@@ -1,6 +1,6 @@
 """The two HBM-bound kernels of the path on the GPU box: accumulate_planes_kernel (frames in flight: sample planes -> accumulator) and
 resolve_kernel (screen.frag:15-25 + RGBA8), at 1920x1080 and 3840x2160, GB/s against the 8 TB/s HBM peak.  Device times come from HIP
-events on the launch stream (glrtx_stats.accumulate_ms_total, .resolve_ms_last).  Writes profiles/r03_aux_kernels.json."""
+events on the launch stream (glrtx_stats.accumulate_ms_total, .resolve_ms_last).  Writes gpurun_out/r06_aux_kernels.json (copied to profiles/)."""
 import json, sys; sys.path.insert(0, '.'); sys.path.insert(0, 'opengl-raytracer_amd/python')
 import numpy as np
 from glrt_amd import scenes, device, host
@@ -28,7 +28,9 @@ for (w, h) in ((1920, 1080), (3840, 2160)):
         d.resolve_rgba8(2.2, True); ms.append(d.stats().resolve_ms_last)
     t = float(np.median(ms[1:]))
     by = w * h * 20
-    out["rows"].append({"kernel": "resolve_kernel", "size": f"{w}x{h}", "ms": round(t, 4), "bytes": by, "gb_s": round(by / t / 1e6, 1),
-                        "frac_of_hbm_peak": round(by / t / 1e6 / PEAK, 4)})
+    tb = d.resolve_burst_ms(2.2, 32)
+    out["rows"].append({"kernel": "resolve_kernel", "size": f"{w}x{h}", "ms": round(tb, 4), "bytes": by, "gb_s": round(by / tb / 1e6, 1),
+                        "frac_of_hbm_peak": round(by / tb / 1e6 / PEAK, 4), "how": "32 launches back to back between one pair of events, per launch",
+                        "single_launch_between_two_events_ms": round(t, 4)})
 for r in out["rows"]: print(r)
-json.dump(out, open("gpurun_out/r03_aux_kernels.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r06_aux_kernels.json", "w"), indent=1)

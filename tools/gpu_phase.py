@@ -3,8 +3,8 @@ import numpy as np
 from glrt_amd import scenes, device, host
 import os
 device.lib_path = lambda: device.LIB_DIR / os.environ.get("GLRTX_PHASE_LIB", "libglrtx_phase.so")
-sc, pr = scenes.config_headline()
-d = device.Device(); d.upload_scene(sc); d.resize(1920, 1080)
+sc, pr = scenes.CONFIGS[os.environ.get("GLRTX_PHASE_CONFIG", "headline")]()
+d = device.Device(); d.upload_scene(sc); d.resize(pr["width"], pr["height"])
 L = device.lib(); out = (C.c_ulonglong * 8)()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 d.render_frames(pr, [host.frame_seed(f) for f in range(B)]); d.sync(); L.glrtx_debug_phase_cycles(out)
