@@ -210,7 +210,12 @@ int glrtx_count_rays(glrtx_ctx *ctx, int enable);
  * outstanding per context).  Consecutive calls overlap on the device: the render kernel of a call runs on one of six internal streams with
  * buffers of its own and hands its samples over in planes; only the pass that adds them to the accumulator runs on the context's stream
  * (glrtx_set_stream), in call order -- so everything a caller orders behind the call on that stream (resolve, read-back, a collective on the
- * rows) sees the finished accumulator, and per pixel the additions happen in the order of the calls. */
+ * rows) sees the finished accumulator, and per pixel the additions happen in the order of the calls.
+ * FED LAUNCHES (ABI 10; the context's own stream only): a call that follows another render call directly -- same camera, samples and depth, nothing in between
+ * that reads the accumulator or changes what a launch depends on -- does not become a launch of its own while that launch is still running: its frame is published to
+ * the running kernel in host-coherent memory and rendered by it (glrtx_stats.feed_appended).  The pixels, and what every later call sees, are the same; only the launch
+ * boundaries go away (one ramp and one drain per burst).  glrtx_sync, glrtx_resolve_rgba8, glrtx_read_accum, glrtx_clear, ... seal the open launch: nothing issued
+ * after them is appended to a launch queued in front of them.  GLRTX_NO_FEED=1 turns this off.  See INTEGRATION.md. */
 int glrtx_render(glrtx_ctx *ctx, const glrtx_params *params);
 /* Frames in flight.  Same result, bit for bit, as n_frames consecutive glrtx_render calls whose params differ only
  * in `seed` (seeds_xy = n_frames pairs; params->seed is ignored) -- the reference's accumulation loop with a static

@@ -23,7 +23,10 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -- 
 rocprofv3 --pmc GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum --output-format csv -d $OUT/pmc_grbm -- $CMD > $OUT/pmc_grbm.log 2>&1
 echo "pmc mem done"
 # traversal statistics of the same config (wave-steps = node fetches / 4, lanes and lines per step): the -DGLRTX_TRAV_STATS build, 8 frames in one launch
-if [ -f opengl-raytracer_amd/lib/libglrtx_stats.so ]; then
+# (config 3 is a chain tree scanned as a list -- csrc/scan_asm.hip.h -- not traversed: there are no traversal steps to count)
+if [ "$CFG" = "c3" ]; then
+  echo "travstats skipped: config 3 is scanned as a list"
+elif [ -f opengl-raytracer_amd/lib/libglrtx_stats.so ]; then
   GLRTX_TRAVSTATS_JSON=$OUT/travstats.json timeout -k 10 300 python3 tools/gpu_travstats.py $CFG 8 > $OUT/travstats.txt 2>&1 || echo "travstats failed"
 fi
 find $OUT -name "*.csv" | head -50
