@@ -325,10 +325,12 @@ class GpuRenderer:
         self.dev.set_stream(0 if on else self.stream.cuda_stream)
 
     def resolve_ms(self):
-        """Device time of one resolve pass over the owned rows (screen.frag), ms."""
+        """Device time of one resolve pass over the owned rows (screen.frag), ms: (per launch in a train of 32 launches between one pair of events, a single launch
+        between two events).  The second also measures the command processor's latency on both sides of a 12-us kernel."""
         self.dev.resolve_rgba8(2.2, True)
         self.dev.resolve_rgba8(2.2, True)
-        return float(self.dev.stats().resolve_ms_last)
+        single = float(self.dev.stats().resolve_ms_last)
+        return float(self.dev.resolve_burst_ms(2.2, 32)), single
 
     def close(self):
         self.dev.set_stream(0)
@@ -767,11 +769,14 @@ def main(argv=None):
                                                "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms": round(ms, 4), "bytes": int(by),
                                                "what": f"{n_planes:g} sample planes of {W}x{len(ys)} float4 added to the accumulator"}
         if resolve_ms:
+            resolve_ms, resolve_single = resolve_ms if isinstance(resolve_ms, tuple) else (resolve_ms, None)
             by = len(ys) * W * 20  # 16 B accumulator texel in, 4 B RGBA8 out (screen.frag:15-25)
             aux["resolve_kernel"] = {"bound": "hbm", "achieved": round(by / (resolve_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(by / (resolve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms": round(resolve_ms, 4), "bytes": int(by),
-                                     "what": f"{W}x{len(ys)}: rgb / count, clamp, pow(1 / 2.2), RGBA8; at this size the launch itself (~10 us) is a third of the time "
-                                             "-- profiles/r03_aux_kernels.json has 4K"}
+                                     "single_launch_between_two_events_ms": None if resolve_single is None else round(resolve_single, 4),
+                                     "what": f"{W}x{len(ys)}: rgb / count, clamp, pow(1 / 2.2), RGBA8; ms = per launch in a train of 32 launches (glrtx_debug_resolve_burst); "
+                                             "the pass is paced by its ~250 vector instructions a pixel as much as by memory (DESIGN.md section 9 row 7); "
+                                             "profiles/r06_aux_kernels.json has 4K"}
 
     cpu_baseline, oracle_check = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and RENDERER_FACTORY is None:

@@ -222,7 +222,7 @@ int next_launch_rec(glrtx_ctx *c, glrtx_ctx::LaunchRec *&out) {
 }
 
 int lds_bytes_for(const DevScene &sc) {
-    return (sc.mats_in_lds ? 3 * sc.n_mat * (int)sizeof(float4) : 0) + 2 * sc.stack_entries * kBlockThreads * (int)sizeof(int);
+    return sc.lds_head_f4 * (int)sizeof(float4) + 2 * sc.stack_entries * kBlockThreads * (int)sizeof(int);  // materials and lights | traversal stacks
 }
 
 int pfail(glrtx_ctx *c, std::string *err_out, int code, const char *fmt, ...) {
@@ -436,6 +436,7 @@ int pack_scene(glrtx_ctx *c, std::string *err_out, Packed &P, const float *vert,
         for (size_t k = 0; k < leaf_tri.size(); k++) {
             for (int j = 0; j < 4; j++) P.tris[4 * (k + 1) + j] = tris[4 * (size_t)leaf_tri[k] + j];
             for (int j = 0; j < 3; j++) P.nrms[3 * (k + 1) + j] = nrms[3 * (size_t)leaf_tri[k] + j];
+            P.nrms[3 * (k + 1)].w = P.tris[4 * (k + 1)].w;  // the material id rides with the normals (round 6): the shade phase reads it there and no longer fetches the leaf record for one word
             P.tris[4 * (k + 1) + 1].w = as_float(leaf_next[k]);
         }
         P.tris[1].w = as_float(REF_FIN);
@@ -666,7 +667,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
                                      : (cr ? (Kernel)pt_render_wgwf<true, false, 0> : (Kernel)pt_render_wgwf<false, false, 0>);
     // (north_star's "primitives staged into LDS": materials, camera block, root box and the per-lane stacks are; the top tree levels were built, measured worth
     // nothing -- profiles/r02_lds_top.json -- and removed.)
-    const int lds = (c->sc.mats_in_lds ? 3 * c->sc.n_mat * (int)sizeof(float4) : 0) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
+    const int lds = c->sc.lds_head_f4 * (int)sizeof(float4) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
                     kWgCtlWords * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block |
                     kWgPathsMax / 8;  // light-test bits, one per path-queue position
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
@@ -1053,6 +1054,8 @@ int glrtx_upload_scene(glrtx_ctx *c, const float *vert, size_t n_vert, const flo
     sc.n_fork = (int)(forks.size() / 4);
     sc.stack_entries = stack_need;
     sc.mats_in_lds = (n_mat > 0 && n_mat <= (size_t)kMaxLdsMaterials) ? 1 : 0;
+    sc.lights_in_lds = (n_light > 0 && n_light <= (size_t)kMaxLdsLights && std::getenv("GLRTX_NO_LDS_LIGHTS") == nullptr) ? 1 : 0;
+    sc.lds_head_f4 = (sc.mats_in_lds ? 3 * (int)n_mat : 0) + (sc.lights_in_lds ? 6 * (int)n_light : 0);
     sc.vine = P.vine.empty() ? nullptr : (const float4 *)c->vine.p;
     sc.n_vine = P.n_vine;
     sc.vine_main = P.vine_main;

@@ -45,6 +45,7 @@ constexpr int kTile = 16;
 constexpr int REF_ABSENT = INT32_MIN;
 constexpr int REF_FIN = INT32_MIN;      // Trav::cur of a finished ray (nothing left on the stack)
 constexpr int kMaxLdsMaterials = 256;   // 12 KiB of LDS at most
+constexpr int kMaxLdsLights = 64;       // 6 KiB of LDS at most
 constexpr int kTopForks = 128;          // forks of the top tree levels, numbered first (pack_scene): one contiguous 8 KiB block
 
 constexpr float PT_EPS = 1.0e-4f;
@@ -70,6 +71,9 @@ struct DevScene {
     int n_fork;
     int stack_entries;  // per-lane traversal stack entries in LDS
     int mats_in_lds;    // 1: materials staged into LDS at kernel start
+    int lights_in_lds;  // 1: the light triangles ({v0, material} {v1} {v2} {n0} {n1} {n2}, at most kMaxLdsLights) staged into LDS behind the materials (round 6): the six
+                        //    gathers of every light sample (:344-352) become LDS reads
+    int lds_head_f4;    // float4s staged at the head of a workgroup's LDS: the materials, then the lights
     // "Vine" trees -- every fork has a leaf as children.y: the brute-force scan of BASELINE config 3 expressed in the
     // node format (glrt_bvh_build_chain) -- are also stored as a list in visiting order and scanned, see trav_scan().
     const float4 *vine;  // records of 4 float4: {fork box min, v0.x} {fork box max, v0.y} {v0.z, v1-v0} {v2-v0, triangle}: the n_vine - 1 fork records, never-hit
@@ -780,7 +784,7 @@ struct Surf {
 };
 DEV Surf surf_tri(const DevScene &sc, const Hit &h) {
     // normal of the closest hit (:254), computed once instead of per candidate
-    const float4 T0 = sc.forks[4 * (ptrdiff_t)(~h.tri)];
+    // (the material id is kept in the unused fourth word of the first normal -- glrtx.hip: pack_scene -- : three gathers per shaded hit instead of four)
     const float4 N0 = sc.nrms[3 * h.tri], N1 = sc.nrms[3 * h.tri + 1], N2 = sc.nrms[3 * h.tri + 2];
     const float w0 = (1.0f - h.u) - h.v;
     const float tx = (w0 * N0.x + h.u * N1.x) + h.v * N2.x;
@@ -789,7 +793,7 @@ DEV Surf surf_tri(const DevScene &sc, const Hit &h) {
     const float r = rsq(dot3(tx, ty, tz, tx, ty, tz));
     Surf S;
     S.nx = tx * r; S.ny = ty * r; S.nz = tz * r;
-    S.mtrl = __float_as_int(T0.w);
+    S.mtrl = __float_as_int(N0.w);
     return S;
 }
 
@@ -970,7 +974,10 @@ DEV void shade_core(const KernelArgs &a, const float4 *lds_mats, Rng &rng, Path 
                 const float ub = flip ? 1.0f - ub0 : ub0;
                 const float w0 = (1.0f - ua) - ub;
                 float4 V0, V1, V2, N0, N1, N2;
-                if (lid >= 0) {
+                if (lid >= 0 && sc.lights_in_lds) {  // (wave-uniform) staged behind the materials: six LDS reads instead of six gathers
+                    const lds_cf4 q = (lds_cf4)lds_mats + (sc.mats_in_lds ? 3 * sc.n_mat : 0) + 6 * lid;
+                    V0 = to_f4(q[0]); V1 = to_f4(q[1]); V2 = to_f4(q[2]); N0 = to_f4(q[3]); N1 = to_f4(q[4]); N2 = to_f4(q[5]);
+                } else if (lid >= 0) {
                     const float4 *Lp = sc.lights + 6 * lid;
                     V0 = Lp[0]; V1 = Lp[1]; V2 = Lp[2]; N0 = Lp[3]; N1 = Lp[4]; N2 = Lp[5];
                 } else {  // u_nLights == 0: out-of-range texelFetch returns zeros in the reference's GL
@@ -1252,20 +1259,25 @@ DEV void stage_mats(const KernelArgs &a, float4 *lds_mats) {
         lds_mats[3 * m] = m0; lds_mats[3 * m + 1] = m1; lds_mats[3 * m + 2] = m2;
     }
 }
+// The light triangles behind them (DevScene::lights_in_lds).
+DEV void stage_lights(const KernelArgs &a, float4 *lds_mats) {
+    if (!a.sc.lights_in_lds) return;
+    float4 *dst = lds_mats + (a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0);
+    for (int i = threadIdx.x; i < 6 * a.sc.n_light; i += kBlockThreads) dst[i] = a.sc.lights[i];
+}
 
 DEV void lds_setup(const KernelArgs &a, unsigned char *lds_raw, float4 *&lds_mats, int *&stack) {
     lds_mats = reinterpret_cast<float4 *>(lds_raw);
-    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    const int mat_f4 = a.sc.lds_head_f4;  // materials, then lights
     stack = reinterpret_cast<int *>(lds_raw + (size_t)mat_f4 * sizeof(float4)) + 2 * threadIdx.x;  // 8-byte entries
-    if (a.sc.mats_in_lds) {
-        stage_mats(a, lds_mats);
-        __syncthreads();
-    }
+    if (a.sc.mats_in_lds) stage_mats(a, lds_mats);
+    stage_lights(a, lds_mats);
+    if (a.sc.lds_head_f4 > 0) __syncthreads();
 }
 
 // Extension kernel: the analytic spheres ({centre, radius}, 16 B each, at most kMaxSpheres) go into LDS behind the traversal stacks.
 DEV float4 *ext_stage_spheres(const KernelArgs &a, const ExtArgs &ex, unsigned char *lds_raw) {
-    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    const int mat_f4 = a.sc.lds_head_f4;  // materials, then lights
     float4 *dst = reinterpret_cast<float4 *>(lds_raw + (size_t)mat_f4 * sizeof(float4) + (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int));
     for (int i = threadIdx.x; i < ex.n_spheres; i += kBlockThreads) dst[i] = ex.spheres[i];
     __syncthreads();
@@ -2224,7 +2236,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     // LDS: materials | stack | ctl[16].  The workgroup's ray/path queues live in its private slice of a
     // global buffer (L2-resident, read and written with unit stride).
     float4 *lds_mats = reinterpret_cast<float4 *>(lds_raw);
-    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    const int mat_f4 = a.sc.lds_head_f4;  // materials, then lights
     unsigned char *pl = lds_raw + (size_t)mat_f4 * sizeof(float4);
     int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
@@ -2243,6 +2255,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
     unsigned *pathQ = reinterpret_cast<unsigned *>(rayQ + 8 * (size_t)w.block_paths);
     if (a.sc.mats_in_lds) stage_mats(a, lds_mats);
+    stage_lights(a, lds_mats);
 
     const int kWgPaths = w.block_paths;
     unsigned long long rays = 0;  // low half: reference rays, high half: those resolved without a traversal
@@ -2412,7 +2425,7 @@ template <int FETCH>
 __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_traverse(const KernelArgs a, const WfArgs w, unsigned *work_counter, float4 *wg_queues,
                                                                                       const float4 *log, const uint2 *trips, int n_trips) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int mat_f4 = a.sc.mats_in_lds ? 3 * a.sc.n_mat : 0;
+    const int mat_f4 = a.sc.lds_head_f4;  // materials, then lights
     unsigned char *pl = lds_raw + (size_t)mat_f4 * sizeof(float4);
     int *stack = reinterpret_cast<int *>(pl) + 2 * threadIdx.x;
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
