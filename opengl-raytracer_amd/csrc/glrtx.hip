@@ -668,7 +668,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // (north_star's "primitives staged into LDS": materials, camera block, root box and the per-lane stacks are; the top tree levels were built, measured worth
     // nothing -- profiles/r02_lds_top.json -- and removed.)
     const int lds = c->sc.lds_head_f4 * (int)sizeof(float4) + 2 * c->sc.stack_entries * kBlockThreads * (int)sizeof(int) +
-                    kWgCtlWords * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + ((kCamFloats + 3) / 4) * (int)sizeof(float4) +  // ctl | root box | camera block |
+                    kWgCtlWords * (int)sizeof(unsigned) + 2 * (int)sizeof(float4) + kCamFloatsPadded * (int)sizeof(float) + kLdsSeeds * (int)sizeof(float2) +  // ctl | root box | camera block | seeds |
                     kWgPathsMax / 8;  // light-test bits, one per path-queue position
     if (lds > 160 * 1024) return fail(c, GLRTX_EDEVICE, "wgwf kernel needs %d B of LDS (> 160 KiB)", lds);
     if (lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -807,6 +807,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
             if ((rc = ensure(c, c->wfSeeds, (size_t)n_frames * sizeof(float2)))) return rc;
             HIP_TRY(c, hipMemcpyAsync(c->wfSeeds.p, seeds_xy, (size_t)n_frames * sizeof(float2), hipMemcpyHostToDevice, c->stream));
             w.seeds = (const float2 *)c->wfSeeds.p;
+            w.seeds_in_lds = n_frames <= kLdsSeeds ? 1 : 0;
         }
         if (n_frames > 1 || slot) {
             if ((rc = ensure(c, planeBuf, (size_t)std::max(n_planes, 1) * plane_f4 * sizeof(float4)))) return rc;

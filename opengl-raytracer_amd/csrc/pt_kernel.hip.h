@@ -1493,6 +1493,8 @@ struct FeedDev {
     unsigned long long seeds[kFeedMaxFrames];  // {seed.x, seed.y} as one 64-bit word
     unsigned long long chunks[kFeedChunks];    // device address of the chunk's planes
 };
+constexpr int kCamFloatsPadded = 36;  // the camera block in LDS: kCamFloats rounded up to float4s
+constexpr int kLdsSeeds = 64;     // frames whose seeds a launch keeps in LDS (WfArgs::seeds_in_lds)
 constexpr int kWfSetPlanes = 6;  // planes of one set of WfArgs::state (kWfStatePlanes counts both sets)
 struct WfArgs {
     // Path state: six float4-wide planes of `ids` entries each, TWICE (one set read, one written per trip), in ONE allocation (one base pointer and one stride
@@ -1502,7 +1504,7 @@ struct WfArgs {
     // (1 KiB, eight lines) whatever has become of the paths in between -- addressed by pixel they spread over three times as many lines once paths had died --
     // and the allocation is 2 x 6 x 16 B x (workgroups x block_paths) = 0.8 GB whatever the number of frames in flight (by pixel: 3.2 GB at 16 frames, 9.5 GB at 48).
     //   0: {next ray origin (= shadow ray origin), rng.x}      1: {next ray direction, rng.y}
-    //   2: {beta, meta}   meta = depth | sample << 8 | flags   3: {L if the pending light sample is accepted (or L), dist}
+    //   2: {beta, meta}   meta = depth | sample << 8 | flags   3: {L if the pending light sample is accepted (or L), path id = frame * total + tile-order pixel}
     //   4: {L if it is rejected, -}                             5: closest hit of the path's ray {t, tri, u, v}   (written by the traversal lane: the ray
     //      record carries the state index its path will be read at; a parked ray's record is re-addressed when its path moves: wg_shade_phase)
     // (a shadow ray leaves no record in memory: the traversal lane evaluates the light test of :367 itself and sets one bit,
@@ -1541,6 +1543,7 @@ struct WfArgs {
     // the samples are added to the accumulator directly, otherwise they go to planes as well (single-frame launches that overlap:
     // the accumulator is then only touched by the plane-accumulation pass, in launch order).
     const float2 *seeds;  // u_seed of every frame
+    int seeds_in_lds;     // 1: the seeds (at most kLdsSeeds frames) are staged into LDS behind the camera block: one gather less per shaded path
     float4 *planes;       // [n_frames * n_samples][owned_rows][pitch_f4] of {min(L, 100), -}
     int n_frames;
     int tiles_per_frame;  // total >> 6
@@ -1584,10 +1587,14 @@ DEV bool wf_pixel(const KernelArgs &a, const WfArgs &w, int id, int &lx, int &lr
 }
 
 // u_seed of the frame a path belongs to
-DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, int id) {
+DEV float2 wf_seed(const KernelArgs &a, const WfArgs &w, const float *cam, int id) {
     if (w.n_frames > 1) {
         int frame, pid;
         w.split(id, frame, pid);
+        if (w.seeds_in_lds) {  // staged behind the camera block (pt_render_wgwf)
+            const float *sd = cam + kCamFloatsPadded + 2 * frame;
+            return make_float2(sd[0], sd[1]);
+        }
         if (w.feed_dev != nullptr) {  // fed launch: the frame's line of the device mirror
             const nfloat2 v = ((glb_cf2)&w.feed_dev->seeds[0])[frame];
             return make_float2(v.x, v.y);
@@ -1643,7 +1650,7 @@ DEV bool wf_start(const KernelArgs &a, const WfArgs &w, const float *cam, int id
 DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam, int id, unsigned sidx, float4 &ray_o, float4 &ray_d) {
     int lx, lrow;
     bool go = false;
-    const float2 sd = wf_seed(a, w, id);
+    const float2 sd = wf_seed(a, w, cam, id);
     Rng rng = {0.f, 0.f, sd.x, sd.y};
     Path P;
     unsigned sample = 0;
@@ -1657,10 +1664,10 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam,
         st_stream(w.A(0, sidx), make_float4(P.ox, P.oy, P.oz, rng.x));
         st_stream(w.A(1, sidx), make_float4(P.dx, P.dy, P.dz, rng.y));
         st_stream(w.A(2, sidx), make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8)));
-        st_stream(w.A(3, sidx), make_float4(0.f, 0.f, 0.f, 0.f));
+        st_stream(w.A(3, sidx), make_float4(0.f, 0.f, 0.f, __uint_as_float((unsigned)id)));  // (the path id travels in the state: there is no queue of path ids any more)
         ray_o = make_float4(P.ox, P.oy, P.oz, __uint_as_float(sidx * 2u));
         ray_d = make_float4(P.dx, P.dy, P.dz, 0.f);
-    }
+    } else st_stream(w.A(3, sidx), make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_INVALID)));  // a position the shade phase skips (a pixel outside the image, nothing to trace)
     return go;
 }
 
@@ -1669,14 +1676,18 @@ DEV bool wf_generate_one(const KernelArgs &a, const WfArgs &w, const float *cam,
 // queue for the next trip: push_ext = the path's next ray, push_sh = this bounce's shadow ray -- and, when the path goes on (either of them, or requeue), its state
 // for the next trip, which the caller stores once it knows the path's next queue position: ray_o = plane 0 {origin, rng.x}, ray_d = plane 1 {direction, rng.y},
 // st2 / st3 = planes 2 / 3, st4 = plane 4 when has4.
-DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, unsigned id, unsigned sidx, bool light_accepted, bool &push_ext,
+DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, unsigned &id, unsigned sidx, bool light_accepted, bool &push_ext,
                        bool &push_sh, bool &requeue, float4 &ray_o, float4 &ray_d, float4 &ray_sd, float4 &st2, float4 &st3, float4 &st4, bool &has4, unsigned long long &rays) {
     const float4 s0 = ld_stream(w.A(0, sidx)), s1 = ld_stream(w.A(1, sidx)), s2 = ld_stream(w.A(2, sidx)), s3 = ld_stream(w.A(3, sidx));
     // the hit record is fetched with the state, not behind the meta word the state delivers: one round trip less per round of the shade loop
     // (-0.9 % per frame, profiles/r03_ab_shade_phase.txt; unused when the path has ended).  Plain load and store for the hit records:
     // -1.6 % against the non-temporal forms, profiles/r02_ab_flags.txt
     const float4 hh = *w.H(sidx);
-    const float2 sd = wf_seed(a, w, (int)id);
+    // the path's id comes with its state (plane 3): until round 6 it was read from a queue of path ids first -- a load and, for every path that goes on, a store per
+    // trip on the unit that paces the kernel.  A position the top-up marked invalid is loaded like any other (its planes are whatever was there) and dropped here.
+    id = __float_as_uint(s3.w);
+    if (id == WF_INVALID) return;
+    const float2 sd = wf_seed(a, w, cam, (int)id);
     Rng rng = {s0.w, s1.w, sd.x, sd.y};
     const unsigned meta = __float_as_uint(s2.w);
     unsigned sample = (meta >> 8) & 0xFFFFFu;
@@ -1732,7 +1743,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
             ray_o = make_float4(P.ox, P.oy, P.oz, rng.x);
             ray_d = make_float4(P.dx, P.dy, P.dz, rng.y);
             st2 = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample << 8));
-            st3 = make_float4(0.f, 0.f, 0.f, 0.f);
+            st3 = make_float4(0.f, 0.f, 0.f, s3.w);
         }
     } else {
         // shade_hit ran and the path goes on and/or awaits its shadow ray
@@ -1742,7 +1753,7 @@ DEV void wf_shade_path(const KernelArgs &a, const WfArgs &w, const float4 *lds_m
         ray_o = make_float4(P.ox, P.oy, P.oz, rng.x);  // the next ray and the shadow ray leave from the same point
         ray_d = make_float4(P.dx, P.dy, P.dz, rng.y);
         st2 = make_float4(P.bx, P.by, P.bz, __uint_as_float(m2));
-        st3 = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, sh.dist);
+        st3 = make_float4(sh.Lpx, sh.Lpy, sh.Lpz, s3.w);
         if (push_sh) { st4 = make_float4(sh.Lfx, sh.Lfy, sh.Lfz, 0.f); has4 = true; }
         ray_sd = make_float4(sh.sdx, sh.sdy, sh.sdz, sh.dist);
     }
@@ -2038,8 +2049,8 @@ DEV void wg_traverse_phase(const KernelArgs &a, const WfArgs &w, const float4 *r
 // lane that finished the path's shadow ray; the shadow ray pushed here carries the position its path will have in pq_next.
 // Path state: the path at queue position i is read at state index cur_base + i and -- if it goes on -- written at next_base + (its position in pq_next); the next
 // ray's record carries that index (even ray id: where the traversal lane stores the hit), and a ray parked in a traversal lane finds it behind the mark it left.
-DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, const unsigned *light_bits, const unsigned *pq, int n_paths,
-                        float4 *rq_next, unsigned *pq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned cur_base, unsigned next_base, unsigned long long &rays,
+DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_mats, const float *cam, const unsigned *light_bits, int n_paths,
+                        float4 *rq_next, unsigned *n_rays_next, unsigned *n_paths_next, unsigned cur_base, unsigned next_base, unsigned long long &rays,
                         unsigned *moved) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -2048,9 +2059,8 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
         bool push_ext = false, push_sh = false, requeue = false, has4 = false;
         unsigned id = WF_INVALID;
         float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro, rsd = ro, st2 = ro, st3 = ro, st4 = ro;
-        if (i < n_paths) id = pq[i];
         const bool light_accepted = i < n_paths && ((light_bits[i >> 5] >> (i & 31)) & 1u) != 0u;
-        if (id != WF_INVALID)
+        if (i < n_paths)
             wf_shade_path(a, w, lds_mats, cam, id, cur_base + (unsigned)i, light_accepted, push_ext, push_sh, requeue, ro, rd, rsd, st2, st3, st4, has4, rays);
         const unsigned long long me = __ballot(push_ext), ms = __ballot(push_sh), mq = __ballot(requeue), mp = me | ms | mq;
         const unsigned long long mv = __ballot(id != WF_INVALID);
@@ -2072,7 +2082,6 @@ DEV void wg_shade_phase(const KernelArgs &a, const WfArgs &w, const float4 *lds_
             st_stream(w.A(2, sidx_next), st2);
             st_stream(w.A(3, sidx_next), st3);
             if (has4) st_stream(w.A(4, sidx_next), st4);
-            pq_next[pos_next] = id;
         }
         // a parked ray's path has moved: the forwarding address goes where the ray left its mark -- the lane reads it when it resumes (wg_traverse_phase), before this
         // set is written again -- and the ray ends the next traverse phase finished or parked again: either way it writes the hit record at the new index
@@ -2247,13 +2256,13 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
     // would occupy ~100 of the 102 SGPRs and spill into VGPR lanes inside the traversal loop)
     float4 *lds_root = reinterpret_cast<float4 *>(pl + kWgCtlWords * sizeof(unsigned));      // {root_lo, root_hi}
     float *lds_cam = reinterpret_cast<float *>(pl + kWgCtlWords * sizeof(unsigned) + 32);     // {c2w, s2c, aperture, focal}
-    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + kWgCtlWords * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);  // kWgPathsMax bits
+    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + kWgCtlWords * sizeof(unsigned) + 32 + kCamFloatsPadded * 4 + kLdsSeeds * 8);  // kWgPathsMax bits
     if (threadIdx.x < kCamFloats) lds_cam[threadIdx.x] = a.cam[threadIdx.x];
+    if (w.seeds_in_lds && (int)threadIdx.x < 2 * w.n_frames) lds_cam[kCamFloatsPadded + threadIdx.x] = reinterpret_cast<const float *>(w.seeds)[threadIdx.x];  // (n_frames <= kLdsSeeds = 64: 128 floats)
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
     if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
     // per-workgroup slice of the queue buffer: ray records float4[2][2 * block_paths][2], then path ids unsigned[2][block_paths]
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
-    unsigned *pathQ = reinterpret_cast<unsigned *>(rayQ + 8 * (size_t)w.block_paths);
     if (a.sc.mats_in_lds) stage_mats(a, lds_mats);
     stage_lights(a, lds_mats);
 
@@ -2312,7 +2321,6 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
             }
             const int nr = (int)ctl[2 + cur], np = (int)ctl[4 + cur];
             float4 *rq_w = rayQ + 2 * ((size_t)cur * 2 * kWgPaths + nr);
-            unsigned *pq_w = pathQ + cur * kWgPaths + np;
             const WgwfKernArgs *kt = wgwf_kernargs();
             const unsigned new_base = kt->w.set_base(cur, (int)blockIdx.x) + (unsigned)np;  // state index of the first new path: set `cur`, behind the live ones
             for (int k = threadIdx.x; k < got; k += kBlockThreads) {
@@ -2321,7 +2329,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
                 const bool go = wf_generate_one(kt->a, kt->w, lds_cam, id, new_base + (unsigned)k, ro, rd);  // pixels outside the image leave skip markers
                 rq_w[2 * k] = ro;  // (plain stores, like every ray record: see st_stream)
                 rq_w[2 * k + 1] = rd;
-                pq_w[k] = go ? (unsigned)id : WF_INVALID;
+                (void)go;
             }
             __syncthreads();  // everyone has read the counts
             if (tid_topup == 0u) { ctl[2 + cur] = (unsigned)(nr + got); ctl[4 + cur] = (unsigned)(np + got); ctl[1] = 0u; }
@@ -2335,7 +2343,6 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
             break;  // nothing alive and nothing left to take
         }
         const float4 *rq = rayQ + 2 * ((size_t)cur * 2 * kWgPaths);
-        const unsigned *pq = pathQ + cur * kWgPaths;
 
 #ifdef GLRTX_RAY_LOG
         if (g_ray_log.on) {  // (wave-uniform) append this trip's ray queue to the log
@@ -2370,7 +2377,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_render_wgw
 
         // ---- shade phase: the live paths; appends go to the other queue pair
         const WgwfKernArgs *ks = wgwf_kernargs();
-        wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, light_bits, pq, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths), pathQ + (cur ^ 1) * kWgPaths,
+        wg_shade_phase(ks->a, ks->w, lds_mats, lds_cam, light_bits, n_paths, rayQ + 2 * ((size_t)(cur ^ 1) * 2 * kWgPaths),
                        &ctl[2 + (cur ^ 1)], &ctl[4 + (cur ^ 1)], ks->w.set_base(cur, (int)blockIdx.x), ks->w.set_base(cur ^ 1, (int)blockIdx.x), rays, &ctl[10]);
         PH_STAMP(ps1);
         __syncthreads();  // everyone has read n_rays/n_paths of `cur` and finished appending
@@ -2431,7 +2438,7 @@ __global__ __launch_bounds__(kBlockThreads, GLRTX_WGWF_WAVES) void pt_replay_tra
     pl += (size_t)2 * a.sc.stack_entries * kBlockThreads * sizeof(int);
     unsigned *ctl = reinterpret_cast<unsigned *>(pl);
     float4 *lds_root = reinterpret_cast<float4 *>(pl + kWgCtlWords * sizeof(unsigned));
-    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + kWgCtlWords * sizeof(unsigned) + 32 + ((kCamFloats + 3) / 4) * 16);
+    unsigned *light_bits = reinterpret_cast<unsigned *>(pl + kWgCtlWords * sizeof(unsigned) + 32 + kCamFloatsPadded * 4 + kLdsSeeds * 8);
     if (threadIdx.x == 64) lds_root[0] = a.sc.root_lo;
     if (threadIdx.x == 65) lds_root[1] = a.sc.root_hi;
     float4 *rayQ = wg_queues + (size_t)blockIdx.x * kWgQueueF4;
