@@ -233,3 +233,44 @@ def test_a_callers_stream_is_never_fed(gpu_device, plain_device):
         d.set_stream(0)
     want, _ = _plain(plain_device, scene, params, _seeds(14))
     assert_bit_equal(d.read_accum(), want, "caller's stream")
+
+
+@pytest.mark.parametrize("n_frames", [64, 70])
+def test_plain_launches_keep_their_seeds_in_lds_or_in_memory(gpu_device, plain_device, monkeypatch, n_frames):
+    """An unfed multi-frame launch keeps the seeds of up to 64 frames in LDS (WfArgs::seeds_in_lds), a longer one reads them from memory: both give the image of
+    one launch per frame."""
+    monkeypatch.setenv("GLRTX_NO_FEED", "1")
+    scene, params = scenes.CONFIGS["headline"](width=160, height=90)
+    seeds = _seeds(n_frames, 500)
+    want, _ = _plain(plain_device, scene, params, seeds)
+    d = gpu_device
+    _setup(d, scene, params)
+    d.render_frames(params, seeds); d.sync()
+    st = d.stats()
+    assert st.kernel_launches == 1 and st.feed_launches == 0
+    assert_bit_equal(d.read_accum(), want, f"{n_frames} frames in one plain launch")
+
+
+def test_light_triangles_in_lds_or_in_memory(gpu_device, monkeypatch):
+    """Up to 64 light triangles are staged into LDS (DevScene::lights_in_lds); GLRTX_NO_LDS_LIGHTS=1 (read at upload) and scenes with more lights read them from memory.
+    Same image, bit for bit, against the oracle."""
+    from oracle import pt_oracle
+    scene, params = scenes.CONFIGS["headline"](width=160, height=90)
+    ref, ref_rays = pt_oracle.render(scene, params)
+    d = gpu_device
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("GLRTX_NO_LDS_LIGHTS", env)
+        _setup(d, scene, params); d.count_rays(True)
+        d.render(params); d.sync()
+        assert d.stats().rays == ref_rays
+        assert_bit_equal(d.read_accum(), ref, f"lights in LDS off={env}")
+    monkeypatch.delenv("GLRTX_NO_LDS_LIGHTS")
+    d.count_rays(False)
+    # many lights (config 5's soup: every tenth triangle emits): more than fit, the global path
+    scene5, params5 = scenes.CONFIGS["c5"](width=160, height=90, n=4000)
+    assert scene5["light"].shape[0] > 64
+    ref5, _ = pt_oracle.render(scene5, params5)
+    _setup(d, scene5, params5)
+    d.render(params5); d.sync()
+    assert_bit_equal(d.read_accum(), ref5, "more lights than LDS holds")
