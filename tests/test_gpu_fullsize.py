@@ -225,3 +225,31 @@ def test_config4_4k_16spp_bands_equal_the_oracle(gpu_device):
     assert np.all(acc[..., 3] == 16.0)
     _assert_bands(acc, scene, p1, seeds16, bands, "c4 4K, 16 accumulated frames of 1 spp in flight")
     assert_bit_equal(_partitioned(d, scene, p1, seeds16), acc, "c4 4K, 16 frames, 8-rank partition vs one rank")
+
+
+def test_headline_two_multi_frame_calls_back_to_back_against_the_oracle(gpu_device):
+    """Round 6: two glrtx_render_frames(8) calls issued back to back at 1920x1080 -- the second is appended to the first one's launch while it
+    runs (a fed launch: pt_kernel.hip.h FeedHost / FeedDev) -- then eight single glrtx_render calls behind them, against the oracle's accumulation of the same 24
+    frames, ray count included; and the same calls with GLRTX_NO_FEED=1 (one launch per call).  tests/test_gpu_feed.py has the other burst shapes."""
+    import os
+    scene, params = scenes.config_headline()
+    seeds = _seeds(24)
+    ref, ref_rays = _oracle(scene, params, seeds)
+    d = gpu_device
+    for fed in (True, False):
+        if not fed:
+            os.environ["GLRTX_NO_FEED"] = "1"
+        try:
+            d.upload_scene(scene); d.set_partition(0, 1, 8); d.resize(params["width"], params["height"]); d.reset_stats(); d.count_rays(True)
+            d.render_frames(params, seeds[:8])
+            d.render_frames(params, seeds[8:16])
+            for sd in seeds[16:]:
+                d.render(dict(params, seed=sd))
+            d.sync()
+            st = d.stats()
+            assert st.rays == ref_rays and st.launches == 24
+            assert (st.feed_appended >= 8 and st.kernel_launches <= 3) if fed else (st.feed_appended == 0 and st.kernel_launches == 10)
+            assert_bit_equal(d.read_accum(), ref, f"two 8-frame calls and eight single ones back to back, fed={fed}")
+        finally:
+            os.environ.pop("GLRTX_NO_FEED", None)
+    d.count_rays(False)
