@@ -775,7 +775,7 @@ def main(argv=None):
                                      "frac": round(by / (resolve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms": round(resolve_ms, 4), "bytes": int(by),
                                      "single_launch_between_two_events_ms": None if resolve_single is None else round(resolve_single, 4),
                                      "what": f"{W}x{len(ys)}: rgb / count, clamp, pow(1 / 2.2), RGBA8; ms = per launch in a train of 32 launches (glrtx_debug_resolve_burst); "
-                                             "the pass is paced by its ~250 vector instructions a pixel as much as by memory (DESIGN.md section 9 row 7); "
+                                             "a one-shot kernel over 41 MB: its ramp and drain count as much as the streaming rate (DESIGN.md section 9 row 7: a version with a third of the instructions takes the same time); "
                                              "profiles/r06_aux_kernels.json has 4K"}
 
     cpu_baseline, oracle_check = None, None
