@@ -532,8 +532,12 @@ def main(argv=None):
                         continue
                     os.environ["GLRTX_NO_FEED"] = "1"
                 try:
-                    run(0, 8, per_launch=1)  # (untimed: every internal slot has its buffers)
-                    barrier()
+                    # untimed: every internal slot has its buffers.  Fed launches alternate between three slots and take their frames' planes 16 at a
+                    # time on demand (0.5 GB per hipMalloc at 1080p, ~1 ms each): three bursts of the timed length leave nothing to allocate inside the
+                    # timed one (an 8-frame warm-up did, until round 6's last session: 2.2 ms of allocations in a 48-frame burst)
+                    for _ in range(3):
+                        run(0, n1, per_launch=1)
+                        barrier()
                     st_a = R.stats()
                     t2 = time.perf_counter()
                     run(args.warmup, n1, per_launch=1)
@@ -741,6 +745,11 @@ def main(argv=None):
                     # launch shape (a launch of few frames carries more of the launch's fixed cost per frame)
                     "frac_of_profiled_dispatches": None if not prof.get("kernel_ms_per_frame_profiled") else
                         round(prof["vmem_insts_per_frame"] / (prof["kernel_ms_per_frame_profiled"] * 1e-3) / 1e9 / vmem_peak, 4),
+                    # the hardware's own figure carried over to this run: the profiled dispatches' busy counter times (their time per frame / this run's).  Since round 6
+                    # the priced model (`frac`) reads 0.09-0.11 above the counter (0.01-0.09 until round 5; its per-instruction prices are round 4's span measurements,
+                    # taken on round 4's kernel) -- of the two, this is the one to quote
+                    "frac_from_ta_busy": None if prof.get("ta_busy_frac") is None or not prof.get("kernel_ms_per_frame_profiled") else
+                        round(prof["ta_busy_frac"] * prof["kernel_ms_per_frame_profiled"] / (kernel_ms / max(frames_equiv, 1e-9)), 4),
                     "vmem_insts_per_launch": int(mi), "source": prof["file"],
                     "note": "SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR per frame (committed --pmc pass) / kernel time of this run, against what a CU's vector-memory pipe takes for "
                             "this mix: node fetches (4 per wave-step, tools/gpu_travstats.py) at the span-measured cost of their access pattern, everything else at the pipe's "

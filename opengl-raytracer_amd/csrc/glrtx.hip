@@ -123,6 +123,8 @@ struct glrtx_ctx {
     // Four words of host-coherent memory the persistent kernel's trip guards report through ({code, workgroup, trips without a tile, live paths}; pt_render_wgwf):
     // read -- and cleared -- when a launch is folded.
     unsigned *guard_host = nullptr, *guard_dev = nullptr;
+    hipEvent_t state_done = nullptr;  // the last render kernel that used wfState (plain launches on the context's stream, fed launches on their slot's) has ended
+    bool state_used = false;
 
     std::vector<int> leaf_tri;  // leaf record k of the uploaded scene -> wire triangle (glrtx_hit_histogram)
     unsigned *hit_hist_dev = nullptr;  // set only inside glrtx_hit_histogram
@@ -634,8 +636,10 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     const size_t frame_bytes = (size_t)std::max(p->n_samples, 1) * plane_bytes;
     int rc;
     // ---- which form
-    const bool burst = c->last_was_render && c->last_render_done && same_camera(c->last_p, *p) && hipEventQuery(c->last_render_done) == hipErrorNotReady;
+    // (busy: the context's last render kernel -- a slot's, or one on the context's stream -- has not ended yet)
+    const bool busy = c->last_render_done && hipEventQuery(c->last_render_done) == hipErrorNotReady;
     (void)hipGetLastError();
+    const bool burst = c->last_was_render && busy && same_camera(c->last_p, *p);
     bool fed = c->feed_ok && std::getenv("GLRTX_NO_FEED") == nullptr && c->pipeline && c->stream == c->own_stream && p->n_samples >= 1 && seeds_xy != nullptr && (n_frames > 1 || burst);
     int fed_cap = fed ? std::min(frames_cap(c, p, (int)kFedSlots), kFeedMaxFrames) : 0;
     if (const char *v = std::getenv("GLRTX_FEED_CAP")) fed_cap = std::max(1, std::min(fed_cap, std::atoi(v)));  // (tests: launches that fill up)
@@ -686,8 +690,8 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // of a group that share this GPU), a slot whose buffers cannot be allocated is given up -- the launch then runs plain on the context's stream instead of failing -- and
     // among the slots in use the next one whose previous launch has completed is taken (round robin only when none has), so that a launch never queues behind a busy slot
     // while an idle one exists.
-    // Shapes.  plain / fed: every workgroup keeps up to kWgPathsMax paths alive, less when the launch cannot give every resident workgroup that many pixels (a fed launch is
-    // sized as if it were to take 16 frames: it may).  overlapped: the frame in ONE helping per workgroup, spread over all the slots (the smallest power of two that holds
+    // Shapes.  plain / fed: every workgroup keeps up to kWgPathsMax paths alive, less when the launch is short (below; a fed launch is sized as if it were to take
+    // 16 frames: it may).  overlapped, issued while the context's last launch is still rendering: the frame in ONE helping per workgroup, spread over all the slots (the smallest power of two that holds
     // work / resident paths: 2048 at 1080p; with 1024 the workgroups come back for a second helping, 1.31 instead of 1.24 ms per frame, with 4096 half of them get
     // nothing, 1.67), every launch has the full grid and takes its tiles without guided self-scheduling, so its workgroups do not finish together -- one that finds the
     // tile counter exhausted and its paths dead leaves, and a workgroup of the next launch (queued on another stream) takes the slot (profiles/r03_ab_pipeline.txt).
@@ -695,8 +699,17 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
         const int resident = std::max(1, per_cu / std::max(share, 1)) * c->n_cu;
         const size_t work = total * (size_t)(is_fed ? std::max(n_frames, std::min(16, fed_cap)) : n_frames);
         block_paths = kWgPathsMax;
-        if (overlapped) { block_paths = 256; while (block_paths < kWgPathsMax && (size_t)resident * block_paths < work) block_paths *= 2; }
-        else while (block_paths > 256 && work < (size_t)resident * block_paths) block_paths /= 2;
+        if (overlapped && busy) { block_paths = 256; while (block_paths < kWgPathsMax && (size_t)resident * block_paths < work) block_paths *= 2; }
+        else {
+            // A launch ends with a tail in which its last paths run out -- about one path item's lifetime, and an item is a pixel's n_samples samples in sequence
+            // (their random numbers are one chain) -- and nothing overlaps that tail when the launch is alone on the device (plain, fed, or a single frame issued
+            // to an idle device).  Fewer paths per workgroup mean more, shorter helpings and a shorter tail, but slower trips: the most paths that still give the
+            // launch two helpings per workgroup (one sample per pixel) or four (more samples: longer items).  Lone launches, profiles/r06_launch_shapes.txt:
+            // 1080p 1 spp, one frame 2.4 -> 1.75 ms; 16 spp, one frame 39 -> 24 ms, four frames 19.4 -> 18.5; config 4 (4K, 16 spp), one frame 51 -> 39 ms.
+            const size_t tenths = p->n_samples > 1 ? 39 : 19;
+            while (block_paths > 512 && work * 10 < tenths * (size_t)resident * block_paths) block_paths /= 2;
+            while (block_paths > 256 && work < (size_t)resident * block_paths) block_paths /= 2;  // (small images: every workgroup of the grid has a full helping)
+        }
         if (const char *v = std::getenv("GLRTX_BLOCK_PATHS")) { const int x = std::atoi(v); if (x >= 256 && x <= kWgPathsMax && (x & (x - 1)) == 0) block_paths = x; }
         grid = std::max(1, (int)std::min<size_t>((size_t)resident, (work + block_paths - 1) / block_paths));
     };
@@ -704,7 +717,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     int pipe_busy = 0, block_paths = 0, grid = 0;
     if (piped) {
         shape(!fed, fed, 1, block_paths, grid);
-        const size_t per_slot = (size_t)kWfStatePlanes * (size_t)grid * block_paths * sizeof(float4) + (size_t)grid * kWgQueueF4 * sizeof(float4) + (fed ? 0 : frame_bytes);
+        const size_t per_slot = (fed ? 0 : (size_t)kWfStatePlanes * (size_t)grid * block_paths * sizeof(float4)) + (size_t)grid * kWgQueueF4 * sizeof(float4) + (fed ? 0 : frame_bytes);
         size_t budget = (size_t)kFramesBudgetGiB << 30;
         if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
         budget /= (size_t)std::max(c->budget_share, 1);
@@ -736,7 +749,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
                 std::memset(slot->feed_h->chunks, 0, sizeof slot->feed_h->chunks);
                 slot->chunk_bytes = frame_bytes;
             }
-            ok = ok && ensure(c, slot->state, (size_t)kWfStatePlanes * (size_t)grid * block_paths * sizeof(float4)) == GLRTX_OK;
+            if (!fed) ok = ok && ensure(c, slot->state, (size_t)kWfStatePlanes * (size_t)grid * block_paths * sizeof(float4)) == GLRTX_OK;
             ok = ok && ensure(c, slot->queues, (size_t)grid * kWgQueueF4 * sizeof(float4)) == GLRTX_OK;
             if (fed) ok = ok && ensure(c, slot->feed_d, sizeof(FeedDev)) == GLRTX_OK && feed_ensure_chunks(c, *slot, 0, n_frames, fed_cap, frame_bytes) == GLRTX_OK;
             else ok = ok && ensure(c, slot->planes, frame_bytes) == GLRTX_OK;
@@ -769,7 +782,12 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
         shape(false, false, 1, block_paths, grid);
     }
     if (slot) c->st.pipe_resident_max = std::max<int32_t>(c->st.pipe_resident_max, pipe_busy + 1);
-    DevBuf &stateBuf = slot ? slot->state : c->wfState;
+    // A fed launch runs on its slot's stream and queues but on the CONTEXT's path state, like a plain launch: the same launch is 0.8 % faster there than on a slot's state
+    // buffer (same-context A/B, two boxes, profiles/r06_ab_feed_cadence.txt -- where a 0.8-GB buffer lands physically decides what its stream of stores costs:
+    // profiles/r04_context_regimes.txt).  Launches that share that buffer run one after the other (state_done below): fed launches end all their workgroups together,
+    // so there was nothing for them to overlap with anyway.
+    const bool ctx_state = !slot || fed;
+    DevBuf &stateBuf = ctx_state ? c->wfState : slot->state;
     DevBuf &queueBuf = slot ? slot->queues : c->wfQ;
     DevBuf &planeBuf = slot ? slot->planes : c->wfPlanes;
     unsigned *const workPtr = (unsigned *)(slot ? slot->work.p : c->work.p);
@@ -850,6 +868,8 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     if ((rc = next_launch_rec(c, rec))) return rc;
     // a slot's render kernel overwrites the planes its previous plane-accumulation pass (two launches ago, on the context's stream) reads
     if (slot && slot->used) HIP_TRY(c, hipStreamWaitEvent(rstream, slot->acc_done, 0));
+    // ... and a kernel on the context's path state starts behind the last one that used it (another stream's, possibly)
+    if (ctx_state && c->state_used) HIP_TRY(c, hipStreamWaitEvent(rstream, c->state_done, 0));
     HIP_TRY(c, hipMemsetAsync(workPtr, 0, sizeof(unsigned), rstream));
     if (fed) {  // the device mirror starts with the frames published so far (kernel boundary: visible to every workgroup of the render kernel)
         hipLaunchKernelGGL(feed_prefill_kernel, dim3(1), dim3(64), 0, rstream, (FeedDev *)slot->feed_d.p, (const FeedHost *)slot->feed_h_dev, n_frames);
@@ -864,6 +884,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     g_dbg_last = {a, w, lds, grid, (float4 *)queueBuf.p, fetch};
 #endif
     HIP_TRY(c, hipEventRecord(rec->evm, rstream));
+    if (ctx_state) { HIP_TRY(c, hipEventRecord(c->state_done, rstream)); c->state_used = true; }
     if (slot) {  // the context's stream -- where the caller's own work, the resolve pass and the next accumulation are ordered -- takes over
         HIP_TRY(c, hipEventRecord(slot->render_done, rstream));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, slot->render_done, 0));
@@ -885,7 +906,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     c->st.frames_last = n_frames;
     c->st.paths += (uint64_t)c->owned_rows * (uint64_t)c->width * (uint64_t)p->n_samples * (uint64_t)n_frames;
     // what the next call may build on
-    c->last_render_done = slot ? slot->render_done : nullptr;
+    c->last_render_done = slot ? slot->render_done : c->state_done;  // (a plain launch runs on the context's path state: ctx_state above)
     if (fed) {
         c->open.slot = slot; c->open.p = *p; c->open.frames = n_frames; c->open.cap = fed_cap; c->open.rec = rec; c->open.frame_bytes = frame_bytes;
         c->st.feed_launches++;
@@ -929,6 +950,7 @@ int glrtx_create(glrtx_ctx **out, int device_id) {
         (e = hipMalloc(&c->counter.p, 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(c->counter.p, 0, 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc(&c->work.p, 64)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->state_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->guard_host, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer((void **)&c->guard_dev, c->guard_host, 0)) != hipSuccess) {
         fail(nullptr, GLRTX_EDEVICE, "context setup failed: %s", hipGetErrorString(e));
@@ -1012,6 +1034,7 @@ void glrtx_destroy(glrtx_ctx *c) {
     if (c->rs1) (void)hipEventDestroy(c->rs1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->guard_host) (void)hipHostFree(c->guard_host);
+    if (c->state_done) (void)hipEventDestroy(c->state_done);
     delete c;
 }
 

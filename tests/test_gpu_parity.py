@@ -798,6 +798,35 @@ def test_path_state_does_not_grow_with_the_frames_in_flight(gpu_device):
     assert sizes[0] == sizes[1] > 0 and sizes[0] % 3 == 0, sizes
 
 
+def test_a_launch_alone_on_the_device_is_shaped_for_its_tail(gpu_device, monkeypatch):
+    """Round 6 (glrtx.hip, launch_wgwf `shape`): a launch ends with a tail in which its last paths run out, and nothing overlaps that tail when the launch is alone on the
+    device -- so a single frame issued to an idle device keeps fewer paths per workgroup alive (more, shorter helpings) than the same frame issued while the previous one is
+    still rendering (one helping, handed over to the next launch), fewer still when a path item is several samples long -- and all of them render the same image."""
+    d = gpu_device
+    monkeypatch.setenv("GLRTX_NO_FEED", "1")  # (every call a launch of its own: the second of two back-to-back calls is an overlapped launch, not a fed one)
+    scene, params = scenes.config_c2(width=1920, height=1080, max_depth=5, subdiv=1)
+    seeds = _seeds(3)
+    want, _ = gpu_render(d, scene, params, frames=seeds)
+    d.clear(); d.sync()
+    d.render(dict(params, seed=seeds[0])); d.sync()
+    lone = d.stats().wf_state_mib
+    d.render(dict(params, seed=seeds[1])); d.render(dict(params, seed=seeds[2])); busy = d.stats().wf_state_mib; d.sync()
+    assert_bit_equal(d.read_accum(), want, "lone and overlapped single-frame launches")
+    assert 0 < lone < busy, (lone, busy)  # (1024 against 2048 paths per workgroup on a 256-CU device)
+    d.clear(); d.sync()
+    d.render(dict(params, seed=seeds[0], n_samples=4)); d.sync()
+    assert 0 < d.stats().wf_state_mib < lone, (d.stats().wf_state_mib, lone)  # (512)
+    ref = None
+    from oracle import pt_oracle
+    small_scene, small = scenes.config_c1(width=96, height=64, max_depth=4, n_samples=3, subdiv=1)
+    for sd in seeds:
+        ref, _ = pt_oracle.render(small_scene, dict(small, seed=sd), accum=ref)
+    for bp in ("4096", "512", "256"):
+        monkeypatch.setenv("GLRTX_BLOCK_PATHS", bp)
+        got, _ = gpu_render(d, small_scene, small, frames=seeds)
+        assert_bit_equal(got, ref, f"block_paths {bp}")
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (3, 2), (17, 1), (1, 33), (9, 9)])
 def test_tiny_images_single_and_in_flight(gpu_device, w, h):
     """Images far smaller than a tile / a workgroup's path set: one frame per launch and four in flight vs the oracle."""

@@ -7,6 +7,7 @@ reads its GLRTX_* switches at every launch), per pass:
   lone20 / lone48   kernel time of ONE glrtx_render_frames launch of 20 / 48 frames, device idle before and after       (ms per frame)
   b2b16             wall time of 6 back-to-back glrtx_render_frames launches of 16 frames, one sync at the end           (ms per frame)
   one_per_frame     wall time of 96 back-to-back glrtx_render calls, one sync at the end (window.cpp:121-169's cadence)  (ms per frame)
+  sync_per_frame    wall time of 32 glrtx_render calls with a glrtx_sync behind each (a host that looks at every frame)   (ms per frame)
 and the image of the whole sequence (sha1 of the accumulator) -- every setting must give the same one.  Prints the medians over the passes."""
 import hashlib
 import os
@@ -58,6 +59,9 @@ def one_pass():
     d.sync(); t0 = time.perf_counter()
     for k in range(96): d.render(dict(pr, seed=host.frame_seed(f))); f += 1
     d.sync(); out["one_per_frame"] = (time.perf_counter() - t0) * 1e3 / 96
+    d.sync(); t0 = time.perf_counter()
+    for k in range(32): d.render(dict(pr, seed=host.frame_seed(f))); d.sync(); f += 1
+    out["sync_per_frame"] = (time.perf_counter() - t0) * 1e3 / 32
     out["sha1"] = hashlib.sha1(np.ascontiguousarray(d.read_accum()).view(np.uint8)).hexdigest()[:16]
     return out
 
@@ -73,8 +77,8 @@ first = None
 for name, env in settings:
     r = res[name]
     first = first or r[0]["sha1"]
-    med = {k: float(np.median([x[k] for x in r])) for k in ("lone20", "lone48", "b2b16", "one_per_frame")}
+    med = {k: float(np.median([x[k] for x in r])) for k in ("lone20", "lone48", "b2b16", "one_per_frame", "sync_per_frame")}
     same = "same image" if all(x["sha1"] == first for x in r) else "IMAGE DIFFERS"
-    print(f"{name:24s} lone20 {med['lone20']:.4f}  lone48 {med['lone48']:.4f}  b2b16 {med['b2b16']:.4f}  one_per_frame {med['one_per_frame']:.4f} ms/frame   {same}   {env}", flush=True)
+    print(f"{name:24s} lone20 {med['lone20']:.4f}  lone48 {med['lone48']:.4f}  b2b16 {med['b2b16']:.4f}  one_per_frame {med['one_per_frame']:.4f}  sync_per_frame {med['sync_per_frame']:.4f} ms/frame   {same}   {env}", flush=True)
 st = d.stats()
 print(f"pipe_slots {st.pipe_slots} pipe_resident_max {st.pipe_resident_max} wf_state_mib {st.wf_state_mib}", flush=True)
