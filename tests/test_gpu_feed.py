@@ -274,3 +274,20 @@ def test_light_triangles_in_lds_or_in_memory(gpu_device, monkeypatch):
     _setup(d, scene5, params5)
     d.render(params5); d.sync()
     assert_bit_equal(d.read_accum(), ref5, "more lights than LDS holds")
+
+
+def test_a_burst_behind_a_plain_launch_is_fed(gpu_device, plain_device):
+    """A frame whose sample planes exceed the overlapped form's 1-GiB limit (1080p at 33 spp: 1.09 GB) is a plain launch on the context's stream.  Since the end of round 6 such a
+    launch counts as the start of a burst as well (its completion event is the context's path state's): the calls behind it open a fed launch and are appended to it.
+    (Config 4, one glrtx_render per frame: 51.5 -> 30.9 ms per frame, profiles/r06_launch_shapes.txt.)  Same image as one launch per frame."""
+    scene, params = scenes.config_c2(width=1920, height=1080, max_depth=1, n_samples=33, subdiv=1)
+    seeds = _seeds(4)
+    want, _ = _plain(plain_device, scene, params, seeds)
+    d = gpu_device
+    _setup(d, scene, params)
+    for sd in seeds:
+        d.render(dict(params, seed=sd))
+    d.sync()
+    st = d.stats()
+    assert st.launches == 4 and st.feed_launches >= 1 and st.kernel_launches < 4, (st.launches, st.feed_launches, st.kernel_launches, st.feed_appended)
+    assert_bit_equal(d.read_accum(), want, "burst behind a plain launch")
