@@ -695,11 +695,11 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     // work / resident paths: 2048 at 1080p; with 1024 the workgroups come back for a second helping, 1.31 instead of 1.24 ms per frame, with 4096 half of them get
     // nothing, 1.67), every launch has the full grid and takes its tiles without guided self-scheduling, so its workgroups do not finish together -- one that finds the
     // tile counter exhausted and its paths dead leaves, and a workgroup of the next launch (queued on another stream) takes the slot (profiles/r03_ab_pipeline.txt).
-    auto shape = [&](bool overlapped, bool is_fed, int share, int &block_paths, int &grid) {
+    auto shape = [&](bool overlapped, bool is_fed, int share, bool device_busy, int &block_paths, int &grid) {
         const int resident = std::max(1, per_cu / std::max(share, 1)) * c->n_cu;
         const size_t work = total * (size_t)(is_fed ? std::max(n_frames, std::min(16, fed_cap)) : n_frames);
         block_paths = kWgPathsMax;
-        if (overlapped && busy) { block_paths = 256; while (block_paths < kWgPathsMax && (size_t)resident * block_paths < work) block_paths *= 2; }
+        if (overlapped && device_busy) { block_paths = 256; while (block_paths < kWgPathsMax && (size_t)resident * block_paths < work) block_paths *= 2; }
         else {
             // A launch ends with a tail in which its last paths run out -- about one path item's lifetime, and an item is a pixel's n_samples samples in sequence
             // (their random numbers are one chain) -- and nothing overlaps that tail when the launch is alone on the device (plain, fed, or a single frame issued
@@ -716,8 +716,12 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     glrtx_ctx::PipeSlot *slot = nullptr;
     int pipe_busy = 0, block_paths = 0, grid = 0;
     if (piped) {
-        shape(!fed, fed, 1, block_paths, grid);
-        const size_t per_slot = (fed ? 0 : (size_t)kWfStatePlanes * (size_t)grid * block_paths * sizeof(float4)) + (size_t)grid * kWgQueueF4 * sizeof(float4) + (fed ? 0 : frame_bytes);
+        shape(!fed, fed, 1, busy, block_paths, grid);
+        // (an overlapped slot's path state holds either of a single frame's two shapes -- issued to an idle or to a busy device: growing it later would free memory, and
+        //  freeing waits for the device)
+        size_t slot_state_entries = (size_t)grid * block_paths;
+        if (!fed) { int b2 = 0, g2 = 0; shape(true, false, 1, !busy, b2, g2); slot_state_entries = std::max(slot_state_entries, (size_t)g2 * b2); }
+        const size_t per_slot = (fed ? 0 : (size_t)kWfStatePlanes * slot_state_entries * sizeof(float4)) + (size_t)grid * kWgQueueF4 * sizeof(float4) + (fed ? 0 : frame_bytes);
         size_t budget = (size_t)kFramesBudgetGiB << 30;
         if (const char *v = std::getenv("GLRTX_FRAMES_BUDGET_MB")) budget = (size_t)std::max(1, std::atoi(v)) << 20;
         budget /= (size_t)std::max(c->budget_share, 1);
@@ -736,7 +740,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
             for (unsigned k = 0; k < kPipeSlots; k++)
                 if (k != pick && c->pipe[k].used && hipEventQuery(c->pipe[k].render_done) == hipErrorNotReady) pipe_busy++;
             (void)hipGetLastError();
-            if (c->pipe_share > 1 && pipe_busy > 0 && !fed) shape(true, false, c->pipe_share, block_paths, grid);  // (GLRTX_PIPE_SHARE: the round-3 form, A/B only)
+            if (c->pipe_share > 1 && pipe_busy > 0 && !fed) shape(true, false, c->pipe_share, busy, block_paths, grid);  // (GLRTX_PIPE_SHARE: the round-3 form, A/B only)
             // the slot's buffers, before anything depends on them.  A fed launch's plane chunks hold a given number of bytes per frame: another size starts afresh
             // (the slot's last launch is waited for first: freeing memory waits for the device anyway)
             bool ok = true;
@@ -749,7 +753,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
                 std::memset(slot->feed_h->chunks, 0, sizeof slot->feed_h->chunks);
                 slot->chunk_bytes = frame_bytes;
             }
-            if (!fed) ok = ok && ensure(c, slot->state, (size_t)kWfStatePlanes * (size_t)grid * block_paths * sizeof(float4)) == GLRTX_OK;
+            if (!fed) ok = ok && ensure(c, slot->state, (size_t)kWfStatePlanes * slot_state_entries * sizeof(float4)) == GLRTX_OK;
             ok = ok && ensure(c, slot->queues, (size_t)grid * kWgQueueF4 * sizeof(float4)) == GLRTX_OK;
             if (fed) ok = ok && ensure(c, slot->feed_d, sizeof(FeedDev)) == GLRTX_OK && feed_ensure_chunks(c, *slot, 0, n_frames, fed_cap, frame_bytes) == GLRTX_OK;
             else ok = ok && ensure(c, slot->planes, frame_bytes) == GLRTX_OK;
@@ -779,7 +783,7 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
     }
     if (!slot) {
         if (n_frames > frames_cap(c, p, 1)) return fail(c, GLRTX_ENOMEM, "glrtx_render_frames: %d frames exceed the frames-in-flight memory budget", n_frames);
-        shape(false, false, 1, block_paths, grid);
+        shape(false, false, 1, busy, block_paths, grid);
     }
     if (slot) c->st.pipe_resident_max = std::max<int32_t>(c->st.pipe_resident_max, pipe_busy + 1);
     // A fed launch runs on its slot's stream and queues but on the CONTEXT's path state, like a plain launch: the same launch is 0.8 % faster there than on a slot's state
