@@ -807,6 +807,8 @@ def test_a_launch_alone_on_the_device_is_shaped_for_its_tail(gpu_device, monkeyp
     scene, params = scenes.config_c2(width=1920, height=1080, max_depth=5, subdiv=1)
     seeds = _seeds(3)
     want, _ = gpu_render(d, scene, params, frames=seeds)
+    for k in range(8):  # (every pipe slot has its buffers: an allocation between two calls below could outlast the first one's launch)
+        d.render(dict(params, seed=seeds[0]))
     d.clear(); d.sync()
     d.render(dict(params, seed=seeds[0])); d.sync()
     lone = d.stats().wf_state_mib
