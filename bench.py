@@ -46,6 +46,7 @@ and in config: `strong` (N > 1: a fixed --steps-per-launch (48) frames in flight
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import pathlib
@@ -485,6 +486,10 @@ def main(argv=None):
     same = (R.accum.view(torch.int32) == counted_img.view(torch.int32)).all().to(torch.int32).reshape(1)
     del counted_img
     clear_accum()
+    # no collector pauses inside anything timed below: a full collection of a process that has imported torch takes ~50 ms on this host -- nothing for a launch that is
+    # already enqueued, 1.5 ms per frame for a leg of 32 calls with a sync behind each (seen in config 5's line: profiles/r06_launch_shapes.txt)
+    gc.collect()
+    gc.disable()
     run(0, args.warmup, prepared=warm_launches)
     R.sync()  # the first host wait since the preamble began; it is part of the barrier that opens the timed region
     st0 = R.stats()
@@ -519,7 +524,7 @@ def main(argv=None):
     # Round 6: on the context's OWN stream -- where nothing but library calls can order work against the accumulator -- such a burst of calls runs as one fed launch (the
     # calls behind the first publish their frames to the launch that is already running: glrtx.hip feed_append); with GLRTX_NO_FEED=1 every call is a launch of its own,
     # overlapped with its neighbours (round 3), which is also what a render-resolve-save loop and a caller's stream get.  Both are measured, the same frames each.
-    single, single_overlapped, single_feed = None, None, None
+    single, single_overlapped, single_feed, single_synced, single_overlapped_slots, single_synced_stats = None, None, None, None, {}, {}
     if world == 1 and S > 1 and not args.no_single:
         n1 = max(args.steps, 48)  # (a burst: its one ramp and one drain are spread over this many frames)
         own = hasattr(R, "use_own_stream")
@@ -553,6 +558,28 @@ def main(argv=None):
                                    "frames_appended_to_a_running_launch": int(getattr(st_b, "feed_appended", 0) - getattr(st_a, "feed_appended", 0))}
                 else:
                     single_overlapped = dt
+                    single_overlapped_slots = {"pipe_slots": int(getattr(st_b, "pipe_slots", 0)), "pipe_resident_max": int(getattr(st_b, "pipe_resident_max", 0)),
+                                               "kernel_launches": int(st_b.kernel_launches - st_a.kernel_launches)}
+            # ... and with a sync behind every call: a host that looks at every frame before it asks for the next one.  Every launch is then alone on the device (and is
+            # shaped for its tail: glrtx.hip, launch_wgwf `shape`)
+            n_sync = min(n1, 32)
+            barrier()
+            R.sync()
+            st_a = R.stats()
+            t2 = time.perf_counter()
+            t_call = 0.0
+            for i in range(n_sync):
+                t3 = time.perf_counter()
+                run(args.warmup + i, 1, per_launch=1)
+                t_call += time.perf_counter() - t3
+                barrier()
+            single_synced = (time.perf_counter() - t2) / n_sync
+            R.sync()
+            st_b = R.stats()
+            single_synced_stats = {"kernel_ms_per_launch": round((st_b.kernel_ms_total - st_a.kernel_ms_total) / n_sync, 4), "wf_state_mib": int(getattr(st_b, "wf_state_mib", 0)),
+                                   "accumulate_ms_per_launch": round((getattr(st_b, "accumulate_ms_total", 0.0) - getattr(st_a, "accumulate_ms_total", 0.0)) / n_sync, 4),
+                                   "host_ms_in_the_call": round(t_call * 1e3 / n_sync, 4),
+                                   "feed_launches": int(getattr(st_b, "feed_launches", 0) - getattr(st_a, "feed_launches", 0))}
         finally:
             if own:
                 R.use_own_stream(False)
@@ -673,6 +700,8 @@ def main(argv=None):
     strong_s = float(elapsed[1].item()) if float(elapsed[1].item()) > 0 and strong_err is None else None  # (MAX over ranks: -1 everywhere = not measured)
     traced_rays = ref_rays - total_untraced
     n_frames = args.steps * world
+
+    gc.enable()
 
     # ---- rooflines of the render kernel (per launch, per GPU)
     scene_b = scenes.scene_bytes(scene)
@@ -912,9 +941,12 @@ def main(argv=None):
                                     "read-back): the calls behind the first feed the launch that is already running",
                             **(single_feed or {}),
                             "overlapped_launches": None if single_overlapped is None else
-                                {"ms_per_step": round(single_overlapped * 1e3, 4), "value": round(traced_rays / args.steps / single_overlapped / 1e6, 3),
+                                {"ms_per_step": round(single_overlapped * 1e3, 4), "value": round(traced_rays / args.steps / single_overlapped / 1e6, 3), **single_overlapped_slots,
                                  "what": "the same calls with GLRTX_NO_FEED=1: one launch per call, overlapped with its neighbours (round 3) -- what a loop that resolves "
-                                         "every frame, or a caller's stream, gets"}},
+                                         "every frame, or a caller's stream, gets"},
+                            "synced_launches": None if single_synced is None else
+                                {"ms_per_step": round(single_synced * 1e3, 4), "value": round(traced_rays / args.steps / single_synced / 1e6, 3), "frames": min(max(args.steps, 48), 32), **single_synced_stats,
+                                 "what": "a glrtx_sync behind every call: every launch alone on the device, wall time per frame"}},
                        "rays_per_frame": round(traced_rays / n_frames, 1),
                        # the reference's algorithm also executes intersect() for shadow rays whose light test cannot change the
                        # radiance (both outcomes bit-identical); those are resolved without a traversal and NOT part of `value`

@@ -704,9 +704,10 @@ int launch_wgwf(glrtx_ctx *c, const KernelArgs &a_in, const glrtx_params *p, con
             // A launch ends with a tail in which its last paths run out -- about one path item's lifetime, and an item is a pixel's n_samples samples in sequence
             // (their random numbers are one chain) -- and nothing overlaps that tail when the launch is alone on the device (plain, fed, or a single frame issued
             // to an idle device).  Fewer paths per workgroup mean more, shorter helpings and a shorter tail, but slower trips: the most paths that still give the
-            // launch two helpings per workgroup (one sample per pixel) or four (more samples: longer items).  Lone launches, profiles/r06_launch_shapes.txt:
-            // 1080p 1 spp, one frame 2.4 -> 1.75 ms; 16 spp, one frame 39 -> 24 ms, four frames 19.4 -> 18.5; config 4 (4K, 16 spp), one frame 51 -> 39 ms.
-            const size_t tenths = p->n_samples > 1 ? 39 : 19;
+            // launch two helpings per workgroup (several frames of one sample per pixel) or four (more samples: longer items; a single frame: its tail is as long
+            // as the rest of it).  Lone launches, profiles/r06_launch_shapes.txt: 1080p 1 spp, one frame 2.4 -> 1.67 ms (config 2: 2.1 -> 1.39, config 3: 17.0 -> 11.4,
+            // config 5: 4.6 -> 3.1); 16 spp, one frame 39 -> 24 ms, four frames 19.4 -> 18.5; config 4 (4K, 16 spp), one frame 51 -> 39 ms.
+            const size_t tenths = (p->n_samples > 1 || (n_frames == 1 && !is_fed)) ? 39 : 19;
             while (block_paths > 512 && work * 10 < tenths * (size_t)resident * block_paths) block_paths /= 2;
             while (block_paths > 256 && work < (size_t)resident * block_paths) block_paths /= 2;  // (small images: every workgroup of the grid has a full helping)
         }

@@ -72,6 +72,10 @@ def test_bench_prints_one_contract_json_line():
     for k in aux.values():
         assert k["bound"] == "hbm" and k["peak"] == 8000.0 and 0.05 < k["frac"] < 1.0 and abs(k["achieved"] - k["bytes"] / (k["ms"] * 1e-3) / 1e9) / k["achieved"] < 1e-2
     assert "bit-identical" in cfg["timed_kernel_image_check"] and cfg["strong"] is None
+    # one glrtx_render per frame, three cadences: a burst (fed), the same as overlapped launches, and a sync behind every call (every launch alone on the device)
+    one = cfg["one_launch_per_frame"]
+    assert one["frames_appended_to_a_running_launch"] > 0 and one["kernel_launches"] < one["frames"]
+    assert 0 < one["ms_per_step"] < one["overlapped_launches"]["ms_per_step"] < one["synced_launches"]["ms_per_step"] < 10 * one["ms_per_step"], one
     pred = cfg["predicted"]
     assert set(pred) == {"2", "4", "8"} and all(0.5 < v["ms_per_step"] / out["ms_per_step"] < 2.0 for v in pred.values())
     cb = out["cpu_baseline"]

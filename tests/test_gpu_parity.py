@@ -814,10 +814,13 @@ def test_a_launch_alone_on_the_device_is_shaped_for_its_tail(gpu_device, monkeyp
     lone = d.stats().wf_state_mib
     d.render(dict(params, seed=seeds[1])); d.render(dict(params, seed=seeds[2])); busy = d.stats().wf_state_mib; d.sync()
     assert_bit_equal(d.read_accum(), want, "lone and overlapped single-frame launches")
-    assert 0 < lone < busy, (lone, busy)  # (1024 against 2048 paths per workgroup on a 256-CU device)
+    assert 0 < lone < busy, (lone, busy)  # (512 against 2048 paths per workgroup on a 256-CU device)
     d.clear(); d.sync()
-    d.render(dict(params, seed=seeds[0], n_samples=4)); d.sync()
-    assert 0 < d.stats().wf_state_mib < lone, (d.stats().wf_state_mib, lone)  # (512)
+    d.render_frames(params, seeds[:2]); d.sync()   # (two frames in one plain launch: two helpings of 2048)
+    assert lone < d.stats().wf_state_mib, (d.stats().wf_state_mib, lone)
+    want2, _ = gpu_render(d, scene, params, frames=seeds[:2])
+    d.clear(); d.render_frames(params, seeds[:2]); d.sync()
+    assert_bit_equal(d.read_accum(), want2, "two frames in one short plain launch")
     ref = None
     from oracle import pt_oracle
     small_scene, small = scenes.config_c1(width=96, height=64, max_depth=4, n_samples=3, subdiv=1)
