@@ -1,3 +1,6 @@
+"""Config 4 (4K, 16 spp), eight glrtx_render calls back to back on the context's own stream, twice: issue time, wall time per frame, kernel launches, fed launches and
+appended frames -- does a burst behind a PLAIN launch (a frame whose sample planes exceed the overlapped form's 1 GiB) become a fed launch?  (profiles/r06_launch_shapes.txt)
+    python tools/gpu_c4_probe.py"""
 import sys, os, time
 sys.path.insert(0,'.'); sys.path.insert(0,'opengl-raytracer_amd/python')
 from glrt_amd import device, host, scenes

@@ -1,3 +1,5 @@
+# The wavefront kernel's run-time knobs on config 5 (refill threshold, parking limit, paths per workgroup, workgroups per CU, self-scheduling divisor, node-fetch form):
+# tools/gpu_ab_env.py, one context, the two settings alternating, 10 rounds of 16 frames, GLRTX_NO_FEED=1.  -> profiles/r06_c5_tune.txt
 L=opengl-raytracer_amd/lib/libglrtx.so
 export GLRTX_NO_FEED=1
 O="--contexts 1 --rounds 10 --frames 16 --config c5"

@@ -1,3 +1,7 @@
+"""Where a workgroup's time goes (libglrtx_phase.so, -DGLRTX_PHASE_STATS): shader clocks of the top-up / traverse / shade phases and of the barrier waits behind them, summed
+over the workgroups of one launch; the refill sections and stepping blocks of wave 0 inside the traverse phase.
+    [GLRTX_PHASE_CONFIG=headline|c2..c5] [GLRTX_PHASE_LIB=libglrtx_phase.so] python tools/gpu_phase.py [frames per launch = 16]
+"""
 import sys, ctypes as C; sys.path.insert(0,'.'); sys.path.insert(0,'opengl-raytracer_amd/python')
 import numpy as np
 from glrt_amd import scenes, device, host

@@ -1,3 +1,7 @@
+"""Traversal statistics of a config (libglrtx_stats.so, -DGLRTX_TRAV_STATS: the C++ statement of the step with counters): wave-steps, lanes and cache lines per step, steps per
+ray; GLRTX_TRAVSTATS_JSON=path writes them as JSON (tools/profile.sh -> profiles/<tag>_travstats.json, which bench.py's roofline_vmem prices the node fetches with).
+    python tools/gpu_travstats.py [config = headline] [frames]
+"""
 import sys, ctypes as C; sys.path.insert(0,'.'); sys.path.insert(0,'opengl-raytracer_amd/python')
 import numpy as np
 from glrt_amd import scenes, device, host

@@ -1,3 +1,6 @@
+"""Kernel names, dispatch counts, mean and minimum durations out of a rocprofv3 rocpd (SQLite) output directory.
+    python tools/rocpd_kernels.py DIR [rows = 8]
+"""
 import sqlite3,sys,glob
 db=sqlite3.connect(glob.glob(sys.argv[1]+'/*.db')[0])
 rows=db.execute("select name, count(*), avg(end-start), min(end-start) from kernels group by name order by 3 desc").fetchall()
