@@ -11,8 +11,9 @@
 //   node = 3 x vec3 = { bboxMin, bboxMax, children }
 //   fork : children = (left, right, -1)      leaf : children = (-1, -1, triIndex)
 //   root = node 0, nodes in DFS pre-order, exactly one triangle per leaf.
-// Closest-hit results do not depend on the tree shape (only exact ties do), so
-// any valid tree is parity-equivalent.
+// A closest hit does not depend on the tree shape except at exact ties and where the reference's float slab test
+// rejects a box whose triangle the ray would hit (grazing rays, flat boxes: a few pixels in ten thousand): the
+// device layer is bit-exact for the tree it is handed, whichever builder made it.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -946,7 +947,7 @@ int glrt_bvh_add_shadow_hits(uint32_t *tri_hits, size_t n_tri, const float *tri,
 // the candidates, so the sum of the forks' areas -- the expected number of box visits of a ray that culls nothing, which is what the reference's fixed-order traversal
 // does until its first hit -- never rises.  Passes repeat until one gains less than 0.1 %.  The children of every fork are then put in a top-down builder's order and the
 // result is renumbered in DFS pre-order (root = node 0, x child first).  Measured: config 5 -2.9 % per frame (its fork area: -2.9 %), config 4 -0.6 %, headline -0.1 %.
-// Closest-hit results do not depend on the tree (exact ties aside: SURVEY.md H4).
+// Closest-hit results do not depend on the tree (exact ties and grazing-ray box misses aside: SURVEY.md H4).
 // nodes: wire format, modified in place.  cost_out (may be NULL): [0] the summed fork area / root area before, [1] after.  Returns the number of subtrees that moved,
 // 0 for trees it leaves alone (fewer than 4 leaves, absent children, non-finite boxes), or a negative GLRT_HOST_E* code for a malformed tree.
 int glrt_bvh_reinsert(float *nodes, size_t n_nodes, int max_passes, int *max_depth_out, double *cost_out) {
