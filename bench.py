@@ -732,6 +732,11 @@ def main(argv=None):
             break
         if stale is None:
             stale = f"{pj['file']} was taken from kernel sources {pj.get('kernel_source_sha16')}, this build is {kernel_source_sha16()}"
+    # which tree the committed counters of this config were taken under (tools/profile.sh's third argument; profiles/README.md), against this run's
+    profiled_bvh = {"c5": "sah-gpu"}.get(args.config, "default")
+    tree_note = None if args.bvh == profiled_bvh else (
+        f"the committed counters were taken under --bvh {profiled_bvh}, this run's tree is --bvh {args.bvh}: instructions and bytes per frame follow the steps per ray "
+        "(the CPU and the device SAH trees: within 1 % of each other; reinserted trees: ~4 % fewer), so the issue rooflines and `traffic` of this line are that approximate")
     if prof is not None and prof.get("clock_ghz"):
         frames_equiv = frames_per_launch * len(ys) / H
         sec = kernel_ms * 1e-3
@@ -751,7 +756,7 @@ def main(argv=None):
                 "effective_fp32_lane_frac": None if prof.get("lane_util") is None else round(rate / valu_peak * prof["lane_util"], 4),
                 "simd_issue_busy_estimate": [round(issue_lo, 3), round(issue_hi, 3)],
                 "wave_cycles_waiting_frac": prof.get("wave_cycles_waiting_frac"),
-                "valu_insts_per_launch": int(vi), "salu_insts_per_launch": int(si), "branch_insts_per_launch": int(bi), "source": prof["file"],
+                "valu_insts_per_launch": int(vi), "salu_insts_per_launch": int(si), "branch_insts_per_launch": int(bi), "source": prof["file"], "profiled_tree": tree_note or "this run's",
                 "note": "SQ_INSTS_VALU per frame from the committed rocprofv3 --pmc pass of this command / kernel time measured in this run; peak = 1024 SIMDs x the clock "
                         "the profiled kernel ran at (GRBM_GUI_ACTIVE / 8 / duration) / 1.97 clk per wave64 v_fma/v_add/v_mul (profiles/r04_ubench_valu.txt, measured at "
                         "the same in-kernel clock); simd_issue_busy_estimate adds the scalar and branch instructions the SIMDs issue beside them; lane_util = "
@@ -779,7 +784,7 @@ def main(argv=None):
                     # taken on round 4's kernel) -- of the two, this is the one to quote
                     "frac_from_ta_busy": None if prof.get("ta_busy_frac") is None or not prof.get("kernel_ms_per_frame_profiled") else
                         round(prof["ta_busy_frac"] * prof["kernel_ms_per_frame_profiled"] / (kernel_ms / max(frames_equiv, 1e-9)), 4),
-                    "vmem_insts_per_launch": int(mi), "source": prof["file"],
+                    "vmem_insts_per_launch": int(mi), "source": prof["file"], "profiled_tree": tree_note or "this run's",
                     "note": "SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR per frame (committed --pmc pass) / kernel time of this run, against what a CU's vector-memory pipe takes for "
                             "this mix: node fetches (4 per wave-step, tools/gpu_travstats.py) at the span-measured cost of their access pattern, everything else at the pipe's "
                             "floor, times the kernel's own clock.  ta_busy_counter = TA_TA_BUSY_sum / 256 / (GRBM_GUI_ACTIVE / 8) of the profiled dispatches (0.965-0.98 on the "
