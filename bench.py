@@ -162,6 +162,10 @@ class GpuRenderer:
             nodes, depth, build_ms = self.dev.build_bvh_sah(scene["vert"], scene["tri"])
             nodes, lf = host.lights_first(nodes, scene["tri"], scene["mat"])
             self.scene = dict(scene, bvh=nodes, bvh_depth=depth, bvh_kind=f"SAH by levels, built on the GPU in {build_ms:.2f} ms", bvh_lights_first=lf)
+        elif bvh == "reference":  # the reference host's own tree: its builder restated rule for rule (glrt_bvh_build_reference), left in its own child order
+            from glrt_amd import scenes as _scenes
+            self.scene = _scenes.rebuild_bvh(scene, "reference")
+            self.scene["bvh_kind"] = "the reference host's own tree (bvh.cpp:72-160 restated: one axis binned, never re-ordered)"
         elif bvh in ("sah-reinsert", "sah-hits", "sah-reinsert-hits"):
             # the CPU SAH tree, optionally + insertion-based optimisation (glrt_bvh_reinsert), optionally + the children of every fork ordered by the closest hits of a
             # calibration frame (glrtx_hit_histogram: one 480x270 frame of this camera counted by the render kernel; glrt_bvh_order_by_hits)
@@ -345,7 +349,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="headline", help="headline | c2 | c3 | c4 | c5 (parity-test configs)")
-    ap.add_argument("--bvh", default="default", help="default (the config's CPU SAH tree) | lbvh (linear BVH built on the GPU, glrtx_build_lbvh) | sah-gpu (binned SAH built on the GPU, glrtx_build_bvh_sah) | sah-reinsert (the CPU SAH tree + glrt_bvh_reinsert) | sah-hits, sah-reinsert-hits (+ every fork's children ordered by the hits of a calibration frame: glrtx_hit_histogram, glrt_bvh_order_by_hits)")
+    ap.add_argument("--bvh", default="default", help="default (the config's CPU SAH tree) | lbvh (linear BVH built on the GPU, glrtx_build_lbvh) | sah-gpu (binned SAH built on the GPU, glrtx_build_bvh_sah) | sah-reinsert (the CPU SAH tree + glrt_bvh_reinsert) | sah-hits, sah-reinsert-hits (+ every fork's children ordered by the hits of a calibration frame: glrtx_hit_histogram, glrt_bvh_order_by_hits) | reference (the reference host's own tree, its builder restated: glrt_bvh_build_reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-llvmpipe", action="store_true", help="skip the llvmpipe leg of cpu_baseline (the repository's own GLSL port through oracle/glref)")

@@ -6,6 +6,8 @@
  *
  * Reference interfaces replaced:
  *   glrt_bvh_build_sah      BVH::construct / constructRec   src/core/bvh.cpp:59-160
+ *   glrt_bvh_build_reference  the same pair, restated rule for rule: the reference host's OWN tree (opt-in: exact ties and
+ *                            grazing-ray box misses then fall where the reference host's would; parity unpinned, see below)
  *   glrt_bvh_build_lbvh     same role, linear BVH for large scenes (BASELINE config 5)
  *   glrt_bvh_build_chain    (no counterpart: expresses BASELINE config "brute force, no BVH"
  *                            in the same node format)
@@ -48,6 +50,14 @@ size_t glrt_bvh_node_count(size_t n_tri);
 int glrt_bvh_build_sah(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
                        int *max_depth_out);
 int glrt_bvh_build_chain(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out);
+/* The tree the reference's own host builds (BVH::constructRec, src/core/bvh.cpp:72-160 with bvh.h:11-82), restated rule for rule: longest centroid axis only,
+ * std::nth_element at the middle for <= 8 triangles, 16 buckets + std::partition above, the cut at the unsorted middle when no bucket split pays, boxes accumulated from
+ * +-1e8, nodes in pre-order.  A closest hit depends on the tree only at exact ties and at grazing-ray box misses: under this tree both fall where
+ * the reference host's do -- to the extent that libstdc++'s nth_element / partition order is the reference build's (same toolchain: yes).  It is a worse tree than
+ * glrt_bvh_build_sah's (one axis binned) and is never improved behind the caller's back: glrt::Scene applies neither glrt_bvh_lights_first nor any other re-ordering to it.
+ * PARITY UNPINNED: the reference host is unbuildable here, no tree of its making exists to compare with.  Same arguments and return codes as
+ * glrt_bvh_build_sah. */
+int glrt_bvh_build_reference(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out, int *max_depth_out);
 /* Linear BVH (30-bit Morton order + Karras hierarchy), improved by GLRT_LBVH_ROTATION_PASSES bottom-up sweeps of tree
  * rotations (child <-> grandchild and grandchild <-> grandchild exchanges) and by rebuilding every maximal subtree of at most
  * GLRT_LBVH_REBUILD_LEAVES leaves with the exact sweep SAH.  Same output, bit for bit, as the GPU builder glrtx_build_lbvh (include/glrtx.h); internal node i at index i,

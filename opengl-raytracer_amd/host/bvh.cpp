@@ -1163,4 +1163,146 @@ int glrt_bvh_build_chain(const float *vert, size_t n_vert, const float *tri, siz
     return GLRT_HOST_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- the reference host's own tree
+// glrt_bvh_build_reference: the tree the reference's host would hand its shader for these triangles -- BVH::construct / constructRec (src/core/bvh.cpp:59-160) with the
+// Bounds / TriangleInfo arithmetic of bvh.h:11-82 -- restated, for hosts that want the reference's OWN choices where the image depends on the tree: which of two exactly
+// tied triangles a ray reports, and at which pixels a grazing ray misses a flat box.  The other builders here make better trees; this one makes that one.
+// The rule (every rounding as the reference's expressions perform it):
+//   * a triangle's box is min / max over its three vertices, its centroid ((v0 + v1) + v2) / 3.0f per component (bvh.h:58-75);
+//   * a node's box is the union of its triangles' boxes, accumulated from +-1e8, not +-inf (bvh.h:12-15): coordinates beyond 1e8 are clipped exactly as there;
+//   * the split axis is the widest axis of the centroids' box, x before y before z at equal spans (bvh.h:36-44);
+//   * up to 8 triangles: std::nth_element at (left + right) / 2 by centroid[axis] (:100-104);
+//   * more: 16 buckets along that axis ONLY -- the bucket of a centroid from the FLOAT difference to the box's minimum, widened to double, times
+//     16 / (|max - min| + 1e-8) in double (:110-121); cost of splitting behind bucket i = 0.125 + float((n0 area0 + n1 area1) / area) (:123-136), the first minimum
+//     wins (:138-145); if that cost is below the triangle count the range is std::partition-ed by a predicate that computes the bucket AGAIN, this time from the
+//     DOUBLE difference (bvh.cpp:39-47: the two can disagree in the last place at a bucket's edge -- restated as written); otherwise the range is cut at its middle
+//     in the order it has, unsorted (:147-152 leaves `mid` alone);
+//   * nodes in pre-order, the left subtree first (:77-78, :155-157); a leaf holds one triangle.
+// nth_element and partition are the standard library's own (as in the reference): the order they leave equal and unordered elements in is this libstdc++'s, which is
+// the reference's when it is built with the same toolchain.  PARITY UNPINNED: the reference's host cannot be built here, so no tree of its making exists
+// to compare with; tests/test_host.py checks the rule level by level against a numpy statement of the same arithmetic.
+// Where the reference itself has no defined outcome this builder stays defined: a bucket index that is not a number in range goes to bucket 0 / 15 (the reference
+// indexes out of bounds), a NaN centroid is ordered as 0 by the nth_element, and a partition that leaves one side empty (the reference recurses for ever) is replaced by the cut at the middle.
+namespace reftree {
+struct Extent {  // bvh.h:11-56
+    float lo[3] = {1.0e8f, 1.0e8f, 1.0e8f}, hi[3] = {-1.0e8f, -1.0e8f, -1.0e8f};
+    void take(const float *p) {
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+    }
+    void take(const Extent &o) {
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], o.lo[a]); hi[a] = std::max(hi[a], o.hi[a]); }
+    }
+    int widest() const {
+        const float sx = std::abs(hi[0] - lo[0]), sy = std::abs(hi[1] - lo[1]), sz = std::abs(hi[2] - lo[2]);
+        const float m = std::max(sx, std::max(sy, sz));
+        return m == sx ? 0 : (m == sy ? 1 : 2);
+    }
+    float area() const {
+        const float sx = std::abs(hi[0] - lo[0]), sy = std::abs(hi[1] - lo[1]), sz = std::abs(hi[2] - lo[2]);
+        return 2.0f * (sx * sy + sy * sz + sz * sx);
+    }
+};
+struct Face {
+    int index;
+    float c[3];
+    Extent box;
+};
+constexpr int kBuckets = 16;
+inline int clamp_bucket(double x) {  // static_cast<int> of the reference, kept in range where that cast is undefined
+    if (!(x >= 0.0)) return 0;
+    return x >= (double)kBuckets ? kBuckets : (int)x;
+}
+}  // namespace reftree
+
+int glrt_bvh_build_reference(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out, int *max_depth_out) {
+    using namespace reftree;
+    if (!vert || !tri || !nodes_out || n_tri == 0) return GLRT_HOST_EINVAL;
+    if (n_tri > (size_t)1 << 29) return GLRT_HOST_EINVAL;
+    std::vector<Face> f(n_tri);
+    for (size_t t = 0; t < n_tri; t++) {
+        const float *v[3];
+        for (int k = 0; k < 3; k++) {
+            const float fi = tri[4 * t + k];
+            if (!(fi >= 0.f) || (size_t)fi >= n_vert) return GLRT_HOST_EINDEX;
+            v[k] = vert + GLRT_VERTEX_FLOATS * (size_t)fi;
+        }
+        Face &x = f[t];
+        x.index = (int)t;
+        for (int a = 0; a < 3; a++) {
+            x.box.lo[a] = std::min(v[0][a], std::min(v[1][a], v[2][a]));
+            x.box.hi[a] = std::max(v[0][a], std::max(v[1][a], v[2][a]));
+            x.c[a] = (v[0][a] + v[1][a] + v[2][a]) / 3.0f;
+        }
+    }
+    struct Job { int l, r, node, depth; };
+    std::vector<Job> todo;
+    todo.push_back({0, (int)n_tri, 0, 0});
+    int deepest = 0;
+    while (!todo.empty()) {
+        const Job j = todo.back();
+        todo.pop_back();
+        const int l = j.l, r = j.r, count = r - l;
+        Extent all;
+        for (int i = l; i < r; i++) all.take(f[i].box);
+        float *out = nodes_out + 9 * (size_t)j.node;
+        for (int a = 0; a < 3; a++) { out[a] = all.lo[a]; out[3 + a] = all.hi[a]; }
+        deepest = std::max(deepest, j.depth);
+        if (count == 1) {
+            out[6] = -1.f; out[7] = -1.f; out[8] = (float)f[l].index;
+            continue;
+        }
+        Extent cb;
+        for (int i = l; i < r; i++) cb.take(f[i].c);
+        const int axis = cb.widest();
+        int mid = (l + r) / 2;
+        if (count <= 8) {
+            // (a centroid that is not a number is ordered as 0: with the bare `<` of :12-14 such input breaks the strict weak order nth_element relies on -- undefined in the reference)
+            auto key = [axis](const Face &x) { const float c = x.c[axis]; return c == c ? c : 0.0f; };
+            std::nth_element(f.begin() + l, f.begin() + mid, f.begin() + r, [&key](const Face &x, const Face &y) { return key(x) < key(y); });
+        } else {
+            int cnt[kBuckets] = {0};
+            Extent bb[kBuckets];
+            const double cmin = cb.lo[axis], cmax = cb.hi[axis];
+            const double idenom = 1.0 / (std::abs(cmax - cmin) + 1.0e-8);
+            for (int i = l; i < r; i++) {
+                const float numer_f = f[i].c[axis] - cb.lo[axis];  // a float difference, widened afterwards (:113)
+                const double numer = numer_f;
+                int b = clamp_bucket(kBuckets * std::abs(numer) * idenom);
+                if (b == kBuckets) b = kBuckets - 1;
+                cnt[b]++;
+                bb[b].take(f[i].box);
+            }
+            double cost[kBuckets - 1];
+            for (int i = 0; i < kBuckets - 1; i++) {
+                Extent b0, b1;
+                int c0 = 0, c1 = 0;
+                for (int k = 0; k <= i; k++) { b0.take(bb[k]); c0 += cnt[k]; }
+                for (int k = i + 1; k < kBuckets; k++) { b1.take(bb[k]); c1 += cnt[k]; }
+                const float ratio = ((float)c0 * b0.area() + (float)c1 * b1.area()) / all.area();
+                cost[i] = 0.125 + (double)ratio;
+            }
+            double best = cost[0];
+            int split = 0;
+            for (int i = 1; i < kBuckets - 1; i++)
+                if (best > cost[i]) { best = cost[i]; split = i; }
+            if (best < (double)count) {
+                auto it = std::partition(f.begin() + l, f.begin() + r, [&](const Face &x) {
+                    const double diff = std::abs((double)x.c[axis] - cmin);  // a double difference this time (:43)
+                    int b = clamp_bucket(kBuckets * diff * idenom);
+                    if (b >= kBuckets) b = kBuckets - 1;
+                    return b <= split;
+                });
+                const int m = (int)(it - f.begin());
+                if (m != l && m != r) mid = m;  // (an empty side: the reference would never return)
+            }
+        }
+        const int left = j.node + 1, right = j.node + 2 * (mid - l);  // a subtree over k triangles has 2k - 1 nodes
+        out[6] = (float)left; out[7] = (float)right; out[8] = -1.f;
+        todo.push_back({mid, r, right, j.depth + 1});
+        todo.push_back({l, mid, left, j.depth + 1});
+    }
+    if (max_depth_out) *max_depth_out = deepest;
+    return deepest < 63 ? GLRT_HOST_OK : GLRT_HOST_EDEPTH;
+}
+
 }  // extern "C"

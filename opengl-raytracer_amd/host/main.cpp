@@ -14,14 +14,14 @@
 using namespace glrt;
 
 static void usage(const char *exe) {
-    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--bvh sah|sah-reinsert|sah-gpu|lbvh|sah-levels-cpu|lbvh-cpu] [--order-by-hits] [--out file.png] [--save-every-frame] [--device G | --gpus N | --devices a,b,..] [--extensions] [--whitted]\n"
+    std::printf("usage: %s -i scene.json [-s N] [--max-depth D] [--spp N] [--frames F] [--frames-in-flight B] [--bvh sah|sah-reinsert|sah-gpu|lbvh|sah-levels-cpu|lbvh-cpu|reference] [--order-by-hits] [--out file.png] [--save-every-frame] [--device G | --gpus N | --devices a,b,..] [--extensions] [--whitted]\n"
                 "  -i, --input             scene description (JSON; schema: SURVEY.md Appendix C)            [required]\n"
                 "  -s, --sample-per-cycle  accepted for compatibility; like the reference (main.cpp:13) it is not read\n"
                 "      --max-depth D       u_maxDepth (default 16, the reference shader's default)\n"
                 "      --spp N             samples per pixel per frame, u_nSamples (default 1 as window.cpp:239)\n"
                 "      --frames F          frames to accumulate before exiting (default 16)\n"
                 "      --frames-in-flight B frames per launch of the render kernel (default 16; same pixels as 1)\n"
-                "      --bvh KIND          sah (CPU, default) | sah-reinsert (sah + insertion-based optimisation: seconds to build, config 5 renders 3 percent faster) | sah-gpu (binned SAH built on the GPU) | lbvh (linear BVH built on the GPU) | sah-levels-cpu | lbvh-cpu\n"
+                "      --bvh KIND          sah (CPU, default) | sah-reinsert (sah + insertion-based optimisation: seconds to build, config 5 renders 3 percent faster) | sah-gpu (binned SAH built on the GPU) | lbvh (linear BVH built on the GPU) | sah-levels-cpu | lbvh-cpu | reference (the reference host's own tree, its builder restated: exact ties and grazing-ray box misses as under the reference host; a worse tree, never re-ordered)\n"
                 "      --order-by-hits     before the first frame, order every fork's children by the closest hits of one calibration frame (config 5: -1 percent per frame)\n"
                 "      --out file.png      tonemapped output (default output.png, written after the last frame)\n"
                 "      --save-every-frame  write the image after every frame, one frame per launch (the reference's cadence, window.cpp:164)\n"

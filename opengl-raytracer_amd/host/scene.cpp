@@ -167,14 +167,16 @@ void Scene::finalize() {
         // BVH::construct (scene.cpp:251-253 -> bvh.cpp:59-160).  Builders: "sah" (CPU, default), "sah-gpu" (binned SAH by levels + exact sweep below, built on the
         // GPU through glrtx_build_bvh_sah: the CPU SAH tree's quality in ~1.3 ms per 100 k triangles), "lbvh" (linear BVH
         // built on the GPU through glrtx_build_lbvh: 20 % faster to build, ~3 % more traversal steps), "sah-levels-cpu" / "lbvh-cpu" (the same trees from the host library),
-        // "sah-reinsert" ("sah" + glrt_bvh_reinsert: config 5 renders 3 % faster, the build takes seconds).
-        // Any of them renders the same image (only exact ties depend on tree shape).
+        // "sah-reinsert" ("sah" + glrt_bvh_reinsert: config 5 renders 3 % faster, the build takes seconds), "reference" (the reference host's OWN tree, its builder
+        // restated rule for rule -- glrt_host.h: glrt_bvh_build_reference -- and left in its own child order: exact ties and grazing-ray box misses then fall where the
+        // reference host's do).  Any of them renders the same image except at those two kinds of pixels.
         std::string kind = bvhBuilder_;
         if (const char *e = std::getenv("GLRT_BVH")) kind = e;
         nodes.resize(glrt_bvh_node_count(triangles.size()));
         const float *v = &vertices[0].pos[0], *t = &triangles[0].indices[0];
-        if (kind == "sah" || kind == "sah-reinsert" || kind == "lbvh-cpu" || kind == "sah-levels-cpu") {
+        if (kind == "sah" || kind == "sah-reinsert" || kind == "lbvh-cpu" || kind == "sah-levels-cpu" || kind == "reference") {
             const int rc = kind == "sah" || kind == "sah-reinsert" ? glrt_bvh_build_sah(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_)
+                         : kind == "reference" ? glrt_bvh_build_reference(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_)
                          : kind == "lbvh-cpu" ? glrt_bvh_build_lbvh(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_)
                                               : glrt_bvh_build_sah_levels(v, vertices.size(), t, triangles.size(), &nodes[0].bboxMin[0], &bvhDepth_);
             if (rc != GLRT_HOST_OK) GLRT_FatalError("BVH construction (%s) failed (%d)", kind.c_str(), rc);
@@ -199,11 +201,13 @@ void Scene::finalize() {
             GLRT_Info("%s over %zu triangles built on the GPU in %.3f ms (depth %d)", kind == "lbvh" ? "LBVH" : "SAH tree", triangles.size(), ms, bvhDepth_);
             glrtx_destroy(ctx);
         } else {
-            GLRT_FatalError("unknown BVH builder '%s' (sah | sah-reinsert | sah-gpu | lbvh | sah-levels-cpu | lbvh-cpu)", kind.c_str());
+            GLRT_FatalError("unknown BVH builder '%s' (sah | sah-reinsert | sah-gpu | lbvh | sah-levels-cpu | lbvh-cpu | reference)", kind.c_str());
         }
         // the light side first: at a fork where only one child holds emitting triangles that child is visited first (glrt_host.h: glrt_bvh_lights_first)
         const char *lf = std::getenv("GLRT_BVH_LIGHTS_FIRST");
-        if (!(lf && lf[0] == '0' && lf[1] == 0) && !materials.empty()) {
+        if (kind == "reference") {
+            GLRT_Info("BVH: the reference host's own tree (bvh.cpp:72-160 restated), left in its own child order (depth %d)", bvhDepth_);
+        } else if (!(lf && lf[0] == '0' && lf[1] == 0) && !materials.empty()) {
             const int sw = glrt_bvh_lights_first(&nodes[0].bboxMin[0], nodes.size(), t, triangles.size(), &materials[0].type[0], materials.size());
             if (sw < 0) GLRT_FatalError("glrt_bvh_lights_first failed (%d)", sw);
             if (sw > 0) GLRT_Info("BVH: the light side first at %d forks", sw);

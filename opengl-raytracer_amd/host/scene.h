@@ -39,7 +39,7 @@ public:
     size_t numLights() const { return lights.size(); }
     size_t numNodes() const { return nodes.size(); }
     int bvhDepth() const { return bvhDepth_; }
-    // "sah" (default) | "sah-gpu" / "lbvh" (built on the GPU) | "sah-levels-cpu" / "lbvh-cpu"; call before parse().  GLRT_BVH overrides.
+    // "sah" (default) | "sah-gpu" / "lbvh" (built on the GPU) | "sah-levels-cpu" / "lbvh-cpu" | "reference" (the reference host's own tree, never re-ordered); call before parse().  GLRT_BVH overrides.
     void setBvhBuilder(const std::string &kind) { bvhBuilder_ = kind; }
     // EXTENSIONS beyond the reference (parity unpinned; include/glrtx.h).  Off, parse() is the reference's: "dielectric" is an
     // unsupported material (FatalError, scene.cpp:216-218) and a shape that is not "obj" contributes no geometry (scene.cpp:222).

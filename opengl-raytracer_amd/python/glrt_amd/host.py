@@ -30,6 +30,7 @@ def lib():
         L.glrt_bvh_build_lbvh.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_build_sah_levels.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_build_chain.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp]
+        L.glrt_bvh_build_reference.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.POINTER(C.c_int)]
         L.glrt_bvh_lights_first.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t]
         L.glrt_bvh_order_by_hits.argtypes = [fp, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t]
         L.glrt_bvh_add_shadow_hits.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, fp, fp, C.c_size_t]
@@ -69,6 +70,8 @@ def build_bvh(vert: np.ndarray, tri: np.ndarray, kind: str = "sah"):
         rc = L.glrt_bvh_build_lbvh(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
     elif kind == "sahl":  # binned SAH by levels + exact sweep at the bottom: the CPU statement of the device builder glrtx_build_bvh_sah
         rc = L.glrt_bvh_build_sah_levels(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
+    elif kind == "reference":  # the reference host's own tree, restated rule for rule (bvh.cpp:72-160); never re-ordered afterwards
+        rc = L.glrt_bvh_build_reference(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes), C.byref(depth))
     elif kind == "chain":
         rc = L.glrt_bvh_build_chain(_fp(vert), vert.shape[0], _fp(tri), tri.shape[0], _fp(nodes))
         depth.value = 2

@@ -136,7 +136,8 @@ class SceneBuilder:
         light = tri[emissive[mid.astype(np.int64)]]
         built, depth = host.build_bvh(vert, tri, bvh)
         # the light side first (host.lights_first: glrt_bvh_lights_first, as glrt::Scene::parse applies it); `bvh_builder` keeps the builder's own output
-        nodes, swapped = host.lights_first(built, tri, mat) if bvh != "chain" else (built, 0)
+        # (the reference host's own tree -- "reference" -- is never re-ordered: its point is the reference's own visiting order)
+        nodes, swapped = host.lights_first(built, tri, mat) if bvh not in ("chain", "reference") else (built, 0)
         return dict(vert=vert, tri=tri, mat=mat, light=np.ascontiguousarray(light.reshape(-1, 4)), bvh=nodes,
                     bvh_depth=depth, bvh_kind=bvh, bvh_builder=built, bvh_lights_first=swapped)
 
@@ -144,7 +145,7 @@ class SceneBuilder:
 def rebuild_bvh(scene, kind: str):
     s = dict(scene)
     s["bvh_builder"], s["bvh_depth"] = host.build_bvh(scene["vert"], scene["tri"], kind)
-    s["bvh"], s["bvh_lights_first"] = host.lights_first(s["bvh_builder"], scene["tri"], scene["mat"]) if kind != "chain" else (s["bvh_builder"], 0)
+    s["bvh"], s["bvh_lights_first"] = host.lights_first(s["bvh_builder"], scene["tri"], scene["mat"]) if kind not in ("chain", "reference") else (s["bvh_builder"], 0)
     s["bvh_kind"] = kind
     return s
 

@@ -66,18 +66,21 @@ def test_glrt_main_with_gpu_built_lbvh_gives_the_same_image(tmp_path, gpu_device
     b = _c1_builder()
     js = scenes.export_json_obj(b, tmp_path, 96, 64, (0, 3, 9), (0, 1, 0), (0, 1, 0), 40.0)
     imgs = {}
-    for kind in ("sah", "lbvh", "lbvh-cpu", "sah-gpu", "sah-levels-cpu"):
+    for kind in ("sah", "lbvh", "lbvh-cpu", "sah-gpu", "sah-levels-cpu", "reference"):
         out = tmp_path / f"{kind}.png"
         r = subprocess.run([str(PKG / "lib" / "glrt_main"), "-i", str(js), "--max-depth", "3", "--frames", "2", "--bvh", kind,
                             "--out", str(out)], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stdout + r.stderr
         if kind in ("lbvh", "sah-gpu"):
             assert "built on the GPU" in r.stdout
+        if kind == "reference":  # round 6: the reference host's own tree (glrt_bvh_build_reference), never re-ordered
+            assert "the reference host's own tree" in r.stdout and "the light side first" not in r.stdout
         imgs[kind] = np.asarray(Image.open(out)).astype(np.int32)
     assert np.array_equal(imgs["lbvh"], imgs["lbvh-cpu"])
     assert np.array_equal(imgs["sah-gpu"], imgs["sah-levels-cpu"])  # round 5: the binned SAH built on the device == its CPU statement
     assert (np.abs(imgs["sah-gpu"] - imgs["sah"]).max(-1) > 0).mean() < 0.01
     assert (np.abs(imgs["lbvh"] - imgs["sah"]).max(-1) > 0).mean() < 0.01
+    assert (np.abs(imgs["reference"] - imgs["sah"]).max(-1) > 0).mean() < 0.01
 
 
 def test_glrt_main_on_several_partitions_writes_the_identical_png(tmp_path):

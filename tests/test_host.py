@@ -18,7 +18,7 @@ def _tri_boxes(scene):
     return p.min(1), p.max(1)
 
 
-@pytest.mark.parametrize("kind", ["sah", "chain", "lbvh", "sahl"])
+@pytest.mark.parametrize("kind", ["sah", "chain", "lbvh", "sahl", "reference"])
 def test_bvh_is_a_valid_tree_over_all_triangles(kind):
     sc, _ = scenes.config_c3(32, 32, n=700, bvh=kind)
     nodes = _nodes(sc)
@@ -383,7 +383,7 @@ def test_row_partition_is_a_bijection(world, stripe, height):
             assert y == ((i // stripe) * world + r) * stripe + i % stripe
 
 
-@pytest.mark.parametrize("kind", ["sah", "chain", "lbvh", "sahl"])
+@pytest.mark.parametrize("kind", ["sah", "chain", "lbvh", "sahl", "reference"])
 def test_builders_take_non_finite_vertices(kind):
     """Vertices at +-inf, at 3e38 (extents that overflow) and NaN: every builder returns a tree over all triangles that the device layer accepts.  A box's
     centre that is not finite is ordered and binned as 0 (host/bvh.cpp: centre, bin_of); until round 4 the SAH builder indexed its bins with (int)NaN."""
