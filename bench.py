@@ -740,7 +740,8 @@ def main(argv=None):
     profiled_bvh = {"c5": "sah-gpu"}.get(args.config, "default")
     tree_note = None if args.bvh == profiled_bvh else (
         f"the committed counters were taken under --bvh {profiled_bvh}, this run's tree is --bvh {args.bvh}: instructions and bytes per frame follow the steps per ray "
-        "(the CPU and the device SAH trees: within 1 % of each other; reinserted trees: ~4 % fewer), so the issue rooflines and `traffic` of this line are that approximate")
+        "(the CPU and the device SAH trees: within 1 % of each other; reinserted trees: ~4 % fewer; the reference host's own tree: a third MORE on the Cornell scenes, "
+        "profiles/r06_reference_tree.txt), so the issue rooflines and `traffic` of this line are that approximate")
     if prof is not None and prof.get("clock_ghz"):
         frames_equiv = frames_per_launch * len(ys) / H
         sec = kernel_ms * 1e-3
