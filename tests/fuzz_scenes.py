@@ -42,6 +42,9 @@ CASES = [
     (19, 1, "sah", 16, 16, 4, 2, 0.0, {}),
     (20, 2, "chain", 16, 16, 4, 1, 0.0, dict(duplicates=True)),
     (21, 300, "sah", 96, 54, 16, 1, 0.2, {}),
+    # round 6: the reference host's own tree (glrt_bvh_build_reference: one axis binned, never re-ordered) -- ties and flat boxes are where a tree shows in the image
+    (22, 130, "reference", 48, 48, 8, 1, 0.0, dict(duplicates=True)),
+    (23, 70, "reference", 32, 32, 6, 1, 0.0, dict(axis_aligned=True, degenerate=True)),
 ]
 
 

@@ -3,7 +3,8 @@
 one- and two-triangle scenes) to the golden fixtures: same file format and the same renderer (the reference's unmodified
 shader on Mesa llvmpipe through oracle/glref) as make_golden.py.  Build container only.
 
-    python tests/golden/make_golden_fuzz.py
+    python tests/golden/make_golden_fuzz.py [--all]      (without --all only the cases that have no fixture yet are rendered: round 6 added seeds 22 and 23,
+                                                          the reference host's own tree -- glrt_bvh_build_reference -- with duplicated and flat triangles)
 """
 import pathlib
 import sys
@@ -22,6 +23,8 @@ from oracle.glref import GLRef  # noqa: E402
 OUT = pathlib.Path(__file__).resolve().parent
 g = GLRef()
 for case in CASES:
+    if "--all" not in sys.argv and (OUT / f"fuzz_seed{case[0]}.npz").exists():
+        continue
     scene, params = case_scene_and_params(case)
     # one draw from cleared accumulators, as SURVEY.md 8(c) prescribes: across frames the reference re-reads its accumulator
     # through a LINEAR sampler, which at non-power-of-two sizes blends in a neighbour texel at the 1e-6 level (SURVEY F7,
