@@ -59,6 +59,7 @@ def test_fuzz_random_parameters(gpu_device, monkeypatch, seed):
     flags = {k: bool(rng.integers(0, 4) == 0) for k in ("duplicates", "degenerate", "axis_aligned")}
     n_tri = int(rng.integers(1, 400))
     bvh = ("sah", "lbvh", "chain")[int(rng.integers(0, 3))] if n_tri < 120 else ("sah", "lbvh")[int(rng.integers(0, 2))]
+    bvh = os.environ.get("GLRT_FUZZ_BVH", bvh)  # (a soak under one builder, e.g. GLRT_FUZZ_BVH=reference: the seeds' own draws stay what they were)
     w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
     depth, spp = int(rng.integers(0, 17)), int(rng.integers(1, 4))
     aperture = float(rng.choice([0.0, 0.0, 0.1]))
