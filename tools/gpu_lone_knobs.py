@@ -1,6 +1,6 @@
-"""Scratch: lone launches (idle device before and after) of 1 / 20 frames of the headline under run-time knobs."""
+"""Lone launches (idle device before and after) of 1 / 20 frames of the headline under run-time knobs."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "opengl-raytracer_amd", "python"))
 from glrt_amd import device, host, scenes
 sc, pr = scenes.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "headline"]()
