@@ -978,7 +978,8 @@ def main(argv=None):
                        "timed_kernel_image_check": f"bit-identical to the counting kernel's accumulator over the {args.steps} timed steps (untimed replay)",
                        # N = 1: the GPU's accumulator over the first n timed frames against the oracle's (the CPU restatement, pinned by the llvmpipe fixtures)
                        "oracle_image_check": oracle_check,
-                       "run_to_run": "one context = one draw: contexts of one binary differ by up to 3 % with where the path-state buffer lands physically (profiles/r04_context_regimes.txt)",
+                       "run_to_run": "contexts of one binary differ by +-0.5 % since the path state is sized by the launch (round 6, profiles/README.md: r06_lone_knobs; 3 % until round 5 with where a 4.6-GB "
+                                     "path-state buffer landed physically, profiles/r04_context_regimes.txt); box to box the driver's cadence spans 0.96-1.015 ms per frame (profiles/r06_run_to_run.txt)",
                        # strong scaling: the same K frames whatever N is, S frames in flight IN TOTAL per launch, framebuffer gathered after every launch
                        "strong": ({"error": strong_err} if strong_err else None) if strong_s is None else
                            {"frames": args.steps, "frames_in_flight_total": S, "gather": "none" if args.no_gather else "to rank 0 after every launch, overlapped with the next launch",
