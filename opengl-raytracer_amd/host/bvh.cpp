@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -80,6 +81,16 @@ constexpr int kBins = 16;
 // shader's stack is int[64], raytrace.frag:284).
 constexpr int kSahDepthCap = 40;
 
+// What a subtree of n triangles is charged in the split cost (round 6, last session).  The surface-area heuristic charges n -- a leaf of n triangles tests them all --, but
+// every subtree here is built down to ONE triangle per leaf (the wire format), where a subtree of n triangles costs a ray that enters it far less than n: charging
+// n^0.8 makes the builder give up some balance for smaller boxes near the top.  Measured inside one context, trees alternating, images bit-identical
+// (profiles/r06_sah_count_weight.txt): headline -0.6 ... -0.8 %, config 2 -0.8 %, config 4 -0.6 ... -2.5 %, config 5 -0.1 ... -0.3 %; every exponent from 0.65 to 0.85
+// within 0.2 % of the others, 0.5 and below lose it again to depth (0.35: +5 % / +25 %), 1 + log2 n: +26 % / +119 %.  GLRT_SAH_ALPHA=1 restores the plain heuristic (A/B).
+inline float weight(int n) {
+    static const float alpha = [] { const char *e = std::getenv("GLRT_SAH_ALPHA"); const float a = e ? (float)std::atof(e) : 0.8f; return a > 0.0f && a <= 1.0f ? a : 0.8f; }();
+    return alpha == 1.0f ? (float)n : std::pow((float)n, alpha);
+}
+
 struct Builder {
     std::vector<Prim> prims;
     float *nodes;  // 9 floats per node
@@ -140,7 +151,7 @@ struct Builder {
                     acc.grow(bb[k]);
                     c += cnt[k];
                     if (c == 0 || right_cnt[k + 1] == 0) continue;
-                    float cost = acc.half_area() * (float)c + right_area[k + 1] * (float)right_cnt[k + 1];
+                    float cost = acc.half_area() * weight(c) + right_area[k + 1] * weight(right_cnt[k + 1]);
                     if (cost < best) {
                         best = cost;
                         best_axis = a;
