@@ -46,7 +46,9 @@ extern "C" {
 size_t glrt_bvh_node_count(size_t n_tri);
 
 /* vert: n_vert * GLRT_VERTEX_FLOATS, tri: n_tri * 4 (i, j, k, material) as floats.
- * nodes_out: glrt_bvh_node_count(n_tri) * 9 floats.  max_depth_out may be NULL. */
+ * nodes_out: glrt_bvh_node_count(n_tri) * 9 floats.  max_depth_out may be NULL.
+ * glrt_bvh_build_sah: 16 bins on each of the three axes; a subtree of n triangles is charged n^0.8 in the split cost (every subtree ends in one-triangle leaves, where the
+ * surface-area heuristic's n overstates what a ray pays: headline -0.6 ... -0.8 % per frame, profiles/r06_sah_count_weight.txt; GLRT_SAH_ALPHA=1 restores the heuristic). */
 int glrt_bvh_build_sah(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out,
                        int *max_depth_out);
 int glrt_bvh_build_chain(const float *vert, size_t n_vert, const float *tri, size_t n_tri, float *nodes_out);
@@ -81,7 +83,8 @@ int glrt_bvh_build_sah_levels(const float *vert, size_t n_vert, const float *tri
  * glrt::Scene::parse and the Python scene builder apply it after their builder (GLRT_BVH_LIGHTS_FIRST=0 leaves the builder's order). */
 int glrt_bvh_lights_first(float *nodes, size_t n_nodes, const float *tri, size_t n_tri, const float *mat, size_t n_mat);
 /* The order of a fork's children from measured hits: tri_hits[t] = closest hits triangle t collected in a calibration frame (glrtx_hit_histogram, glrtx.h); at every
- * fork the child whose subtree collected more goes into the slot the traversal visits first (raytrace.frag:299-307).  No box and no closest hit changes; exact ties between
+ * fork the child whose subtree collected more hits PER UNIT COST (a subtree of n triangles is charged n^0.5; GLRT_HITS_COST_EXP overrides, 0 = hits alone: round 6's first
+ * form, which sent every ray through the bigger child first on unbalanced trees) goes into the slot the traversal visits first (raytrace.frag:299-307).  No box and no closest hit changes; exact ties between
  * two triangles may resolve to the other one.  Apply it last.  Returns the forks exchanged, or GLRT_HOST_E*. */
 int glrt_bvh_order_by_hits(float *nodes, size_t n_nodes, const uint32_t *tri_hits, size_t n_tri);
 /* The shadow rays' share of a calibration frame's hits, by the reference's sampling rule (raytrace.frag:341-343: a light triangle is drawn uniformly for every shaded

@@ -907,6 +907,13 @@ int glrt_bvh_order_by_hits(float *nodes, size_t n_nodes, const uint32_t *tri_hit
                 if (N[k] >= 0.0f) st.push_back((size_t)N[k]);
     }
     std::vector<uint64_t> hits(n_nodes, 0);
+    std::vector<uint32_t> leaves(n_nodes, 0);
+    // Hits PER UNIT COST decide (a subtree of n triangles is charged n^e, e = 0.5): which of two searches to make first, when the first one's success spares the second,
+    // is a question of probability over cost, not of probability alone.  Hits alone (e = 0, this pass's first form) sent every ray through the bigger child first and cost
+    // config 5 +11.6 % on a less balanced tree; with e = 0.5 / 1: config 5 -1.0 %, config 2 -1.0 / -0.7 %, headline -0.2 / -0.3 %, config 4 +1.4 % (hits alone: -0.75 %),
+    // profiles/r06_hit_order_cost.txt.  GLRT_HITS_COST_EXP overrides (A/B).
+    const char *ee = std::getenv("GLRT_HITS_COST_EXP");
+    const double e = ee ? std::max(0.0, std::atof(ee)) : 0.5;
     int swapped = 0;
     for (size_t q = order.size(); q-- > 0;) {  // children before parents
         const size_t i = order[q];
@@ -914,12 +921,16 @@ int glrt_bvh_order_by_hits(float *nodes, size_t n_nodes, const uint32_t *tri_hit
         if (N[8] >= 0.0f) {
             const size_t t = (size_t)N[8];
             hits[i] = t < n_tri ? tri_hits[t] : 0;
+            leaves[i] = 1;
             continue;
         }
         const bool hx = N[6] >= 0.0f, hy = N[7] >= 0.0f;
         const uint64_t ax = hx ? hits[(size_t)N[6]] : 0, ay = hy ? hits[(size_t)N[7]] : 0;
+        const uint32_t cx = hx ? leaves[(size_t)N[6]] : 0, cy = hy ? leaves[(size_t)N[7]] : 0;
         hits[i] = ax + ay;
-        if (hx && hy && ax > ay) { std::swap(N[6], N[7]); swapped++; }
+        leaves[i] = cx + cy;
+        const bool x_first = e == 0.0 ? ax > ay : (double)ax * std::pow((double)std::max(cy, 1u), e) > (double)ay * std::pow((double)std::max(cx, 1u), e);
+        if (hx && hy && x_first) { std::swap(N[6], N[7]); swapped++; }
     }
     return swapped;
 }

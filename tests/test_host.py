@@ -572,9 +572,16 @@ def test_lights_first_can_be_switched_off(monkeypatch):
     assert sc["bvh_lights_first"] == 0 and np.array_equal(np.asarray(sc["bvh"]), np.asarray(sc["bvh_builder"]))
 
 
-def test_order_by_hits_puts_the_busier_child_first():
-    """glrt_bvh_order_by_hits: at every fork the child whose subtree collected more hits goes into children.y (the slot raytrace.frag:299-307 pops first); equal counts
-    keep the builder's order; boxes, leaves and the set of triangles are untouched.  glrt_bvh_add_shadow_hits adds (all hits) / (light triangles) to every emitter."""
+@pytest.mark.parametrize("exp", ["0", None, "1"])
+def test_order_by_hits_puts_the_busier_child_first(monkeypatch, exp):
+    """glrt_bvh_order_by_hits: at every fork the child whose subtree collected more hits PER UNIT COST (a subtree of n triangles is charged n^e, e = 0.5 by default,
+    GLRT_HITS_COST_EXP; e = 0: hits alone) goes into children.y (the slot raytrace.frag:299-307 pops first); equal scores keep the builder's order; boxes, leaves and the
+    set of triangles are untouched.  glrt_bvh_add_shadow_hits adds (all hits) / (light triangles) to every emitter."""
+    if exp is None:
+        monkeypatch.delenv("GLRT_HITS_COST_EXP", raising=False)
+    else:
+        monkeypatch.setenv("GLRT_HITS_COST_EXP", exp)
+    e = 0.5 if exp is None else float(exp)
     sc, _ = scenes.config_c1(32, 32, subdiv=1)
     nodes = np.asarray(sc["bvh"], np.float32).reshape(-1, 9)
     n_tri = sc["tri"].shape[0]
@@ -586,12 +593,17 @@ def test_order_by_hits_puts_the_busier_child_first():
 
     def subtree_hits(n, i):
         return int(hits[int(n[i, 8])]) if n[i, 8] >= 0 else sum(subtree_hits(n, int(c)) for c in n[i, 6:8] if c >= 0)
+
+    def subtree_leaves(n, i):
+        return 1 if n[i, 8] >= 0 else sum(subtree_leaves(n, int(c)) for c in n[i, 6:8] if c >= 0)
     for i in range(out.shape[0]):
         if out[i, 8] < 0 and out[i, 6] >= 0 and out[i, 7] >= 0:
             hx, hy = subtree_hits(out, int(out[i, 6])), subtree_hits(out, int(out[i, 7]))
-            assert hy >= hx
+            cx, cy = subtree_leaves(out, int(out[i, 6])), subtree_leaves(out, int(out[i, 7]))
+            sx, sy = hx * float(cy) ** e, hy * float(cx) ** e  # hx / cx^e against hy / cy^e, cross-multiplied as the library does
+            assert sy >= sx * (1 - 1e-12)
             assert {out[i, 6], out[i, 7]} == {nodes[i, 6], nodes[i, 7]}
-            if hx == hy:
+            if hx == hy and cx == cy:
                 assert out[i, 6] == nodes[i, 6]
     same, n0 = host.order_by_hits(sc["bvh"], np.zeros(n_tri, np.uint32))
     assert n0 == 0 and np.array_equal(same.reshape(-1, 9), nodes)
