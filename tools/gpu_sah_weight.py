@@ -19,8 +19,9 @@ alphas = (sys.argv[4] if len(sys.argv) > 4 else "1,0.9,0.8,0.7,0.6,0.5,0.35").sp
 sc, pr = scenes.CONFIGS[cfg]()
 trees = {}
 for a in alphas:
-    f = f"/tmp/tree_{cfg}_{a}.pkl"
-    env = dict(os.environ, GLRT_SAH_ALPHA=a)
+    f = f"/tmp/tree_{cfg}_{a.replace('/', '_')}.pkl"
+    parts = a.split("@")  # "0.8" or "0.8@GLRT_SAH_BINS_TOP=32@..." (further builder switches for this variant)
+    env = dict(os.environ, GLRT_SAH_ALPHA=parts[0], **dict(kv.split("=", 1) for kv in parts[1:]))
     subprocess.run([sys.executable, __file__, "--build", cfg, f], env=env, check=True)
     trees[a] = pickle.load(open(f, "rb"))
 d = device.Device()
@@ -45,4 +46,4 @@ base = float(np.median(ms[names[0]]))
 print(f"{cfg}: {F} frames per launch, {rounds} rounds, trees alternated inside one context")
 for k in names:
     m = float(np.median(ms[k]))
-    print(f"  alpha {k:5s} {m:8.4f} ms/frame ({(m / base - 1) * 100:+6.2f} %)  depth {trees[k][1]:3d}  stack {sig[k][2]:3d}  rays {sig[k][0]}  image {sig[k][1]}", flush=True)
+    print(f"  alpha {k:34s} {m:8.4f} ms/frame ({(m / base - 1) * 100:+6.2f} %)  depth {trees[k][1]:3d}  stack {sig[k][2]:3d}  rays {sig[k][0]}  image {sig[k][1]}", flush=True)
