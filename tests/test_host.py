@@ -616,3 +616,39 @@ def test_order_by_hits_puts_the_busier_child_first(monkeypatch, exp):
     assert n_light == sc["light"].shape[0] > 0
     emit = np.array([np.linalg.norm(mat[int(t[3]), 3:6]) != 0 for t in tri])
     assert np.array_equal(h2[~emit], hits[~emit]) and np.all(h2[emit] == hits[emit] + int(hits.sum()) // n_light)
+
+
+def test_sah_count_weight_switch_builds_another_valid_tree():
+    """glrt_bvh_build_sah charges a subtree of n triangles n^0.8 in its split cost (host/bvh.cpp: weight(), profiles/r06_sah_count_weight.txt); GLRT_SAH_ALPHA=1 restores the
+    plain surface-area heuristic.  The switch is read once per process, so the plain tree is built in a child: both are valid trees over all triangles within the depth
+    bound, they differ, and the plain one is the better tree by the plain heuristic's own measure (the sum of its forks' areas weighted by triangle counts)."""
+    import pickle
+    import subprocess
+    import sys
+    code = ("import sys, pickle; sys.path[:0] = %r; from glrt_amd import scenes; import numpy as np; "
+            "sc, _ = scenes.config_c2(16, 16, bvh='sah', subdiv=2); pickle.dump((np.asarray(sc['bvh_builder']), sc['bvh_depth']), sys.stdout.buffer)") % (sys.path[:3],)
+    import os
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=dict(os.environ, GLRT_SAH_ALPHA="1"), timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    plain, plain_depth = pickle.loads(r.stdout)
+    sc, _ = scenes.config_c2(16, 16, bvh="sah", subdiv=2)
+    n_tri = sc["tri"].shape[0]
+    mine = np.asarray(sc["bvh_builder"], np.float32)
+    _tree_ok(mine, n_tri); _tree_ok(plain, n_tri)
+    assert sc["bvh_depth"] < 63 and plain_depth < 63
+    assert not np.array_equal(mine.reshape(-1, 9), np.asarray(plain, np.float32).reshape(-1, 9))
+
+    def linear_cost(nodes):
+        N = np.asarray(nodes, np.float32).reshape(-1, 9)
+        cnt = np.zeros(N.shape[0], np.int64)
+        order, st = [], [0]
+        while st:
+            i = st.pop(); order.append(i)
+            if N[i, 8] < 0:
+                st += [int(N[i, 6]), int(N[i, 7])]
+        for i in reversed(order):
+            cnt[i] = 1 if N[i, 8] >= 0 else cnt[int(N[i, 6])] + cnt[int(N[i, 7])]
+        d = (N[:, 3:6] - N[:, 0:3]).astype(np.float64)
+        area = d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]
+        return float((area * cnt)[N[:, 8] < 0].sum())
+    assert linear_cost(plain) <= linear_cost(mine)
