@@ -1285,11 +1285,11 @@ int glrt_bvh_build_reference(const float *vert, size_t n_vert, const float *tri,
             int cnt[kBuckets] = {0};
             Extent bb[kBuckets];
             const double cmin = cb.lo[axis], cmax = cb.hi[axis];
-            const double idenom = 1.0 / (std::abs(cmax - cmin) + 1.0e-8);
+            const double per_span = 1.0 / (std::abs(cmax - cmin) + 1.0e-8);  // (:112 and :42: the same value in both places)
             for (int i = l; i < r; i++) {
                 const float numer_f = f[i].c[axis] - cb.lo[axis];  // a float difference, widened afterwards (:113)
                 const double numer = numer_f;
-                int b = clamp_bucket(kBuckets * std::abs(numer) * idenom);
+                int b = clamp_bucket(kBuckets * std::abs(numer) * per_span);
                 if (b == kBuckets) b = kBuckets - 1;
                 cnt[b]++;
                 bb[b].take(f[i].box);
@@ -1310,7 +1310,7 @@ int glrt_bvh_build_reference(const float *vert, size_t n_vert, const float *tri,
             if (best < (double)count) {
                 auto it = std::partition(f.begin() + l, f.begin() + r, [&](const Face &x) {
                     const double diff = std::abs((double)x.c[axis] - cmin);  // a double difference this time (:43)
-                    int b = clamp_bucket(kBuckets * diff * idenom);
+                    int b = clamp_bucket(kBuckets * diff * per_span);
                     if (b >= kBuckets) b = kBuckets - 1;
                     return b <= split;
                 });
